@@ -1,0 +1,240 @@
+/* thzgpu.h — C ABI of libthzgpu.so, the MI355X (gfx950) engine for the
+ * data_thread recompute path of unibe-icelab/thz-image-explorer.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * C++/torch types.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference checkout).  A Rust maintainer
+ * binds these with an `extern "C"` block (INTEGRATION.md shows the stub); the
+ * tests bind them with ctypes; the C++ host mirror (thz_image_explorer_amd/host)
+ * sits on top of them.
+ *
+ * Conventions
+ *  - One context per process per GPU; calls on one context are made from one
+ *    thread at a time (the reference's single data thread, data_thread.rs:162).
+ *  - Every function returns THZ_OK (0) or a negative thz_status; it never
+ *    throws or aborts.  thz_last_error() gives the text.  On error device
+ *    buffers named as outputs are unspecified but inputs are untouched, so a
+ *    caller can do what the reference does on failure: keep `input.clone()`.
+ *  - Pointers named d_* are DEVICE pointers (from thz_malloc or any other HIP
+ *    allocation on the context's device); all others are host pointers.
+ *  - Layout is the reference's: cubes are C-order (x, y, t|f) with the last
+ *    axis contiguous (data_container.rs:136-151); complex = interleaved
+ *    {re, im} f32 (num_complex::Complex32).  `npix` = nx*ny traces.
+ *  - Kernels are enqueued on the context's stream; thz_sync() / any D2H copy
+ *    waits for them.
+ */
+#ifndef THZGPU_H
+#define THZGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THZGPU_ABI_VERSION 1
+
+typedef struct thz_ctx thz_ctx;
+
+typedef enum thz_status {
+    THZ_OK = 0,
+    THZ_ERR_INVALID = -1,      /* bad argument / shape */
+    THZ_ERR_UNSUPPORTED = -2,  /* transform length not supported */
+    THZ_ERR_HIP = -3,          /* HIP runtime failure (no GPU, OOM, fault) */
+    THZ_ERR_NOT_READY = -4,    /* geometry / cube not set */
+    THZ_ERR_ABORTED = -5       /* abort flag observed between kernel batches */
+} thz_status;
+
+/* FftWindowType, math_tools.rs:35-46 (same order) */
+typedef enum thz_window_type {
+    THZ_WIN_ADAPTED_BLACKMAN = 0,
+    THZ_WIN_BLACKMAN = 1,
+    THZ_WIN_HANNING = 2,
+    THZ_WIN_HAMMING = 3,
+    THZ_WIN_FLAT_TOP = 4
+} thz_window_type;
+
+/* ConfigContainer.fft_window / fft_window_type, config.rs:171-213 */
+typedef struct thz_window_cfg {
+    int32_t type;   /* thz_window_type */
+    float lower;    /* fft_window[0], ps; default 1.0 */
+    float upper;    /* fft_window[1], ps; default 7.0 */
+} thz_window_cfg;
+
+/* ------------------------------------------------------------------ */
+/* lifecycle                                                           */
+/* ------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device`.  Fails with THZ_ERR_HIP when no
+ * GPU is present — there is no CPU fallback. */
+int thz_create(int device, thz_ctx **out);
+void thz_destroy(thz_ctx *ctx);
+const char *thz_last_error(const thz_ctx *ctx);
+int thz_abi_version(void);
+/* hipStream_t of the context as an opaque pointer (for callers that want to
+ * order their own HIP work, e.g. torch.cuda.ExternalStream). */
+void *thz_stream(thz_ctx *ctx);
+int thz_sync(thz_ctx *ctx);
+
+/* device memory helpers so that a non-HIP caller can own buffers */
+int thz_malloc(thz_ctx *ctx, void **d_ptr, size_t bytes);
+int thz_free(thz_ctx *ctx, void *d_ptr);
+int thz_memcpy_h2d(thz_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int thz_memcpy_d2h(thz_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int thz_memcpy_d2d(thz_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* ------------------------------------------------------------------ */
+/* geometry / plan                                                     */
+/* ------------------------------------------------------------------ */
+
+/* Sets trace length and time axis; builds the transform tables ("plans").
+ * Replaces RealFftPlanner::plan_fft_forward/inverse + the frequency-axis rule
+ * at io.rs:614-621, data_thread.rs:1194-1207, tilt_compensation.rs:206-217:
+ * frequency[i] = i / (time[nt-1] - time[0]), i = 0..nt/2.
+ * Supported nt: powers of two 4..8192 (Stockham path) and any other
+ * 2 <= nt <= 4096 (Bluestein path over the same kernels). */
+int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
+size_t thz_nt(const thz_ctx *ctx);
+size_t thz_nf(const thz_ctx *ctx);
+int thz_get_frequency(const thz_ctx *ctx, float *frequency /* nf */);
+
+/* ------------------------------------------------------------------ */
+/* host-side multiplier vectors (O(nt) work, computed once per call)   */
+/* ------------------------------------------------------------------ */
+
+/* Window multiplier for the fft stage, math_tools.rs:102-198, 356-371:
+ * out[i] = w(time[i]) such that windowed = data * out. */
+int thz_make_fft_window(const thz_ctx *ctx, const thz_window_cfg *cfg, float *out /* nt */);
+
+/* "Time Band Pass" multiplier, band_pass_td_before_fft.rs:124-182 (and
+ * _after_fft.rs): 0 outside [lower,upper), adapted-Blackman taper inside.
+ * The low / high values are clamped in place exactly as the filter clamps its own fields
+ * (:137-138).  lower/upper indices are returned when non-NULL. */
+int thz_make_td_bandpass(const thz_ctx *ctx, double *low, double *high, double window_width,
+                         float *out /* nt */, int64_t *lower, int64_t *upper);
+
+/* "Frequency Band Pass" multiplier, band_pass_fd.rs:135-168 + zero padding
+ * :194-212: 0 outside [lower,upper), taper inside. */
+int thz_make_fd_bandpass(const thz_ctx *ctx, double low, double high, double window_width,
+                         float *out /* nf */, int64_t *lower, int64_t *upper);
+
+/* Tilt compensation's tail taper at zero tilt (tilt_compensation.rs:186-188:
+ * apply_adapted_blackman_window(trace, time, 0.0, 7.0)). */
+int thz_make_tilt_taper(const thz_ctx *ctx, float *out /* nt */);
+
+/* ------------------------------------------------------------------ */
+/* stage kernels (device pointers)                                     */
+/* ------------------------------------------------------------------ */
+
+/* math_tools::fft, math_tools.rs:330-398 (K1+K2+K3), optionally fused with
+ * the Frequency Band Pass multiply, band_pass_fd.rs:184-187 (K4).
+ *   d_in        (npix, nt) f32
+ *   d_win_a/b   (nt) f32 multipliers applied in that order, each may be NULL
+ *   d_data_out  (npix, nt) windowed trace (the stage's `data` output), or NULL
+ *   d_fft       (npix, nf) complex, or NULL
+ *   d_amp       (npix, nf) = |X| (Complex::norm, :384), or NULL
+ *   d_phase     (npix, nf) = numpy_unwrap(arg X, 2*pi) (:387-388), or NULL
+ *   d_fd_mask   (nf) f32 or NULL: when given, d_fft and d_amp are multiplied
+ *               by it (phases are not — band_pass_fd.rs leaves them) */
+int thz_fft(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win_a,
+            const float *d_win_b, float *d_data_out, float *d_fft, float *d_amp, float *d_phase,
+            const float *d_fd_mask);
+
+/* FrequencyDomainBandPass::filter per-pixel part, band_pass_fd.rs:175-212,
+ * in place: fft *= mask, amp *= mask.  Either array may be NULL. */
+int thz_apply_fd_mask(thz_ctx *ctx, size_t npix, float *d_fft, float *d_amp, const float *d_mask);
+
+/* Same with a complex per-bin multiplier (interleaved, nf entries): the
+ * build-defined reference-pulse (Wiener) deconvolution K13.  Bin 0 and, for
+ * even nt, the last bin have their imaginary part forced to 0 so the result
+ * stays a valid C2R input (SURVEY a'-4).  amp *= |mask|. */
+int thz_apply_fd_cmask(thz_ctx *ctx, size_t npix, float *d_fft, float *d_amp,
+                       const float *d_cmask);
+
+/* math_tools::ifft per-pixel part, math_tools.rs:545-568 (K5: C2R then /nt),
+ * optionally fused with a time multiplier (K6, band_pass_td_after_fft.rs) and
+ * the intensity image (K7, data_thread.rs:1288-1307).
+ *   d_fft      (npix, nf) complex
+ *   d_td_win   (nt) or NULL
+ *   d_data_out (npix, nt)
+ *   d_img      (npix) or NULL: sum_t out^2 */
+int thz_ifft(thz_ctx *ctx, size_t npix, const float *d_fft, const float *d_td_win,
+             float *d_data_out, float *d_img);
+
+/* Whole default chain for one cube tile in ONE launch (the hot path):
+ * raw -> *pre window -> R2C -> amp/phase/unwrap -> *fd mask -> store
+ *     -> C2R /nt -> *post window -> store + intensity.
+ * d_pre_win is the composition of every time-domain multiplier in front of
+ * the transform (tilt taper, Time Band Pass, fft window); d_post_win the Time
+ * Band Pass after the inverse.  Output pointers other than d_data_out may be
+ * NULL (not materialised). */
+int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_pre_win,
+                 const float *d_fd_mask, const float *d_post_win, float *d_fft, float *d_amp,
+                 float *d_phase, float *d_data_out, float *d_img);
+
+/* Time multiplier alone (K6): out = in * win; in place allowed. */
+int thz_apply_td_window(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win,
+                        float *d_out);
+
+/* Intensity image (K7), data_thread.rs:1288-1307 / io.rs:588-594. */
+int thz_intensity(thz_ctx *ctx, size_t npix, const float *d_data, float *d_img);
+
+/* Load-time preprocessing, io.rs:578-596: per-trace subtract data[x,y,0],
+ * then intensity.  In place; d_img may be NULL. */
+int thz_subtract_bias(thz_ctx *ctx, size_t npix, float *d_data, float *d_img);
+
+/* Pixel means (K8), math_tools.rs:421-440: mean over x then over y of an
+ * (nx, ny, len*ncomp) f32 array -> len*ncomp values.  ncomp = 2 for complex.
+ * Also used for avg_data (data_thread.rs:1423-1429).
+ * d_out holds *sums* scaled as the reference does: (sum_x / nx) summed over y
+ * / ny.  For multi-GPU tiles use thz_pixel_sum and divide after the
+ * all-reduce. */
+int thz_pixel_mean(thz_ctx *ctx, size_t nx, size_t ny, size_t len, int ncomp, const float *d_arr,
+                   float *d_out);
+int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float *d_arr,
+                  float *d_out);
+
+/* ROI (K9), math_tools.rs:574-661.  Polygon vertices are (x, y) pairs of
+ * u64 as the reference's Vec<(usize, usize)>; arithmetic is u64 with
+ * release-mode wrapping, bit-exact.  mask is (shape0, shape1) u8 indexed
+ * [y * shape1 + x] in the function's own (swapped) coordinates. */
+int thz_roi_mask(thz_ctx *ctx, const uint64_t *poly_xy, size_t n_vertices, uint64_t scaling,
+                 size_t shape0, size_t shape1, uint8_t *d_mask);
+/* mean over masked pixels of data[shape0 - y - 1, x, :] (:647); zeros when
+ * the mask is empty (:656-658).  d_count (u32, may be NULL) gets the pixel
+ * count; with sum_only != 0 the division is skipped (multi-GPU partials). */
+int thz_roi_mean(thz_ctx *ctx, const float *d_arr, size_t shape0, size_t shape1, size_t len,
+                 const uint8_t *d_mask, float *d_out, uint32_t *d_count, int sum_only);
+
+/* math_tools::scaling scale_3d helper, math_tools.rs:273-301 (K10). */
+int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t len, int ncomp,
+                size_t s, float *d_out);
+
+/* Per-stage device time of the most recent call of each kind, the value the
+ * reference shows next to each filter (filter.rs:607-621).  `stage` is one
+ * of the THZ_STAGE_* ids. */
+enum {
+    THZ_STAGE_FFT = 0,
+    THZ_STAGE_FD_MASK = 1,
+    THZ_STAGE_IFFT = 2,
+    THZ_STAGE_PIPELINE = 3,
+    THZ_STAGE_TD_WINDOW = 4,
+    THZ_STAGE_INTENSITY = 5,
+    THZ_STAGE_MEAN = 6,
+    THZ_STAGE_ROI = 7,
+    THZ_STAGE_COUNT = 8
+};
+/* Enables hipEvent bracketing of every stage call (off by default). */
+int thz_enable_timing(thz_ctx *ctx, int enable);
+int thz_stage_time_ns(thz_ctx *ctx, int stage, uint64_t *ns);
+
+/* Kernel variant actually used for the current nt ("stockham-lds-r2", …),
+ * for logs and for the tests that assert the native path ran. */
+const char *thz_kernel_variant(const thz_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THZGPU_H */

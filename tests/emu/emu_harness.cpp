@@ -1,0 +1,53 @@
+// emu_harness.cpp — C entry points over the product's kernel launchers,
+// built with -DTHZ_EMU (host threads instead of a GPU).  TEST INFRASTRUCTURE
+// ONLY: lets tests/test_emu_kernels.py check the kernels' index arithmetic in a
+// container without a GPU.  "Device" pointers are host pointers here.
+#include "plan_host.hpp"
+
+using namespace thz;
+
+extern "C" {
+
+int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const float *wb,
+                float *data_out, float *fft, float *amp, float *ph, const float *mask)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H)) return -2;
+    PlanDev D = plan_dev(H, H.tw.data(), H.tw_split.data(), H.chirp_conj.data(), H.bfft.data());
+    launch_fft_fwd(nullptr, D, npix, in, wa, wb, data_out, (c32 *)fft, amp, ph, mask);
+    return 0;
+}
+
+int emu_fft_inv(int nt, size_t npix, const float *fft, const float *win, float *out, float *img)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H)) return -2;
+    PlanDev D = plan_dev(H, H.tw.data(), H.tw_split.data(), H.chirp_conj.data(), H.bfft.data());
+    launch_fft_inv(nullptr, D, npix, (const c32 *)fft, win, out, img);
+    return 0;
+}
+
+int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const float *mask,
+                 const float *post, float *fft, float *amp, float *ph, float *out, float *img)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H)) return -2;
+    if (H.mode != kModePow2) return -2;
+    PlanDev D = plan_dev(H, H.tw.data(), H.tw_split.data(), H.chirp_conj.data(), H.bfft.data());
+    launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img);
+    return 0;
+}
+
+int emu_intensity(size_t npix, int nt, float *data, float *img, int subtract_bias)
+{
+    launch_intensity(nullptr, npix, nt, data, img, subtract_bias);
+    return 0;
+}
+
+int emu_roi_mask(const uint64_t *poly, int n, uint64_t x_min, uint64_t x_max, uint64_t y_min,
+                 uint64_t y_max, uint64_t x_size, uint64_t y_size, uint8_t *mask)
+{
+    launch_roi_mask(nullptr, poly, n, x_min, x_max, y_min, y_max, x_size, y_size, mask);
+    return 0;
+}
+}

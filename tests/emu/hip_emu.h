@@ -1,0 +1,132 @@
+// hip_emu.h — minimal host emulation of the HIP constructs the thz kernels use.
+//
+// TEST INFRASTRUCTURE ONLY.  tests/emu/build_emu.py compiles the product's
+// csrc/kernels.hip with -DTHZ_EMU against this header so that the kernels'
+// index arithmetic (LDS exchanges, lane->bin maps, scans) can be checked on a
+// CPU-only container.  Every lane is a host thread; blocks run one after the
+// other; wave_sync()/__syncthreads() are pthread barriers.  It is slow and it
+// is never linked into libthzgpu.so.
+#pragma once
+
+#include <pthread.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __align__(n) __attribute__((aligned(n)))
+
+typedef void *hipStream_t;
+
+struct float2 {
+    float x, y;
+};
+struct float4 {
+    float x, y, z, w;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+namespace thz_emu {
+
+struct Dim3 {
+    unsigned x = 1, y = 1, z = 1;
+};
+
+inline thread_local Dim3 t_threadIdx, t_blockIdx;
+inline Dim3 g_blockDim, g_gridDim;
+inline unsigned char *g_dyn_lds = nullptr;
+
+struct BlockSync {
+    pthread_barrier_t block;
+    std::vector<pthread_barrier_t> waves;
+    std::vector<float> slots;
+};
+inline BlockSync *g_sync = nullptr;
+
+template <class F>
+void run_grid(unsigned grid, unsigned block, size_t lds_bytes, F body)
+{
+    if (block % 64 != 0) {
+        std::fprintf(stderr, "hip_emu: block size must be a multiple of 64\n");
+        std::abort();
+    }
+    g_blockDim.x = block;
+    g_gridDim.x = grid;
+    const unsigned nwaves = block / 64;
+    for (unsigned b = 0; b < grid; ++b) {
+        BlockSync sync;
+        pthread_barrier_init(&sync.block, nullptr, block);
+        sync.waves.resize(nwaves);
+        for (auto &w : sync.waves) pthread_barrier_init(&w, nullptr, 64);
+        sync.slots.assign((size_t)block, 0.f);
+        g_sync = &sync;
+        void *raw = nullptr;
+        if (posix_memalign(&raw, 64, lds_bytes + 64) != 0) std::abort();
+        g_dyn_lds = (unsigned char *)raw;
+        std::memset(g_dyn_lds, 0xCD, lds_bytes + 64);
+        std::vector<std::thread> th;
+        th.reserve(block);
+        for (unsigned t = 0; t < block; ++t) {
+            th.emplace_back([&, t, b]() {
+                t_threadIdx.x = t;
+                t_blockIdx.x = b;
+                body();
+            });
+        }
+        for (auto &x : th) x.join();
+        std::free(raw);
+        g_dyn_lds = nullptr;
+        for (auto &w : sync.waves) pthread_barrier_destroy(&w);
+        pthread_barrier_destroy(&sync.block);
+        g_sync = nullptr;
+    }
+}
+
+}  // namespace thz_emu
+
+#define threadIdx thz_emu::t_threadIdx
+#define blockIdx thz_emu::t_blockIdx
+#define blockDim thz_emu::g_blockDim
+#define gridDim thz_emu::g_gridDim
+
+static inline void __syncthreads() { pthread_barrier_wait(&thz_emu::g_sync->block); }
+
+namespace thz {
+
+inline void wave_sync() { pthread_barrier_wait(&thz_emu::g_sync->waves[threadIdx.x / 64]); }
+inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+inline float wave_shfl(float v, int src)
+{
+    float *s = thz_emu::g_sync->slots.data() + (threadIdx.x / 64) * 64;
+    s[threadIdx.x & 63] = v;
+    wave_sync();
+    float r = s[src & 63];
+    wave_sync();
+    return r;
+}
+inline float wave_shfl_up(float v, int d)
+{
+    int l = lane_id();
+    float r = wave_shfl(v, l - d >= 0 ? l - d : l);
+    return r;
+}
+inline float wave_shfl_xor(float v, int m) { return wave_shfl(v, lane_id() ^ m); }
+
+}  // namespace thz
+
+#define THZ_DYN_LDS(name) unsigned char *name = thz_emu::g_dyn_lds
+
+#define THZ_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+    thz_emu::run_grid((unsigned)(grid), (unsigned)(block), (size_t)(lds_bytes), [&]() { kernel(__VA_ARGS__); })

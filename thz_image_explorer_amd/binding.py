@@ -1,0 +1,287 @@
+"""ctypes binding of libthzgpu.so (include/thzgpu.h).
+
+Test / bench harness glue only: the product is the C-ABI library.  There is no
+CPU fallback — if the library is missing or no GPU is visible, loading or
+`Engine()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libthzgpu.so")
+
+THZ_OK = 0
+STATUS = {0: "THZ_OK", -1: "THZ_ERR_INVALID", -2: "THZ_ERR_UNSUPPORTED", -3: "THZ_ERR_HIP",
+          -4: "THZ_ERR_NOT_READY", -5: "THZ_ERR_ABORTED"}
+
+WIN_ADAPTED_BLACKMAN, WIN_BLACKMAN, WIN_HANNING, WIN_HAMMING, WIN_FLAT_TOP = range(5)
+STAGE_FFT, STAGE_FD_MASK, STAGE_IFFT, STAGE_PIPELINE, STAGE_TD_WINDOW, STAGE_INTENSITY, \
+    STAGE_MEAN, STAGE_ROI = range(8)
+
+
+class WindowCfg(C.Structure):
+    _fields_ = [("type", C.c_int32), ("lower", C.c_float), ("upper", C.c_float)]
+
+
+class ThzError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+# every symbol include/thzgpu.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SZ = C.c_size_t
+SYMBOLS = [
+    ("thz_abi_version", C.c_int, []),
+    ("thz_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("thz_destroy", None, [_P]),
+    ("thz_last_error", C.c_char_p, [_P]),
+    ("thz_stream", _P, [_P]),
+    ("thz_sync", C.c_int, [_P]),
+    ("thz_malloc", C.c_int, [_P, C.POINTER(_P), _SZ]),
+    ("thz_free", C.c_int, [_P, _P]),
+    ("thz_memcpy_h2d", C.c_int, [_P, _P, _P, _SZ]),
+    ("thz_memcpy_d2h", C.c_int, [_P, _P, _P, _SZ]),
+    ("thz_memcpy_d2d", C.c_int, [_P, _P, _P, _SZ]),
+    ("thz_memset", C.c_int, [_P, _P, C.c_int, _SZ]),
+    ("thz_set_time_axis", C.c_int, [_P, _P, _SZ]),
+    ("thz_nt", _SZ, [_P]),
+    ("thz_nf", _SZ, [_P]),
+    ("thz_get_frequency", C.c_int, [_P, _P]),
+    ("thz_make_fft_window", C.c_int, [_P, C.POINTER(WindowCfg), _P]),
+    ("thz_make_td_bandpass", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                       _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("thz_make_fd_bandpass", C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("thz_make_tilt_taper", C.c_int, [_P, _P]),
+    ("thz_fft", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("thz_apply_fd_mask", C.c_int, [_P, _SZ, _P, _P, _P]),
+    ("thz_apply_fd_cmask", C.c_int, [_P, _SZ, _P, _P, _P]),
+    ("thz_ifft", C.c_int, [_P, _SZ, _P, _P, _P, _P]),
+    ("thz_pipeline", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("thz_apply_td_window", C.c_int, [_P, _SZ, _P, _P, _P]),
+    ("thz_intensity", C.c_int, [_P, _SZ, _P, _P]),
+    ("thz_subtract_bias", C.c_int, [_P, _SZ, _P, _P]),
+    ("thz_pixel_mean", C.c_int, [_P, _SZ, _SZ, _SZ, C.c_int, _P, _P]),
+    ("thz_pixel_sum", C.c_int, [_P, _SZ, _SZ, C.c_int, _P, _P]),
+    ("thz_roi_mask", C.c_int, [_P, _P, _SZ, C.c_uint64, _SZ, _SZ, _P]),
+    ("thz_roi_mean", C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _P, _P, C.c_int]),
+    ("thz_scale3d", C.c_int, [_P, _P, _SZ, _SZ, _SZ, C.c_int, _SZ, _P]),
+    ("thz_enable_timing", C.c_int, [_P, C.c_int]),
+    ("thz_stage_time_ns", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
+    ("thz_kernel_variant", C.c_char_p, [_P]),
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libthzgpu.so and declares every prototype.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DevBuf:
+    """A device allocation owned through thz_malloc/thz_free."""
+
+    def __init__(self, eng: "Engine", nbytes: int):
+        self.eng = eng
+        self.nbytes = int(nbytes)
+        p = _P()
+        eng._check(eng.lib.thz_malloc(eng.ctx, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.eng.lib.thz_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+    def upload(self, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        self.eng._check(self.eng.lib.thz_memcpy_h2d(self.eng.ctx, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.eng._check(self.eng.lib.thz_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        self.eng._check(self.eng.lib.thz_memset(self.eng.ctx, self.ptr, 0, self.nbytes))
+        return self
+
+
+def _dp(x) -> Optional[int]:
+    """device pointer of a DevBuf / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, DevBuf):
+        return x.ptr
+    return int(x)
+
+
+class Engine:
+    """One thz_ctx.  Methods are 1:1 with the C entry points."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.ctx = _P()
+        rc = self.lib.thz_create(device, C.byref(self.ctx))
+        if rc != THZ_OK:
+            raise ThzError(rc, "thz_create failed (no HIP device?)")
+        self._bufs = []
+
+    # -- helpers
+    def _check(self, rc: int):
+        if rc != THZ_OK:
+            raise ThzError(rc, self.lib.thz_last_error(self.ctx).decode())
+
+    def close(self):
+        if self.ctx:
+            for b in self._bufs:
+                b.free()
+            self._bufs = []
+            self.lib.thz_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def alloc(self, nbytes: int) -> DevBuf:
+        b = DevBuf(self, nbytes)
+        self._bufs.append(b)
+        return b
+
+    def to_device(self, a: np.ndarray) -> DevBuf:
+        a = np.ascontiguousarray(a)
+        return self.alloc(max(a.nbytes, 4)).upload(a)
+
+    def empty(self, shape, dtype=np.float32) -> DevBuf:
+        return self.alloc(max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 4))
+
+    def sync(self):
+        self._check(self.lib.thz_sync(self.ctx))
+
+    @property
+    def stream(self) -> int:
+        return self.lib.thz_stream(self.ctx) or 0
+
+    # -- plan
+    def set_time_axis(self, time: np.ndarray):
+        t = np.ascontiguousarray(time, np.float32)
+        self._check(self.lib.thz_set_time_axis(self.ctx, t.ctypes.data, t.size))
+        self.nt = int(self.lib.thz_nt(self.ctx))
+        self.nf = int(self.lib.thz_nf(self.ctx))
+
+    def frequency(self) -> np.ndarray:
+        f = np.empty(self.nf, np.float32)
+        self._check(self.lib.thz_get_frequency(self.ctx, f.ctypes.data))
+        return f
+
+    def kernel_variant(self) -> str:
+        return self.lib.thz_kernel_variant(self.ctx).decode()
+
+    # -- host multipliers
+    def make_fft_window(self, wtype=WIN_ADAPTED_BLACKMAN, lower=1.0, upper=7.0) -> np.ndarray:
+        cfg = WindowCfg(int(wtype), float(lower), float(upper))
+        out = np.empty(self.nt, np.float32)
+        self._check(self.lib.thz_make_fft_window(self.ctx, C.byref(cfg), out.ctypes.data))
+        return out
+
+    def make_td_bandpass(self, low: float, high: float, width: float):
+        lo, hi = C.c_double(low), C.c_double(high)
+        l, u = C.c_int64(), C.c_int64()
+        out = np.empty(self.nt, np.float32)
+        self._check(self.lib.thz_make_td_bandpass(self.ctx, C.byref(lo), C.byref(hi), width,
+                                                  out.ctypes.data, C.byref(l), C.byref(u)))
+        return out, lo.value, hi.value, l.value, u.value
+
+    def make_fd_bandpass(self, low: float, high: float, width: float):
+        l, u = C.c_int64(), C.c_int64()
+        out = np.empty(self.nf, np.float32)
+        self._check(self.lib.thz_make_fd_bandpass(self.ctx, low, high, width, out.ctypes.data,
+                                                  C.byref(l), C.byref(u)))
+        return out, l.value, u.value
+
+    def make_tilt_taper(self) -> np.ndarray:
+        out = np.empty(self.nt, np.float32)
+        self._check(self.lib.thz_make_tilt_taper(self.ctx, out.ctypes.data))
+        return out
+
+    # -- stages
+    def fft(self, npix, d_in, win_a=None, win_b=None, data_out=None, fft=None, amp=None,
+            phase=None, fd_mask=None):
+        self._check(self.lib.thz_fft(self.ctx, npix, _dp(d_in), _dp(win_a), _dp(win_b),
+                                     _dp(data_out), _dp(fft), _dp(amp), _dp(phase), _dp(fd_mask)))
+
+    def apply_fd_mask(self, npix, fft, amp, mask):
+        self._check(self.lib.thz_apply_fd_mask(self.ctx, npix, _dp(fft), _dp(amp), _dp(mask)))
+
+    def apply_fd_cmask(self, npix, fft, amp, cmask):
+        self._check(self.lib.thz_apply_fd_cmask(self.ctx, npix, _dp(fft), _dp(amp), _dp(cmask)))
+
+    def ifft(self, npix, fft, td_win, data_out, img=None):
+        self._check(self.lib.thz_ifft(self.ctx, npix, _dp(fft), _dp(td_win), _dp(data_out), _dp(img)))
+
+    def pipeline(self, npix, raw, pre_win, fd_mask, post_win, fft, amp, phase, data_out, img):
+        self._check(self.lib.thz_pipeline(self.ctx, npix, _dp(raw), _dp(pre_win), _dp(fd_mask),
+                                          _dp(post_win), _dp(fft), _dp(amp), _dp(phase),
+                                          _dp(data_out), _dp(img)))
+
+    def apply_td_window(self, npix, d_in, win, d_out):
+        self._check(self.lib.thz_apply_td_window(self.ctx, npix, _dp(d_in), _dp(win), _dp(d_out)))
+
+    def intensity(self, npix, data, img):
+        self._check(self.lib.thz_intensity(self.ctx, npix, _dp(data), _dp(img)))
+
+    def subtract_bias(self, npix, data, img=None):
+        self._check(self.lib.thz_subtract_bias(self.ctx, npix, _dp(data), _dp(img)))
+
+    def pixel_mean(self, nx, ny, length, ncomp, arr, out):
+        self._check(self.lib.thz_pixel_mean(self.ctx, nx, ny, length, ncomp, _dp(arr), _dp(out)))
+
+    def pixel_sum(self, npix, length, ncomp, arr, out):
+        self._check(self.lib.thz_pixel_sum(self.ctx, npix, length, ncomp, _dp(arr), _dp(out)))
+
+    def roi_mask(self, poly_xy, scaling, shape0, shape1, mask):
+        poly = np.ascontiguousarray(poly_xy, np.uint64).reshape(-1, 2)
+        self._check(self.lib.thz_roi_mask(self.ctx, poly.ctypes.data if poly.size else None,
+                                          poly.shape[0], scaling, shape0, shape1, _dp(mask)))
+
+    def roi_mean(self, arr, shape0, shape1, length, mask, out, count=None, sum_only=False):
+        self._check(self.lib.thz_roi_mean(self.ctx, _dp(arr), shape0, shape1, length, _dp(mask),
+                                          _dp(out), _dp(count), int(sum_only)))
+
+    def scale3d(self, arr, nx, ny, length, ncomp, s, out):
+        self._check(self.lib.thz_scale3d(self.ctx, _dp(arr), nx, ny, length, ncomp, s, _dp(out)))
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.thz_enable_timing(self.ctx, int(on)))
+
+    def stage_time_ns(self, stage: int) -> int:
+        v = C.c_uint64()
+        self._check(self.lib.thz_stage_time_ns(self.ctx, stage, C.byref(v)))
+        return v.value

@@ -1,0 +1,544 @@
+// api.cpp — the C ABI of libthzgpu.so (include/thzgpu.h).
+//
+// Thin: argument checks, plan/table ownership, launches on the context's
+// stream.  No CPU compute path exists here — without a HIP device every entry
+// point that would compute returns THZ_ERR_HIP.
+#include "../../include/thzgpu.h"
+
+#include "host_windows.hpp"
+#include "kernels.hpp"
+#include "plan_host.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace thz;
+
+struct thz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<float> time, freq;
+    PlanHost plan_h;
+    PlanDev plan_d{};
+    c32 *d_tables = nullptr;  // one allocation: tw | tw_split | chirp_conj | bfft
+    bool have_plan = false;
+    void *ws = nullptr;  // scratch workspace (pixel means, ROI lists)
+    size_t ws_bytes = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t stage_ns[THZ_STAGE_COUNT] = {0};
+};
+
+namespace {
+
+int fail(thz_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, THZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int use_device(thz_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return THZ_OK;
+}
+
+int ensure_ws(thz_ctx *ctx, size_t bytes)
+{
+    if (ctx->ws_bytes >= bytes) return THZ_OK;
+    if (ctx->ws) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return THZ_OK;
+}
+
+struct StageTimer {
+    thz_ctx *ctx;
+    int stage;
+    StageTimer(thz_ctx *c, int s) : ctx(c), stage(s)
+    {
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    ~StageTimer()
+    {
+        if (!ctx->timing) return;
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
+                ctx->stage_ns[stage] = (uint64_t)((double)ms * 1e6);
+        }
+    }
+};
+
+int check_launch(thz_ctx *ctx)
+{
+    HIP_TRY(ctx, hipGetLastError());
+    return THZ_OK;
+}
+
+int need_plan(thz_ctx *ctx)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return fail(ctx, THZ_ERR_NOT_READY, "thz_set_time_axis has not been called");
+    return use_device(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int thz_abi_version(void) { return THZGPU_ABI_VERSION; }
+
+int thz_create(int device, thz_ctx **out)
+{
+    if (!out) return THZ_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return THZ_ERR_HIP;
+    thz_ctx *ctx = new thz_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return THZ_ERR_HIP;
+    }
+    *out = ctx;
+    return THZ_OK;
+}
+
+void thz_destroy(thz_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *thz_last_error(const thz_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void *thz_stream(thz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int thz_sync(thz_ctx *ctx)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+int thz_malloc(thz_ctx *ctx, void **d_ptr, size_t bytes)
+{
+    if (!ctx || !d_ptr) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return THZ_OK;
+}
+
+int thz_free(thz_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return THZ_OK;
+}
+
+int thz_memcpy_h2d(thz_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !src))) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+int thz_memcpy_d2h(thz_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !d_src))) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+int thz_memcpy_d2d(thz_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !d_src))) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return THZ_OK;
+}
+
+int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes)
+{
+    if (!ctx || (bytes && !d_dst)) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return THZ_OK;
+}
+
+/* ---------------------------------------------------------------- plan */
+
+int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
+{
+    if (!ctx || !time || nt < 2) return fail(ctx, THZ_ERR_INVALID, "time axis needs >= 2 samples");
+    if (int rc = use_device(ctx)) return rc;
+    PlanHost H;
+    if (!build_plan(nt, H))
+        return fail(ctx, THZ_ERR_UNSUPPORTED,
+                    "unsupported trace length " + std::to_string(nt) +
+                        " (powers of two 4..16384, or any length 2..4096)");
+    const size_t n_tw = H.tw.size(), n_sp = H.tw_split.size(), n_ch = H.chirp_conj.size(),
+                 n_bf = H.bfft.size();
+    const size_t total = n_tw + n_sp + n_ch + n_bf;
+    c32 *d = nullptr;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void **)&d, total * sizeof(c32)));
+    std::vector<c32> pack;
+    pack.reserve(total);
+    pack.insert(pack.end(), H.tw.begin(), H.tw.end());
+    pack.insert(pack.end(), H.tw_split.begin(), H.tw_split.end());
+    pack.insert(pack.end(), H.chirp_conj.begin(), H.chirp_conj.end());
+    pack.insert(pack.end(), H.bfft.begin(), H.bfft.end());
+    hipError_t e = hipMemcpy(d, pack.data(), total * sizeof(c32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(ctx, THZ_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
+    }
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    ctx->d_tables = d;
+    ctx->plan_h = H;
+    ctx->plan_d = plan_dev(H, d, n_sp ? d + n_tw : nullptr, n_ch ? d + n_tw + n_sp : nullptr,
+                           n_bf ? d + n_tw + n_sp + n_ch : nullptr);
+    ctx->time.assign(time, time + nt);
+    // frequency axis, io.rs:614-621: i / (t_last - t_first)
+    const float rng = time[nt - 1] - time[0];
+    ctx->freq.resize(nt / 2 + 1);
+    for (size_t i = 0; i < ctx->freq.size(); ++i) ctx->freq[i] = (float)i / rng;
+    ctx->have_plan = true;
+    return THZ_OK;
+}
+
+size_t thz_nt(const thz_ctx *ctx) { return ctx && ctx->have_plan ? ctx->time.size() : 0; }
+size_t thz_nf(const thz_ctx *ctx) { return ctx && ctx->have_plan ? ctx->freq.size() : 0; }
+
+int thz_get_frequency(const thz_ctx *ctx, float *frequency)
+{
+    if (!ctx || !frequency) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
+    std::memcpy(frequency, ctx->freq.data(), ctx->freq.size() * sizeof(float));
+    return THZ_OK;
+}
+
+const char *thz_kernel_variant(const thz_ctx *ctx)
+{
+    return (ctx && ctx->have_plan) ? ctx->plan_h.variant : "";
+}
+
+/* ------------------------------------------------------ host multipliers */
+
+int thz_make_fft_window(const thz_ctx *ctx, const thz_window_cfg *cfg, float *out)
+{
+    if (!ctx || !cfg || !out) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
+    if (cfg->type < 0 || cfg->type > 4) return THZ_ERR_INVALID;
+    fft_window(cfg->type, ctx->time.data(), ctx->time.size(), cfg->lower, cfg->upper, out);
+    return THZ_OK;
+}
+
+int thz_make_td_bandpass(const thz_ctx *ctx, double *low, double *high, double window_width,
+                         float *out, int64_t *lower, int64_t *upper)
+{
+    if (!ctx || !low || !high || !out) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
+    td_bandpass(ctx->time.data(), ctx->time.size(), low, high, window_width, out, lower, upper);
+    return THZ_OK;
+}
+
+int thz_make_fd_bandpass(const thz_ctx *ctx, double low, double high, double window_width,
+                         float *out, int64_t *lower, int64_t *upper)
+{
+    if (!ctx || !out) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
+    fd_bandpass(ctx->freq.data(), ctx->freq.size(), low, high, window_width, out, lower, upper);
+    return THZ_OK;
+}
+
+int thz_make_tilt_taper(const thz_ctx *ctx, float *out)
+{
+    if (!ctx || !out) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
+    adapted_blackman(ctx->time.data(), ctx->time.size(), 0.0f, 7.0f, out);
+    return THZ_OK;
+}
+
+/* ------------------------------------------------------------ stages */
+
+int thz_fft(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win_a,
+            const float *d_win_b, float *d_data_out, float *d_fft, float *d_amp, float *d_phase,
+            const float *d_fd_mask)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_in) return fail(ctx, THZ_ERR_INVALID, "thz_fft: d_in is null");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_FFT);
+    launch_fft_fwd(ctx->stream, ctx->plan_d, npix, d_in, d_win_a, d_win_b, d_data_out,
+                   reinterpret_cast<c32 *>(d_fft), d_amp, d_phase, d_fd_mask);
+    return check_launch(ctx);
+}
+
+int thz_apply_fd_mask(thz_ctx *ctx, size_t npix, float *d_fft, float *d_amp, const float *d_mask)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_mask) return fail(ctx, THZ_ERR_INVALID, "thz_apply_fd_mask: d_mask is null");
+    if (npix == 0 || (!d_fft && !d_amp)) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_FD_MASK);
+    launch_fd_mask(ctx->stream, npix, ctx->plan_d.nf, reinterpret_cast<c32 *>(d_fft), d_amp, d_mask);
+    return check_launch(ctx);
+}
+
+int thz_apply_fd_cmask(thz_ctx *ctx, size_t npix, float *d_fft, float *d_amp, const float *d_cmask)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_cmask) return fail(ctx, THZ_ERR_INVALID, "thz_apply_fd_cmask: d_cmask is null");
+    if (npix == 0 || (!d_fft && !d_amp)) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_FD_MASK);
+    launch_fd_cmask(ctx->stream, npix, ctx->plan_d.nf, ctx->plan_d.nt, reinterpret_cast<c32 *>(d_fft),
+                    d_amp, reinterpret_cast<const c32 *>(d_cmask));
+    return check_launch(ctx);
+}
+
+int thz_ifft(thz_ctx *ctx, size_t npix, const float *d_fft, const float *d_td_win,
+             float *d_data_out, float *d_img)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_fft || !d_data_out) return fail(ctx, THZ_ERR_INVALID, "thz_ifft: null input/output");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_IFFT);
+    launch_fft_inv(ctx->stream, ctx->plan_d, npix, reinterpret_cast<const c32 *>(d_fft), d_td_win,
+                   d_data_out, d_img);
+    return check_launch(ctx);
+}
+
+int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_pre_win,
+                 const float *d_fd_mask, const float *d_post_win, float *d_fft, float *d_amp,
+                 float *d_phase, float *d_data_out, float *d_img)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_raw || !d_data_out) return fail(ctx, THZ_ERR_INVALID, "thz_pipeline: null input/output");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_PIPELINE);
+    if (ctx->plan_d.mode == kModePow2) {
+        launch_pipeline(ctx->stream, ctx->plan_d, npix, d_raw, d_pre_win, d_fd_mask, d_post_win,
+                        reinterpret_cast<c32 *>(d_fft), d_amp, d_phase, d_data_out, d_img);
+        return check_launch(ctx);
+    }
+    // chirp-z lengths: forward and inverse launches; the spectrum has to be
+    // materialised between them
+    if (!d_fft) return fail(ctx, THZ_ERR_INVALID, "thz_pipeline: d_fft is required for this trace length");
+    launch_fft_fwd(ctx->stream, ctx->plan_d, npix, d_raw, d_pre_win, nullptr, nullptr,
+                   reinterpret_cast<c32 *>(d_fft), d_amp, d_phase, d_fd_mask);
+    if (int rc = check_launch(ctx)) return rc;
+    launch_fft_inv(ctx->stream, ctx->plan_d, npix, reinterpret_cast<const c32 *>(d_fft), d_post_win,
+                   d_data_out, d_img);
+    return check_launch(ctx);
+}
+
+int thz_apply_td_window(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win,
+                        float *d_out)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_in || !d_win || !d_out) return fail(ctx, THZ_ERR_INVALID, "thz_apply_td_window: null pointer");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_TD_WINDOW);
+    launch_td_window(ctx->stream, npix, ctx->plan_d.nt, d_in, d_win, d_out);
+    return check_launch(ctx);
+}
+
+int thz_intensity(thz_ctx *ctx, size_t npix, const float *d_data, float *d_img)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_data || !d_img) return fail(ctx, THZ_ERR_INVALID, "thz_intensity: null pointer");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_INTENSITY);
+    launch_intensity(ctx->stream, npix, ctx->plan_d.nt, const_cast<float *>(d_data), d_img, 0);
+    return check_launch(ctx);
+}
+
+int thz_subtract_bias(thz_ctx *ctx, size_t npix, float *d_data, float *d_img)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_data) return fail(ctx, THZ_ERR_INVALID, "thz_subtract_bias: null pointer");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_INTENSITY);
+    launch_intensity(ctx->stream, npix, ctx->plan_d.nt, d_data, d_img, 1);
+    return check_launch(ctx);
+}
+
+int thz_pixel_mean(thz_ctx *ctx, size_t nx, size_t ny, size_t len, int ncomp, const float *d_arr,
+                   float *d_out)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_arr || !d_out || nx == 0 || ny == 0 || len == 0 || (ncomp != 1 && ncomp != 2))
+        return fail(ctx, THZ_ERR_INVALID, "thz_pixel_mean: bad argument");
+    const size_t L = len * (size_t)ncomp;
+    if (int rc = ensure_ws(ctx, ny * L * sizeof(float))) return rc;
+    StageTimer t(ctx, THZ_STAGE_MEAN);
+    float *acc = reinterpret_cast<float *>(ctx->ws);
+    launch_sum_axis0(ctx->stream, d_arr, nx, ny * L, (float)nx, acc);
+    launch_sum_axis0(ctx->stream, acc, ny, L, (float)ny, d_out);
+    return check_launch(ctx);
+}
+
+int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float *d_arr,
+                  float *d_out)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_arr || !d_out || npix == 0 || len == 0 || (ncomp != 1 && ncomp != 2))
+        return fail(ctx, THZ_ERR_INVALID, "thz_pixel_sum: bad argument");
+    const size_t L = len * (size_t)ncomp;
+    // two-level: 256 partial rows, then one
+    const size_t rows = npix < 256 ? 1 : 256;
+    StageTimer t(ctx, THZ_STAGE_MEAN);
+    if (rows == 1) {
+        launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
+        return check_launch(ctx);
+    }
+    if (int rc = ensure_ws(ctx, (rows + 1) * L * sizeof(float))) return rc;
+    float *part = reinterpret_cast<float *>(ctx->ws);
+    const size_t per = npix / rows;  // first rows*per pixels, strided view: row r = pixels r, r+rows, ...
+    // view arr as (per, rows*L): summing axis 0 gives rows*L partials over pixels r + rows*a
+    launch_sum_axis0(ctx->stream, d_arr, per, rows * L, 0.0f, part);
+    const size_t rem = npix - per * rows;
+    if (rem) {
+        // tail pixels: add into one extra partial row
+        launch_sum_axis0(ctx->stream, d_arr + per * rows * L, rem, L, 0.0f, part + rows * L);
+        launch_sum_axis0(ctx->stream, part, rows + 1, L, 0.0f, d_out);
+    } else {
+        launch_sum_axis0(ctx->stream, part, rows, L, 0.0f, d_out);
+    }
+    return check_launch(ctx);
+}
+
+int thz_roi_mask(thz_ctx *ctx, const uint64_t *poly_xy, size_t n_vertices, uint64_t scaling,
+                 size_t shape0, size_t shape1, uint8_t *d_mask)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_mask || shape0 == 0 || shape1 == 0 || scaling == 0 || (n_vertices && !poly_xy))
+        return fail(ctx, THZ_ERR_INVALID, "thz_roi_mask: bad argument");
+    // math_tools.rs:604-637: scale vertices (integer division), bounding box, clamp
+    std::vector<uint64_t> poly(2 * (n_vertices ? n_vertices : 1), 0);
+    uint64_t x_min = UINT64_MAX, y_min = UINT64_MAX, x_max = 0, y_max = 0;
+    for (size_t i = 0; i < n_vertices; ++i) {
+        const uint64_t x = poly_xy[2 * i] / scaling, y = poly_xy[2 * i + 1] / scaling;
+        poly[2 * i] = x;
+        poly[2 * i + 1] = y;
+        if (x < x_min) x_min = x;
+        if (y < y_min) y_min = y;
+        if (x > x_max) x_max = x;
+        if (y > y_max) y_max = y;
+    }
+    const uint64_t x_size = shape1, y_size = shape0;
+    if (x_min > x_size - 1) x_min = x_size - 1;
+    if (y_min > y_size - 1) y_min = y_size - 1;
+    if (x_max > x_size - 1) x_max = x_size - 1;
+    if (y_max > y_size - 1) y_max = y_size - 1;
+    if (int rc = ensure_ws(ctx, poly.size() * sizeof(uint64_t))) return rc;
+    StageTimer t(ctx, THZ_STAGE_ROI);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, poly.data(), poly.size() * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `poly` is a stack-lifetime vector
+    launch_roi_mask(ctx->stream, reinterpret_cast<const uint64_t *>(ctx->ws), (int)n_vertices, x_min,
+                    x_max, y_min, y_max, x_size, y_size, d_mask);
+    if (int rc = check_launch(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // workspace is reused by the next call
+    return THZ_OK;
+}
+
+int thz_roi_mean(thz_ctx *ctx, const float *d_arr, size_t shape0, size_t shape1, size_t len,
+                 const uint8_t *d_mask, float *d_out, uint32_t *d_count, int sum_only)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_arr || !d_mask || !d_out || shape0 == 0 || shape1 == 0 || len == 0)
+        return fail(ctx, THZ_ERR_INVALID, "thz_roi_mean: bad argument");
+    std::vector<uint8_t> mask(shape0 * shape1);
+    HIP_TRY(ctx, hipMemcpyAsync(mask.data(), d_mask, mask.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // math_tools.rs:640-651: y outer, x inner; sampled pixel is [shape0 - y - 1, x]
+    std::vector<uint32_t> list;
+    for (size_t y = 0; y < shape0; ++y)
+        for (size_t x = 0; x < shape1; ++x)
+            if (mask[y * shape1 + x]) list.push_back((uint32_t)((shape0 - y - 1) * shape1 + x));
+    const uint32_t count = (uint32_t)list.size();
+    if (d_count) HIP_TRY(ctx, hipMemcpyAsync(d_count, &count, sizeof(count), hipMemcpyHostToDevice, ctx->stream));
+    StageTimer t(ctx, THZ_STAGE_ROI);
+    if (count == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, len * sizeof(float), ctx->stream));  // :656-658
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return THZ_OK;
+    }
+    if (int rc = ensure_ws(ctx, list.size() * sizeof(uint32_t))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, list.data(), list.size() * sizeof(uint32_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    launch_gather_sum(ctx->stream, d_arr, len, reinterpret_cast<const uint32_t *>(ctx->ws), count,
+                      sum_only ? 0.0f : (float)count, d_out);
+    if (int rc = check_launch(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t len, int ncomp,
+                size_t s, float *d_out)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_arr || !d_out || s == 0 || nx / s == 0 || ny / s == 0 || len == 0 ||
+        (ncomp != 1 && ncomp != 2))
+        return fail(ctx, THZ_ERR_INVALID, "thz_scale3d: bad argument");
+    launch_scale3d(ctx->stream, d_arr, nx, ny, len * (size_t)ncomp, s, d_out);
+    return check_launch(ctx);
+}
+
+int thz_enable_timing(thz_ctx *ctx, int enable)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    ctx->timing = enable != 0;
+    return THZ_OK;
+}
+
+int thz_stage_time_ns(thz_ctx *ctx, int stage, uint64_t *ns)
+{
+    if (!ctx || !ns || stage < 0 || stage >= THZ_STAGE_COUNT) return THZ_ERR_INVALID;
+    *ns = ctx->stage_ns[stage];
+    return THZ_OK;
+}
+
+}  // extern "C"

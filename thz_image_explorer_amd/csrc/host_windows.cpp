@@ -1,0 +1,112 @@
+// host_windows.cpp — O(nt) host-side multiplier vectors for the stage kernels.
+//
+// The reference evaluates its window formulas once per trace inside the pixel
+// loops; the value only depends on the time/frequency axis, so the engine
+// evaluates each formula once per call on the host, in the reference's f32
+// operation order, and the kernels multiply by the resulting vector.
+// Built with -ffp-contract=off (no FMA where the Rust code has mul then add).
+#include "host_windows.hpp"
+
+#include <cmath>
+#include <limits>
+
+namespace thz {
+
+static const float kPiF = 3.14159274101257324219f;  // std::f32::consts::PI
+
+// blackman_window, math_tools.rs:81-90
+static float blackman_window(float n, float m)
+{
+    const float res = 0.42f - 0.5f * std::cos(2.0f * kPiF * n / m) + 0.08f * std::cos(4.0f * kPiF * n / m);
+    if (std::isnan(res)) return 1.0f;
+    return res < 0.0f ? 0.0f : (res > 1.0f ? 1.0f : res);
+}
+
+// apply_adapted_blackman_window on a vector of ones, math_tools.rs:102-122.
+// `axis` is the slice the reference passes (its own first/last coordinates are
+// the taper origins).
+void adapted_blackman(const float *axis, size_t len, float lower, float upper, float *out)
+{
+    if (len == 0) return;
+    const float a0 = axis[0], an = axis[len - 1];
+    for (size_t i = 0; i < len; ++i) {
+        const float t = axis[i];
+        float w = 1.0f;
+        if (t <= lower + a0) {
+            w = blackman_window(t - a0, 2.0f * lower);
+        } else if (t >= an - upper) {
+            w = blackman_window(t - (an - upper * 2.0f), 2.0f * upper);
+        }
+        out[i] = w;
+    }
+}
+
+// apply_hamming / hanning / blackman / flat_top, math_tools.rs:131-198
+void fft_window(int type, const float *time, size_t nt, float lower, float upper, float *out)
+{
+    if (type == 0) {  // AdaptedBlackman, math_tools.rs:357-364
+        adapted_blackman(time, nt, lower, upper, out);
+        return;
+    }
+    float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < nt; ++i) {
+        mn = std::fmin(mn, time[i]);
+        mx = std::fmax(mx, time[i]);
+    }
+    for (size_t i = 0; i < nt; ++i) {
+        const float t = (time[i] - mn) / (mx - mn);
+        float w = 1.0f;
+        switch (type) {
+        case 3: w = 0.54f - 0.46f * std::cos(2.0f * kPiF * t); break;                    // Hamming
+        case 2: w = 0.5f * (1.0f - std::cos(2.0f * kPiF * t)); break;                    // Hanning
+        case 1: w = 0.42f - 0.5f * std::cos(2.0f * kPiF * t) + 0.08f * std::cos(4.0f * kPiF * t); break;
+        case 4:
+            w = 1.0f - 1.93f * std::cos(2.0f * kPiF * t) + 1.29f * std::cos(4.0f * kPiF * t)
+                - 0.388f * std::cos(6.0f * kPiF * t) + 0.028f * std::cos(8.0f * kPiF * t);
+            break;
+        default: break;
+        }
+        out[i] = w;
+    }
+}
+
+// TimeDomainBandPass*::filter index rule, band_pass_td_before_fft.rs:134-152
+void td_bandpass(const float *time, size_t nt, double *low, double *high, double width, float *out,
+                 int64_t *lower_out, int64_t *upper_out)
+{
+    const float min_time = nt ? time[0] : 0.0f, max_time = nt ? time[nt - 1] : 0.0f;
+    if (*low < (double)min_time) *low = (double)min_time;    // self.low.max(min_time)
+    if (*high > (double)max_time) *high = (double)max_time;  // self.high.min(max_time)
+    size_t lower = 0;
+    for (size_t i = 0; i < nt; ++i)
+        if (time[i] >= (float)*low) { lower = i; break; }
+    size_t upper = nt ? nt - 1 : 0;
+    for (size_t i = 0; i < nt; ++i)
+        if (time[i] >= (float)*high) { upper = i; break; }
+    if (upper < lower + 1) upper = lower + 1;
+    if (upper > nt) upper = nt;
+    for (size_t i = 0; i < nt; ++i) out[i] = 0.0f;
+    if (upper > lower) adapted_blackman(time + lower, upper - lower, (float)width, (float)width, out + lower);
+    if (lower_out) *lower_out = (int64_t)lower;
+    if (upper_out) *upper_out = (int64_t)upper;
+}
+
+// FrequencyDomainBandPass::filter index rule + taper, band_pass_fd.rs:134-168
+void fd_bandpass(const float *freq, size_t nf, double low, double high, double width, float *out,
+                 int64_t *lower_out, int64_t *upper_out)
+{
+    const float safe_low = (float)(low > 0.0 ? low : 0.0);
+    const double last = nf ? (double)freq[nf - 1] : 10.0;
+    const float safe_high = (float)(high < last ? high : last);
+    size_t lower = 0, upper = nf;
+    for (size_t i = 0; i < nf; ++i)
+        if (freq[i] >= safe_low) { lower = i; break; }
+    for (size_t i = nf; i-- > 0;)
+        if (freq[i] <= safe_high) { upper = i + 1; break; }
+    for (size_t i = 0; i < nf; ++i) out[i] = 0.0f;
+    if (upper > lower) adapted_blackman(freq + lower, upper - lower, (float)width, (float)width, out + lower);
+    if (lower_out) *lower_out = (int64_t)lower;
+    if (upper_out) *upper_out = (int64_t)upper;
+}
+
+}  // namespace thz

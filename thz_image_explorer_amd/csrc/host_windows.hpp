@@ -1,0 +1,13 @@
+// host_windows.hpp — see host_windows.cpp
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace thz {
+void adapted_blackman(const float *axis, size_t len, float lower, float upper, float *out);
+void fft_window(int type, const float *time, size_t nt, float lower, float upper, float *out);
+void td_bandpass(const float *time, size_t nt, double *low, double *high, double width, float *out,
+                 int64_t *lower_out, int64_t *upper_out);
+void fd_bandpass(const float *freq, size_t nf, double low, double high, double width, float *out,
+                 int64_t *lower_out, int64_t *upper_out);
+}  // namespace thz

@@ -1,0 +1,700 @@
+// kernels.hip — gfx950 kernels of the THz per-pixel engine and their launchers.
+//
+// "G" family (this file): one trace per wavefront, the whole transform staged
+// in that wave's private slice of LDS, Stockham radix-4/2 autosort passes, no
+// workgroup barriers (waves never wait for each other).  It handles every
+// supported trace length: powers of two directly (real transform as a
+// half-length complex transform + split), anything else through Bluestein's
+// chirp-z over the same wave-level complex FFT.
+//
+// Reference arithmetic being replaced (paths relative to the reference):
+//   window + R2C + |.| + arg + unwrap   src/math_tools.rs:330-398, 211-240
+//   frequency band-pass multiply        src/filters/band_pass_fd.rs:184-212
+//   C2R + 1/nt                          src/math_tools.rs:545-568
+//   time band-pass multiply             src/filters/band_pass_td_*.rs:155-175
+//   intensity image                     src/data_thread.rs:1288-1307
+//   pixel means                         src/math_tools.rs:421-440
+//   ROI mask / mean                     src/math_tools.rs:574-661
+//   block-mean scaling                  src/math_tools.rs:273-301
+//   load-time bias subtraction          src/io.rs:578-596
+#include "kernels.hpp"
+
+namespace thz {
+
+// ---------------------------------------------------------------------------
+// wave-level complex FFT in LDS (Stockham autosort, radix-4 then radix-2)
+// a, b: ping-pong buffers of N = 1 << log2n entries, input in a.
+// tw:   W_N^m = exp(-2*pi*i*m/N), m in [0, N)
+// Returns the buffer that holds the result.  Ends with a wave_sync().
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ c32 *wave_cfft(c32 *a, c32 *b, int log2n, const c32 *__restrict__ tw,
+                                          int lane)
+{
+    const int N = 1 << log2n;
+    c32 *src = a, *dst = b;
+    int log2ns = 0;
+    int rem = log2n;
+    while (rem >= 2) {
+        const int Ns = 1 << log2ns;
+        const int q4 = N >> 2;
+        const int tws = N >> (log2ns + 2);  // N / (4*Ns)
+        for (int t = lane; t < q4; t += kWave) {
+            const int k = t & (Ns - 1);
+            c32 u0 = src[t], u1 = src[t + q4], u2 = src[t + 2 * q4], u3 = src[t + 3 * q4];
+            if (log2ns > 0) {
+                u1 = cmul(u1, tw[k * tws]);
+                u2 = cmul(u2, tw[2 * k * tws]);
+                u3 = cmul(u3, tw[3 * k * tws]);
+            }
+            const c32 s02 = cadd(u0, u2), d02 = csub(u0, u2);
+            const c32 s13 = cadd(u1, u3), d13 = csub(u1, u3);
+            const int j = ((t - k) << 2) + k;
+            dst[j] = cadd(s02, s13);
+            dst[j + Ns] = c32{d02.re + d13.im, d02.im - d13.re};
+            dst[j + 2 * Ns] = csub(s02, s13);
+            dst[j + 3 * Ns] = c32{d02.re - d13.im, d02.im + d13.re};
+        }
+        wave_sync();
+        c32 *t_ = src; src = dst; dst = t_;
+        log2ns += 2;
+        rem -= 2;
+    }
+    if (rem == 1) {
+        const int Ns = 1 << log2ns;
+        const int q2 = N >> 1;
+        const int tws = N >> (log2ns + 1);  // N / (2*Ns)
+        for (int t = lane; t < q2; t += kWave) {
+            const int k = t & (Ns - 1);
+            c32 u0 = src[t], u1 = src[t + q2];
+            if (log2ns > 0) u1 = cmul(u1, tw[k * tws]);
+            const int j = ((t - k) << 1) + k;
+            dst[j] = cadd(u0, u1);
+            dst[j + Ns] = csub(u0, u1);
+        }
+        wave_sync();
+        c32 *t_ = src; src = dst; dst = t_;
+    }
+    return src;
+}
+
+// Bluestein core: on entry `a` holds the chirp-premultiplied, zero-padded
+// sequence (M entries).  Leaves c = IFFT_M(FFT_M(a) .* bfft) SWAPPED (re<->im)
+// in the returned buffer; bfft already carries 1/M.
+__device__ __forceinline__ c32 *wave_bluestein_core(c32 *a, c32 *b, const PlanDev &P, int lane)
+{
+    const int M = 1 << P.log2n;
+    c32 *Z = wave_cfft(a, b, P.log2n, P.tw, lane);
+    c32 *other = (Z == a) ? b : a;
+    for (int i = lane; i < M; i += kWave) {
+        const c32 v = cmul(Z[i], P.bfft[i]);
+        Z[i] = c32{v.im, v.re};  // swap: inverse transform through the forward passes
+    }
+    wave_sync();
+    return wave_cfft(Z, other, P.log2n, P.tw, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Shared epilogue of the forward transform: Xb holds the nf spectrum bins in
+// natural order; scratch is an LDS area of >= nf floats no longer in use.
+// Writes fft (masked), |X| (masked), unwrapped phase (never masked).
+// When KEEP_MASKED the masked spectrum is also written back into Xb (the fused
+// pipeline feeds it to the inverse transform).
+// ---------------------------------------------------------------------------
+template <bool KEEP_MASKED>
+__device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int nf, size_t p,
+                                                  c32 *__restrict__ fft_out,
+                                                  float *__restrict__ amp_out,
+                                                  float *__restrict__ ph_out,
+                                                  const float *__restrict__ mask, int lane)
+{
+    const bool want_phase = ph_out != nullptr;
+    for (int k = lane; k < nf; k += kWave) {
+        const c32 X = Xb[k];
+        const float m = mask ? mask[k] : 1.0f;
+        if (amp_out) {
+            const float a = sqrtf(fmaf(X.re, X.re, X.im * X.im));
+            amp_out[p * nf + k] = mask ? a * m : a;
+        }
+        if (want_phase) scratch[k] = atan2f(X.im, X.re);
+        const c32 Xm = mask ? c32{X.re * m, X.im * m} : X;
+        if (fft_out) fft_out[p * nf + k] = Xm;
+        if (KEEP_MASKED) Xb[k] = Xm;
+    }
+    wave_sync();
+    if (!want_phase) return;
+
+    // numpy_unwrap (math_tools.rs:211-240) as a two-level scan: each lane owns
+    // a contiguous chunk, corrections are decided on raw successive
+    // differences exactly as the recurrence does.
+    const float kPi = 3.14159274101257324219f;
+    const float kTwoPi = 2.0f * kPi;
+    const int C = (nf + kWave - 1) / kWave;
+    const int start = lane * C;
+    const int end = (start + C < nf) ? start + C : nf;
+    float prev = (start > 0 && start < nf) ? scratch[start - 1] : 0.0f;
+    const float first = scratch[0];
+    wave_sync();
+    float s = 0.0f;
+    for (int i = start; i < end; ++i) {
+        const float v = scratch[i];
+        float d = 0.0f;
+        if (i > 0) {
+            d = v - prev;
+            if (d > kPi) d -= kTwoPi;
+            else if (d < -kPi) d += kTwoPi;
+        }
+        prev = v;
+        s += d;
+        scratch[i] = s;
+    }
+    const float incl = wave_scan_add(s);
+    float excl = wave_shfl_up(incl, 1);
+    if (lane == 0) excl = 0.0f;
+    for (int i = start; i < end; ++i) scratch[i] = first + (excl + scratch[i]);
+    wave_sync();
+    for (int k = lane; k < nf; k += kWave) ph_out[p * nf + k] = scratch[k];
+    wave_sync();
+}
+
+// R2C split for the power-of-two path: Z = FFT_N(z), z[n] = x[2n] + i x[2n+1]
+// -> X[0..N] into Xb (N+1 entries).
+__device__ __forceinline__ void r2c_split(const c32 *Z, c32 *Xb, int N,
+                                          const c32 *__restrict__ tw_split, int lane)
+{
+    for (int k = lane; k <= N / 2; k += kWave) {
+        if (k == 0) {
+            const c32 z = Z[0];
+            Xb[0] = c32{z.re + z.im, 0.0f};
+            Xb[N] = c32{z.re - z.im, 0.0f};
+        } else {
+            const c32 a = Z[k], b = Z[N - k];
+            const c32 E = c32{0.5f * (a.re + b.re), 0.5f * (a.im - b.im)};
+            const c32 O = c32{0.5f * (a.im + b.im), -0.5f * (a.re - b.re)};
+            const c32 t = cmul(O, tw_split[k]);
+            Xb[k] = cadd(E, t);
+            Xb[N - k] = cconj(csub(E, t));
+        }
+    }
+    wave_sync();
+}
+
+// Inverse of r2c_split for the unnormalised C2R, written SWAPPED (re<->im) so
+// that the forward passes compute the inverse transform.
+__device__ __forceinline__ void c2r_merge_swapped(const c32 *X, c32 *Zs, int N,
+                                                  const c32 *__restrict__ tw_split, int lane)
+{
+    for (int k = lane; k <= N / 2; k += kWave) {
+        if (k == 0) {
+            const float x0 = X[0].re, xn = X[N].re;
+            Zs[0] = c32{x0 - xn, x0 + xn};  // swapped {im, re}
+        } else {
+            const c32 a = X[k], b = X[N - k];
+            const c32 E = c32{a.re + b.re, a.im - b.im};
+            const c32 D = c32{a.re - b.re, a.im + b.im};
+            const c32 w = tw_split[k];
+            const c32 O = c32{D.re * w.re + D.im * w.im, D.im * w.re - D.re * w.im};
+            // Z[k] = E + iO ; Z[N-k] = conj(E - iO)
+            const c32 zk = c32{E.re - O.im, E.im + O.re};
+            const c32 zn = c32{E.re + O.im, -(E.im - O.re)};
+            Zs[k] = c32{zk.im, zk.re};
+            Zs[N - k] = c32{zn.im, zn.re};
+        }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ float apply2(float v, const float *__restrict__ wa,
+                                        const float *__restrict__ wb, int i)
+{
+    if (wa) v *= wa[i];
+    if (wb) v *= wb[i];
+    return v;
+}
+
+// Final stage of the inverse for the power-of-two path: R holds the swapped
+// result; x[2n] = R[n].im, x[2n+1] = R[n].re; /nt, * window, store, sum of
+// squares.
+__device__ __forceinline__ void c2r_store(const c32 *R, int N, int nt, size_t p,
+                                          const float *__restrict__ win, float *__restrict__ out,
+                                          float *__restrict__ img, int lane)
+{
+    const float fnt = (float)nt;
+    float acc = 0.0f;
+    for (int n = lane; n < N; n += kWave) {
+        const c32 r = R[n];
+        float v0 = r.im / fnt, v1 = r.re / fnt;
+        if (win) { v0 *= win[2 * n]; v1 *= win[2 * n + 1]; }
+        *reinterpret_cast<float2 *>(out + p * nt + 2 * n) = make_float2(v0, v1);
+        acc += v0 * v0;
+        acc += v1 * v1;
+    }
+    if (img) {
+        acc = wave_reduce_add(acc);
+        if (lane == 0) img[p] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward:  math_tools::fft (+ optional band-pass multiply)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fft_fwd(PlanDev P, size_t npix,
+                                                 const float *__restrict__ in,
+                                                 const float *__restrict__ wa,
+                                                 const float *__restrict__ wb,
+                                                 float *__restrict__ data_out,
+                                                 c32 *__restrict__ fft_out,
+                                                 float *__restrict__ amp_out,
+                                                 float *__restrict__ ph_out,
+                                                 const float *__restrict__ mask)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    const int nt = P.nt, nf = P.nf;
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
+    c32 *B = A + P.buf_entries;
+
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = in + p * nt;
+        c32 *Xb;
+        float *scratch;
+        if (P.mode == kModePow2) {
+            for (int i = lane; i < N; i += kWave) {
+                float2 v = *reinterpret_cast<const float2 *>(x + 2 * i);
+                v.x = apply2(v.x, wa, wb, 2 * i);
+                v.y = apply2(v.y, wa, wb, 2 * i + 1);
+                if (data_out) *reinterpret_cast<float2 *>(data_out + p * nt + 2 * i) = v;
+                A[i] = c32{v.x, v.y};
+            }
+            wave_sync();
+            c32 *Z = wave_cfft(A, B, P.log2n, P.tw, lane);
+            Xb = (Z == A) ? B : A;
+            r2c_split(Z, Xb, N, P.tw_split, lane);
+            scratch = reinterpret_cast<float *>(Z);
+        } else {
+            for (int i = lane; i < N; i += kWave) {
+                c32 v = c32{0.0f, 0.0f};
+                if (i < nt) {
+                    const float xv = apply2(x[i], wa, wb, i);
+                    if (data_out) data_out[p * nt + i] = xv;
+                    const c32 c = P.chirp_conj[i];
+                    v = c32{xv * c.re, xv * c.im};
+                }
+                A[i] = v;
+            }
+            wave_sync();
+            c32 *R = wave_bluestein_core(A, B, P, lane);
+            Xb = (R == A) ? B : A;
+            for (int k = lane; k < nf; k += kWave) {
+                const c32 r = R[k];
+                Xb[k] = cmul(c32{r.im, r.re}, P.chirp_conj[k]);
+            }
+            wave_sync();
+            if (lane == 0) {
+                Xb[0].im = 0.0f;  // real input: DC (and Nyquist) bins are real
+                if ((nt & 1) == 0) Xb[nf - 1].im = 0.0f;
+            }
+            wave_sync();
+            scratch = reinterpret_cast<float *>(R);
+        }
+        spectrum_epilogue<false>(Xb, scratch, nf, p, fft_out, amp_out, ph_out, mask, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// inverse:  math_tools::ifft per-pixel part (+ optional window, intensity)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void inverse_from_lds(const PlanDev &P, c32 *X, c32 *other, size_t p,
+                                                 const float *__restrict__ win,
+                                                 float *__restrict__ out, float *__restrict__ img,
+                                                 int lane)
+{
+    const int N = 1 << P.log2n;
+    // pow2 only: X holds nf = N+1 bins in natural order
+    c2r_merge_swapped(X, other, N, P.tw_split, lane);
+    c32 *R = wave_cfft(other, X, P.log2n, P.tw, lane);
+    c2r_store(R, N, P.nt, p, win, out, img, lane);
+    wave_sync();
+}
+
+__global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
+                                                 const c32 *__restrict__ fft_in,
+                                                 const float *__restrict__ win,
+                                                 float *__restrict__ out, float *__restrict__ img)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    const int nt = P.nt, nf = P.nf;
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
+    c32 *B = A + P.buf_entries;
+
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        const c32 *Xg = fft_in + p * nf;
+        if (P.mode == kModePow2) {
+            for (int k = lane; k < nf; k += kWave) A[k] = Xg[k];
+            wave_sync();
+            inverse_from_lds(P, A, B, p, win, out, img, lane);
+        } else {
+            // x[t] = Re DFT(conj Xfull)[t]; Xfull = Hermitian extension
+            const int half = nt / 2;
+            for (int j = lane; j < N; j += kWave) {
+                c32 v = c32{0.0f, 0.0f};
+                if (j < nt) {
+                    const int kk = (j <= half) ? j : nt - j;
+                    c32 X = Xg[kk];
+                    if (kk == 0 || ((nt & 1) == 0 && kk == half)) X.im = 0.0f;
+                    // conj(Xfull[j]): for j <= half conj(X), else conj(conj X) = X
+                    if (j <= half) X.im = -X.im;
+                    v = cmul(X, P.chirp_conj[j]);
+                }
+                A[j] = v;
+            }
+            wave_sync();
+            c32 *R = wave_bluestein_core(A, B, P, lane);
+            const float fnt = (float)nt;
+            float acc = 0.0f;
+            for (int t = lane; t < nt; t += kWave) {
+                const c32 r = R[t];
+                const c32 c = P.chirp_conj[t];
+                // Re( swap(r) * c ) = r.im*c.re - r.re*c.im
+                float v = (r.im * c.re - r.re * c.im) / fnt;
+                if (win) v *= win[t];
+                out[p * nt + t] = v;
+                acc += v * v;
+            }
+            if (img) {
+                acc = wave_reduce_add(acc);
+                if (lane == 0) img[p] = acc;
+            }
+            wave_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused default chain (power-of-two nt): one launch, one HBM pass
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pipeline(PlanDev P, size_t npix,
+                                                  const float *__restrict__ raw,
+                                                  const float *__restrict__ pre_win,
+                                                  const float *__restrict__ mask,
+                                                  const float *__restrict__ post_win,
+                                                  c32 *__restrict__ fft_out,
+                                                  float *__restrict__ amp_out,
+                                                  float *__restrict__ ph_out,
+                                                  float *__restrict__ data_out,
+                                                  float *__restrict__ img)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    const int nt = P.nt, nf = P.nf;
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
+    c32 *B = A + P.buf_entries;
+
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = raw + p * nt;
+        for (int i = lane; i < N; i += kWave) {
+            float2 v = *reinterpret_cast<const float2 *>(x + 2 * i);
+            if (pre_win) { v.x *= pre_win[2 * i]; v.y *= pre_win[2 * i + 1]; }
+            A[i] = c32{v.x, v.y};
+        }
+        wave_sync();
+        c32 *Z = wave_cfft(A, B, P.log2n, P.tw, lane);
+        c32 *Xb = (Z == A) ? B : A;
+        r2c_split(Z, Xb, N, P.tw_split, lane);
+        spectrum_epilogue<true>(Xb, reinterpret_cast<float *>(Z), nf, p, fft_out, amp_out, ph_out,
+                                mask, lane);
+        inverse_from_lds(P, Xb, Z, p, post_win, data_out, img, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// elementwise / reduction kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fd_mask(size_t npix, int nf, c32 *__restrict__ fft,
+                                                 float *__restrict__ amp,
+                                                 const float *__restrict__ mask)
+{
+    const size_t total = npix * (size_t)nf;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float m = mask[i % nf];
+        if (fft) { c32 v = fft[i]; fft[i] = c32{v.re * m, v.im * m}; }
+        if (amp) amp[i] = amp[i] * m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fd_cmask(size_t npix, int nf, int nt,
+                                                  c32 *__restrict__ fft, float *__restrict__ amp,
+                                                  const c32 *__restrict__ cmask)
+{
+    const size_t total = npix * (size_t)nf;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % nf);
+        const c32 m = cmask[k];
+        if (fft) {
+            c32 v = cmul(fft[i], m);
+            if (k == 0 || ((nt & 1) == 0 && k == nf - 1)) v.im = 0.0f;
+            fft[i] = v;
+        }
+        if (amp) amp[i] = amp[i] * sqrtf(fmaf(m.re, m.re, m.im * m.im));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_td_window(size_t npix, int nt,
+                                                   const float *__restrict__ in,
+                                                   const float *__restrict__ win,
+                                                   float *__restrict__ out)
+{
+    const size_t total = npix * (size_t)nt;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = in[i] * win[i % nt];
+}
+
+// one wave per trace; optional bias subtraction first (io.rs:578-596)
+__global__ __launch_bounds__(256) void k_intensity(size_t npix, int nt, float *__restrict__ data,
+                                                   float *__restrict__ img, int subtract_bias)
+{
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        float *x = data + p * nt;
+        const float off = subtract_bias ? x[0] : 0.0f;
+        wave_sync();
+        float acc = 0.0f;
+        for (int i = lane; i < nt; i += kWave) {
+            float v = x[i];
+            if (subtract_bias) { v = v - off; x[i] = v; }
+            acc += v * v;
+        }
+        if (img) {
+            acc = wave_reduce_add(acc);
+            if (lane == 0) img[p] = acc;
+        }
+    }
+}
+
+// pixel sums in the reference's order (math_tools.rs:421-440):
+// pass 1: acc[y][i] = (sum over x, sequential) / nx   (divide skipped if nx_div == 0)
+__global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr, size_t n0,
+                                                   size_t inner, float div,
+                                                   float *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (size_t a = 0; a < n0; ++a) s += arr[a * inner + i];
+        out[i] = (div > 0.0f) ? s / div : s;
+    }
+}
+
+// ROI mask, bit-exact u64 restatement of math_tools.rs:574-591, 604-652
+__global__ __launch_bounds__(256) void k_roi_mask(const uint64_t *__restrict__ poly, int n,
+                                                  uint64_t x_min, uint64_t x_max, uint64_t y_min,
+                                                  uint64_t y_max, uint64_t x_size, uint64_t y_size,
+                                                  uint8_t *__restrict__ mask)
+{
+    const uint64_t total = x_size * y_size;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t y = idx / x_size, x = idx % x_size;
+        bool inside = false;
+        if (n > 0 && x >= x_min && x <= x_max && y >= y_min && y <= y_max) {
+            int j = n - 1;
+            for (int i = 0; i < n; ++i) {
+                const uint64_t xi = poly[2 * i], yi = poly[2 * i + 1];
+                const uint64_t xj = poly[2 * j], yj = poly[2 * j + 1];
+                if ((yi > y) != (yj > y)) {
+                    const uint64_t rhs = (xj - xi) * (y - yi) / (yj - yi) + xi;
+                    if (x < rhs) inside = !inside;
+                }
+                j = i;
+            }
+        }
+        mask[idx] = inside ? 1 : 0;
+    }
+}
+
+// out[z] = sum over listed pixels (in list order) of arr[pix*len + z]
+__global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ arr, size_t len,
+                                                    const uint32_t *__restrict__ list,
+                                                    uint32_t count, float div,
+                                                    float *__restrict__ out)
+{
+    for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < len;
+         z += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (uint32_t c = 0; c < count; ++c) s += arr[(size_t)list[c] * len + z];
+        out[z] = (div > 0.0f) ? s / div : s;
+    }
+}
+
+// scale_3d, math_tools.rs:273-301
+__global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, size_t nx,
+                                                 size_t ny, size_t L, size_t s,
+                                                 float *__restrict__ out)
+{
+    const size_t nw = nx / s, nh = ny / s;
+    const size_t total = nw * nh * L;
+    const float sf = (float)(s * s);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = idx % L;
+        const size_t ay = (idx / L) % nh;
+        const size_t ax = idx / (L * nh);
+        float sum = 0.0f;
+        for (size_t i = 0; i < s; ++i)
+            for (size_t j = 0; j < s; ++j) {
+                const size_t ox = ax * s + i, oy = ay * s + j;
+                if (ox < nx && oy < ny) sum += arr[(ox * ny + oy) * L + z];
+            }
+        out[idx] = sum / sf;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline unsigned grid_1d(size_t total, unsigned block, unsigned cap)
+{
+    size_t g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// Kernels that stage whole traces need more dynamic LDS than HIP's 64 KiB
+// default; raise the per-kernel limit once per size.
+template <class K>
+static inline void allow_dynamic_lds(K kernel, size_t bytes)
+{
+#ifndef THZ_EMU
+    static size_t allowed = 0;
+    if (bytes > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        allowed = bytes;
+    }
+#else
+    (void)kernel;
+    (void)bytes;
+#endif
+}
+
+static inline void wave_launch_geometry(const PlanDev &P, size_t npix, unsigned *grid,
+                                        unsigned *block, size_t *lds)
+{
+    const unsigned wpb = (unsigned)P.waves_per_block;
+    *block = wpb * kWave;
+    *lds = (size_t)P.lds_per_wave * wpb;
+    size_t blocks_per_cu = kLdsBytesPerCU / (*lds ? *lds : 1);
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu * wpb > 32) blocks_per_cu = 32 / wpb;
+    size_t g = (npix + wpb - 1) / wpb;
+    const size_t cap = (size_t)kNumCU * blocks_per_cu;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    *grid = (unsigned)g;
+}
+
+void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
+                    const float *wa, const float *wb, float *data_out, c32 *fft_out,
+                    float *amp_out, float *ph_out, const float *mask)
+{
+    unsigned grid, block;
+    size_t lds;
+    wave_launch_geometry(P, npix, &grid, &block, &lds);
+    allow_dynamic_lds(k_fft_fwd, lds);
+    THZ_LAUNCH(k_fft_fwd, grid, block, lds, st, P, npix, in, wa, wb, data_out, fft_out, amp_out,
+               ph_out, mask);
+}
+
+void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *fft_in,
+                    const float *win, float *out, float *img)
+{
+    unsigned grid, block;
+    size_t lds;
+    wave_launch_geometry(P, npix, &grid, &block, &lds);
+    allow_dynamic_lds(k_fft_inv, lds);
+    THZ_LAUNCH(k_fft_inv, grid, block, lds, st, P, npix, fft_in, win, out, img);
+}
+
+void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
+                     const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
+                     float *amp_out, float *ph_out, float *data_out, float *img)
+{
+    unsigned grid, block;
+    size_t lds;
+    wave_launch_geometry(P, npix, &grid, &block, &lds);
+    allow_dynamic_lds(k_pipeline, lds);
+    THZ_LAUNCH(k_pipeline, grid, block, lds, st, P, npix, raw, pre_win, mask, post_win, fft_out,
+               amp_out, ph_out, data_out, img);
+}
+
+void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask)
+{
+    THZ_LAUNCH(k_fd_mask, grid_1d(npix * nf, 256, kNumCU * 8), 256, 0, st, npix, nf, fft, amp,
+               mask);
+}
+
+void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
+                     const c32 *cmask)
+{
+    THZ_LAUNCH(k_fd_cmask, grid_1d(npix * nf, 256, kNumCU * 8), 256, 0, st, npix, nf, nt, fft, amp,
+               cmask);
+}
+
+void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
+                      float *out)
+{
+    THZ_LAUNCH(k_td_window, grid_1d(npix * nt, 256, kNumCU * 8), 256, 0, st, npix, nt, in, win,
+               out);
+}
+
+void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *img,
+                      int subtract_bias)
+{
+    THZ_LAUNCH(k_intensity, grid_1d(npix * kWave, 256, kNumCU * 8), 256, 0, st, npix, nt, data, img,
+               subtract_bias);
+}
+
+void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
+                      float *out)
+{
+    THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out);
+}
+
+void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_min, uint64_t x_max,
+                     uint64_t y_min, uint64_t y_max, uint64_t x_size, uint64_t y_size,
+                     uint8_t *d_mask)
+{
+    THZ_LAUNCH(k_roi_mask, grid_1d(x_size * y_size, 256, kNumCU * 8), 256, 0, st, d_poly, n, x_min,
+               x_max, y_min, y_max, x_size, y_size, d_mask);
+}
+
+void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list,
+                       uint32_t count, float div, float *out)
+{
+    THZ_LAUNCH(k_gather_sum, grid_1d(len, 256, kNumCU * 8), 256, 0, st, arr, len, d_list, count,
+               div, out);
+}
+
+void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,
+                    float *out)
+{
+    const size_t total = (nx / s) * (ny / s) * L;
+    THZ_LAUNCH(k_scale3d, grid_1d(total, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+}
+
+}  // namespace thz

@@ -1,0 +1,57 @@
+// kernels.hpp — plan descriptor and launcher prototypes shared by kernels.hip
+// (device code) and api.cpp (C ABI).
+#pragma once
+
+#include "thz_device.hpp"
+
+#include <stddef.h>
+
+namespace thz {
+
+constexpr int kNumCU = 256;                    // MI355X: 8 XCD x 32 CU
+constexpr size_t kLdsBytesPerCU = 160 * 1024;  // gfx950 LDS per CU
+
+enum : int { kModePow2 = 0, kModeBluestein = 1 };
+
+// Passed by value to the transform kernels.
+struct PlanDev {
+    int nt;               // real trace length
+    int nf;               // nt/2 + 1
+    int mode;             // kModePow2: nt = 2N, half-length complex FFT + split
+                          // kModeBluestein: chirp-z over a length-N complex FFT
+    int log2n;            // complex transform length N = 1 << log2n
+    int buf_entries;      // c32 entries per LDS ping-pong buffer
+    int lds_per_wave;     // bytes (two buffers)
+    int waves_per_block;  // 1..4
+    const c32 *tw;        // exp(-2*pi*i*m/N), m in [0, N)
+    const c32 *tw_split;  // pow2: exp(-2*pi*i*k/nt), k in [0, N/2]
+    const c32 *chirp_conj;  // bluestein: exp(-i*pi*n^2/nt), n in [0, nt)
+    const c32 *bfft;        // bluestein: FFT_N(chirp filter)/N, N entries
+};
+
+void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
+                    const float *wa, const float *wb, float *data_out, c32 *fft_out,
+                    float *amp_out, float *ph_out, const float *mask);
+void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *fft_in,
+                    const float *win, float *out, float *img);
+void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
+                     const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
+                     float *amp_out, float *ph_out, float *data_out, float *img);
+void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask);
+void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
+                     const c32 *cmask);
+void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
+                      float *out);
+void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *img,
+                      int subtract_bias);
+void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
+                      float *out);
+void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_min, uint64_t x_max,
+                     uint64_t y_min, uint64_t y_max, uint64_t x_size, uint64_t y_size,
+                     uint8_t *d_mask);
+void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list,
+                       uint32_t count, float div, float *out);
+void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,
+                    float *out);
+
+}  // namespace thz

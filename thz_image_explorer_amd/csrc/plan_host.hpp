@@ -1,0 +1,135 @@
+// plan_host.hpp — host-side construction of the transform tables ("plan").
+// Replaces RealFftPlanner::plan_fft_forward/plan_fft_inverse (io.rs:616-618,
+// data_thread.rs:1200-1202, tilt_compensation.rs:210-212): what those calls
+// prepare inside realfft/rustfft is here a set of twiddle tables computed in
+// double precision and rounded once to f32.
+#pragma once
+
+#include "kernels.hpp"
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+namespace thz {
+
+struct PlanHost {
+    int nt = 0, nf = 0, mode = kModePow2, log2n = 0;
+    int buf_entries = 0, lds_per_wave = 0, waves_per_block = 1;
+    std::vector<c32> tw, tw_split, chirp_conj, bfft;
+    const char *variant = "";
+};
+
+inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
+
+// in-place iterative radix-2 FFT in double (host, table construction only)
+inline void host_fft_pow2(std::vector<std::complex<double>> &a)
+{
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    const double pi = 3.14159265358979323846;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double ang = -2.0 * pi * (double)k / (double)len;
+                const std::complex<double> w(std::cos(ang), std::sin(ang));
+                const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+// Returns false when nt is outside the supported range.
+inline bool build_plan(size_t nt, PlanHost &P)
+{
+    const double pi = 3.14159265358979323846;
+    if (nt < 2) return false;
+    P.nt = (int)nt;
+    P.nf = (int)(nt / 2 + 1);
+    size_t N;
+    if (is_pow2(nt) && nt >= 4) {
+        if (nt > 16384) return false;
+        P.mode = kModePow2;
+        N = nt / 2;
+        P.variant = "g-stockham-lds-r4r2";
+    } else {
+        if (nt > 4096) return false;
+        P.mode = kModeBluestein;
+        N = 1;
+        while (N < 2 * nt - 1) N <<= 1;
+        P.variant = "g-bluestein-stockham-lds-r4r2";
+    }
+    int lg = 0;
+    while (((size_t)1 << lg) < N) ++lg;
+    P.log2n = lg;
+    P.buf_entries = (int)(((N > (size_t)P.nf ? N : (size_t)P.nf) + 1) & ~(size_t)1);
+    P.lds_per_wave = 2 * P.buf_entries * (int)sizeof(c32);
+    int wpb = (int)(kLdsBytesPerCU / (size_t)P.lds_per_wave);
+    if (wpb < 1) return false;
+    if (wpb > 4) wpb = 4;
+    P.waves_per_block = wpb;
+
+    P.tw.resize(N);
+    for (size_t m = 0; m < N; ++m) {
+        const double a = -2.0 * pi * (double)m / (double)N;
+        P.tw[m] = c32{(float)std::cos(a), (float)std::sin(a)};
+    }
+    P.tw_split.clear();
+    P.chirp_conj.clear();
+    P.bfft.clear();
+    if (P.mode == kModePow2) {
+        P.tw_split.resize(N / 2 + 1);
+        for (size_t k = 0; k <= N / 2; ++k) {
+            const double a = -2.0 * pi * (double)k / (double)nt;
+            P.tw_split[k] = c32{(float)std::cos(a), (float)std::sin(a)};
+        }
+    } else {
+        // chirp[n] = exp(+i*pi*n^2/nt); reduce n^2 mod 2nt in integers first
+        std::vector<std::complex<double>> chirp(nt);
+        for (size_t n = 0; n < nt; ++n) {
+            const unsigned long long q = ((unsigned long long)n * n) % (2ull * nt);
+            const double a = pi * (double)q / (double)nt;
+            chirp[n] = std::complex<double>(std::cos(a), std::sin(a));
+        }
+        P.chirp_conj.resize(nt);
+        for (size_t n = 0; n < nt; ++n)
+            P.chirp_conj[n] = c32{(float)chirp[n].real(), (float)(-chirp[n].imag())};
+        std::vector<std::complex<double>> b(N, std::complex<double>(0.0, 0.0));
+        b[0] = chirp[0];
+        for (size_t n = 1; n < nt; ++n) {
+            b[n] = chirp[n];
+            b[N - n] = chirp[n];
+        }
+        host_fft_pow2(b);
+        P.bfft.resize(N);
+        for (size_t m = 0; m < N; ++m)
+            P.bfft[m] = c32{(float)(b[m].real() / (double)N), (float)(b[m].imag() / (double)N)};
+    }
+    return true;
+}
+
+inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
+                        const c32 *chirp_conj, const c32 *bfft)
+{
+    PlanDev D;
+    D.nt = H.nt;
+    D.nf = H.nf;
+    D.mode = H.mode;
+    D.log2n = H.log2n;
+    D.buf_entries = H.buf_entries;
+    D.lds_per_wave = H.lds_per_wave;
+    D.waves_per_block = H.waves_per_block;
+    D.tw = tw;
+    D.tw_split = tw_split;
+    D.chirp_conj = chirp_conj;
+    D.bfft = bfft;
+    return D;
+}
+
+}  // namespace thz
