@@ -101,28 +101,40 @@ size_t thz_nf(const thz_ctx *ctx);
 int thz_get_frequency(const thz_ctx *ctx, float *frequency /* nf */);
 
 /* ------------------------------------------------------------------ */
-/* host-side multiplier vectors (O(nt) work, computed once per call)   */
+/* host-side multiplier vectors (O(nt) work, no GPU involved)          */
 /* ------------------------------------------------------------------ */
+/* The reference re-evaluates its window formulas for every trace inside the
+ * pixel loops; they only depend on the axis, so the engine evaluates them once
+ * per call on the host, in the reference's f32 operation order, and the
+ * kernels multiply by the resulting vector.  These need no context. */
 
-/* Window multiplier for the fft stage, math_tools.rs:102-198, 356-371:
+/* frequency[i] = i / (time[nt-1] - time[0]), i = 0..nt/2 (io.rs:614-621). */
+int thz_host_frequency_axis(const float *time, size_t nt, float *frequency /* nt/2+1 */);
+
+/* Window multiplier of the fft stage, math_tools.rs:102-198, 356-371:
  * out[i] = w(time[i]) such that windowed = data * out. */
-int thz_make_fft_window(const thz_ctx *ctx, const thz_window_cfg *cfg, float *out /* nt */);
+int thz_host_fft_window(const float *time, size_t nt, const thz_window_cfg *cfg,
+                        float *out /* nt */);
+
+/* apply_adapted_blackman_window on ones (math_tools.rs:102-122) over an
+ * arbitrary axis slice; tilt compensation's tail taper is (lower 0, upper 7),
+ * tilt_compensation.rs:186-188. */
+int thz_host_adapted_blackman(const float *axis, size_t len, float lower, float upper,
+                              float *out /* len */);
 
 /* "Time Band Pass" multiplier, band_pass_td_before_fft.rs:124-182 (and
  * _after_fft.rs): 0 outside [lower,upper), adapted-Blackman taper inside.
- * The low / high values are clamped in place exactly as the filter clamps its own fields
- * (:137-138).  lower/upper indices are returned when non-NULL. */
-int thz_make_td_bandpass(const thz_ctx *ctx, double *low, double *high, double window_width,
-                         float *out /* nt */, int64_t *lower, int64_t *upper);
+ * The low / high values are clamped in place exactly as the filter clamps its
+ * own fields (:137-138).  lower/upper indices are returned when non-NULL. */
+int thz_host_td_bandpass(const float *time, size_t nt, double *low, double *high,
+                         double window_width, float *out /* nt */, int64_t *lower,
+                         int64_t *upper);
 
 /* "Frequency Band Pass" multiplier, band_pass_fd.rs:135-168 + zero padding
  * :194-212: 0 outside [lower,upper), taper inside. */
-int thz_make_fd_bandpass(const thz_ctx *ctx, double low, double high, double window_width,
-                         float *out /* nf */, int64_t *lower, int64_t *upper);
-
-/* Tilt compensation's tail taper at zero tilt (tilt_compensation.rs:186-188:
- * apply_adapted_blackman_window(trace, time, 0.0, 7.0)). */
-int thz_make_tilt_taper(const thz_ctx *ctx, float *out /* nt */);
+int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double high,
+                         double window_width, float *out /* nf */, int64_t *lower,
+                         int64_t *upper);
 
 /* ------------------------------------------------------------------ */
 /* stage kernels (device pointers)                                     */
@@ -212,6 +224,14 @@ int thz_roi_mean(thz_ctx *ctx, const float *d_arr, size_t shape0, size_t shape1,
 int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t len, int ncomp,
                 size_t s, float *d_out);
 
+/* Synthetic input generator for benchmarks and tests (not a reference
+ * function): derivative-of-Gaussian pulse + echo + 1 % noise
+ * per trace from counter-based Philox4x32-10, identical to tests/synth.py.
+ * Trace ids first_trace .. first_trace+ntraces-1; d_time is the nt-sample
+ * time axis on the device. */
+int thz_synth_cube(thz_ctx *ctx, float *d_out, size_t ntraces, uint64_t first_trace,
+                   const float *d_time, uint32_t seed, int subtract_bias);
+
 /* Per-stage device time of the most recent call of each kind, the value the
  * reference shows next to each filter (filter.rs:607-621).  `stage` is one
  * of the THZ_STAGE_* ids. */
@@ -226,9 +246,16 @@ enum {
     THZ_STAGE_ROI = 7,
     THZ_STAGE_COUNT = 8
 };
-/* Enables hipEvent bracketing of every stage call (off by default). */
-int thz_enable_timing(thz_ctx *ctx, int enable);
+/* hipEvent bracketing of every stage call on the context's stream.
+ *   0  off (default)
+ *   1  immediate: the call waits for its kernel; thz_stage_time_ns() then
+ *      returns the device time of the latest call of that stage
+ *   2  deferred: events are recorded without any host wait;
+ *      thz_timing_collect() later synchronises once and returns the summed
+ *      device time and the number of calls of `stage` since the last collect */
+int thz_enable_timing(thz_ctx *ctx, int mode);
 int thz_stage_time_ns(thz_ctx *ctx, int stage, uint64_t *ns);
+int thz_timing_collect(thz_ctx *ctx, int stage, uint64_t *total_ns, uint64_t *count);
 
 /* Kernel variant actually used for the current nt ("stockham-lds-r2", …),
  * for logs and for the tests that assert the native path ran. */

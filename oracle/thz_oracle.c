@@ -556,47 +556,6 @@ void thz_oracle_scale3d(const float *arr, int nx, int ny, int len, int ncomp, in
 }
 
 /* ---------------------------------------------------------------------------
- * Tilt compensation — src/filters/tilt_compensation.rs:97-226.
- * Two calls: _plan computes the extension (time_shift, num_steps, new nt and
- * the new time axis), _apply fills the output cube.
- * ------------------------------------------------------------------------- */
-#define TILT_C_MM_PS 0.299792458f
-#define TILT_DT 0.05f
-
-int thz_oracle_tilt_plan(int nx, int ny, int nt, const float *time, double tilt_x_deg,
-                         double tilt_y_deg, float dx, float dy, float *time_shift_out,
-                         float *new_time /* nt + 2*steps entries, may be NULL for sizing */)
-{
-    float center_x = (float)(nx - 1) / 2.0f * dx;
-    float center_y = (float)(ny - 1) / 2.0f * dy;
-    float tx = (float)(tilt_x_deg / 180.0 * M_PI);
-    float ty = (float)(tilt_y_deg / 180.0 * M_PI);
-    float time_shift_x = fabsf(center_x * tx) / TILT_C_MM_PS;
-    float time_shift_y = fabsf(center_y * ty) / TILT_C_MM_PS;
-    float raw = time_shift_x + time_shift_y;
-    float time_shift = floorf(raw / TILT_DT) * TILT_DT;
-    int num_steps = (int)roundf(time_shift / TILT_DT);
-    if (time_shift_out) *time_shift_out = time_shift;
-    if (new_time && nt > 0) {
-        /* Array1::linspace(first - time_shift, first - dt, num_steps) ++ time ++
-         * Array1::linspace(last + dt, last + time_shift, num_steps) */
-        float first = time[0], last = time[nt - 1];
-        for (int i = 0; i < num_steps; ++i) {
-            float a = first - time_shift, b = first - TILT_DT;
-            float step = num_steps > 1 ? (b - a) / (float)(num_steps - 1) : 0.0f;
-            new_time[i] = a + step * (float)i;
-        }
-        for (int i = 0; i < nt; ++i) new_time[num_steps + i] = time[i];
-        for (int i = 0; i < num_steps; ++i) {
-            float a = last + TILT_DT, b = last + time_shift;
-            float step = num_steps > 1 ? (b - a) / (float)(num_steps - 1) : 0.0f;
-            new_time[num_steps + nt + i] = a + step * (float)i;
-        }
-    }
-    return num_steps;
-}
-
-/* ---------------------------------------------------------------------------
  * CPU baseline: the default chain, stage-fused per trace without per-stage
  * container copies (SURVEY §8d variant (i)), OpenMP over Axis(0) like the
  * reference's rayon split.  Composite of the functions above.
@@ -604,7 +563,8 @@ int thz_oracle_tilt_plan(int nx, int ny, int nt, const float *time, double tilt_
  *   out  : fft (band-passed), amplitudes (band-passed), phases, data_out, img
  * ------------------------------------------------------------------------- */
 void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny, int nt,
-                         const float *w_td_before, int window_type, float win_lo, float win_hi,
+                         const float *w_tilt /* may be NULL */, const float *w_td_before,
+                         int window_type, float win_lo, float win_hi,
                          const float *w_fd, const float *w_td_after, float *fft_interleaved,
                          float *amplitudes, float *phases, float *data_out, float *img, int nthreads)
 {
@@ -626,7 +586,11 @@ void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny
             for (int y = 0; y < ny; ++y) {
                 size_t p = (size_t)x * ny + y;
                 const float *src = data_in + p * nt;
-                for (int i = 0; i < nt; ++i) tr[i] = src[i] * w_td_before[i];
+                /* tilt taper (tilt_compensation.rs:186-188), then Time Band Pass
+                 * (band_pass_td_before_fft.rs:155-175), then the fft window */
+                if (w_tilt) for (int i = 0; i < nt; ++i) tr[i] = src[i] * w_tilt[i];
+                else for (int i = 0; i < nt; ++i) tr[i] = src[i];
+                for (int i = 0; i < nt; ++i) tr[i] = tr[i] * w_td_before[i];
                 thz_oracle_apply_window(window_type, tr, time, nt, win_lo, win_hi);
                 rfft_f(r, tr, spec, work);
                 float *amp = amplitudes + p * nf;

@@ -1,0 +1,241 @@
+"""ctypes binding of oracle/libthz_oracle.so — the CPU restatement of the
+reference used as the checker (tests, smoke, bench cpu_baseline only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libthz_oracle.so")
+
+_P = C.c_void_p
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make"], cwd=ORACLE_DIR)
+        L = C.CDLL(ORACLE_SO)
+        L.thz_oracle_blackman_window.restype = C.c_float
+        L.thz_oracle_blackman_window.argtypes = [C.c_float, C.c_float]
+        L.thz_oracle_ifft_stage.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def blackman_window(n, m):
+    return lib().thz_oracle_blackman_window(C.c_float(n), C.c_float(m))
+
+
+def apply_adapted_blackman(signal, time, lo, hi):
+    s = f32(signal).copy()
+    t = f32(time)
+    lib().thz_oracle_apply_adapted_blackman(_p(s), _p(t), C.c_int(s.size), C.c_float(lo), C.c_float(hi))
+    return s
+
+
+def apply_window(wtype, signal, time, lo=0.0, hi=0.0):
+    s = f32(signal).copy()
+    t = f32(time)
+    lib().thz_oracle_apply_window(C.c_int(wtype), _p(s), _p(t), C.c_int(s.size), C.c_float(lo), C.c_float(hi))
+    return s
+
+
+def numpy_unwrap(x, period=2 * np.float32(np.pi)):
+    x = f32(x)
+    out = np.empty_like(x)
+    lib().thz_oracle_numpy_unwrap(_p(x), C.c_int(x.size), C.c_float(period), _p(out))
+    return out
+
+
+def frequency_axis(time):
+    t = f32(time)
+    out = np.empty(t.size // 2 + 1, np.float32)
+    lib().thz_oracle_frequency_axis(_p(t), C.c_int(t.size), _p(out))
+    return out
+
+
+def rfft_f32(x):
+    x = f32(x)
+    out = np.empty(2 * (x.size // 2 + 1), np.float32)
+    lib().thz_oracle_rfft_f32(_p(x), C.c_int(x.size), _p(out))
+    return out[0::2] + 1j * out[1::2]
+
+
+def irfft_f32(X, n):
+    Xi = np.empty(2 * X.size, np.float32)
+    Xi[0::2] = X.real
+    Xi[1::2] = X.imag
+    out = np.empty(n, np.float32)
+    lib().thz_oracle_irfft_f32(_p(Xi), C.c_int(n), _p(out))
+    return out
+
+
+def rfft_f64(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(2 * (x.size // 2 + 1), np.float64)
+    lib().thz_oracle_rfft_f64(_p(x), C.c_int(x.size), _p(out))
+    return out[0::2] + 1j * out[1::2]
+
+
+def rdft_direct_f64(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(2 * (x.size // 2 + 1), np.float64)
+    lib().thz_oracle_rdft_direct_f64(_p(x), C.c_int(x.size), _p(out))
+    return out[0::2] + 1j * out[1::2]
+
+
+def fft_stage(data, time, wtype=0, lo=1.0, hi=7.0, nthreads=0):
+    """math_tools::fft.  data (nx,ny,nt) -> dict(data=windowed, fft, amplitudes, phases)"""
+    d = f32(data).copy()
+    nx, ny, nt = d.shape
+    nf = nt // 2 + 1
+    t = f32(time)
+    fft = np.empty((nx, ny, nf, 2), np.float32)
+    amp = np.empty((nx, ny, nf), np.float32)
+    ph = np.empty((nx, ny, nf), np.float32)
+    lib().thz_oracle_fft_stage(_p(d), _p(t), nx, ny, nt, C.c_int(wtype), C.c_float(lo), C.c_float(hi),
+                               _p(fft), _p(amp), _p(ph), C.c_int(nthreads))
+    return dict(data=d, fft=fft, amplitudes=amp, phases=ph)
+
+
+def fd_bandpass_window(frequency, low, high, width):
+    f = f32(frequency)
+    w = np.empty(f.size, np.float32)
+    lo_i, up_i = C.c_int(), C.c_int()
+    lib().thz_oracle_fd_bandpass_window(_p(f), C.c_int(f.size), C.c_double(low), C.c_double(high),
+                                        C.c_double(width), _p(w), C.byref(lo_i), C.byref(up_i))
+    return w, lo_i.value, up_i.value
+
+
+def fd_bandpass(fft, amplitudes, frequency, low, high, width):
+    f = f32(fft).copy()
+    a = f32(amplitudes).copy()
+    fr = f32(frequency)
+    npix = a.size // fr.size
+    lib().thz_oracle_fd_bandpass(_p(f), _p(a), _p(fr), C.c_size_t(npix), C.c_int(fr.size),
+                                 C.c_double(low), C.c_double(high), C.c_double(width))
+    return f, a
+
+
+def td_bandpass_window(time, low, high, width):
+    t = f32(time)
+    w = np.empty(t.size, np.float32)
+    lo, hi = C.c_double(low), C.c_double(high)
+    lo_i, up_i = C.c_int(), C.c_int()
+    lib().thz_oracle_td_bandpass_window(_p(t), C.c_int(t.size), C.byref(lo), C.byref(hi), C.c_double(width),
+                                        _p(w), C.byref(lo_i), C.byref(up_i))
+    return w, lo.value, hi.value, lo_i.value, up_i.value
+
+
+def td_bandpass(data, time, low, high, width):
+    d = f32(data).copy()
+    t = f32(time)
+    lo, hi = C.c_double(low), C.c_double(high)
+    lib().thz_oracle_td_bandpass(_p(d), _p(t), C.c_size_t(d.size // t.size), C.c_int(t.size),
+                                 C.byref(lo), C.byref(hi), C.c_double(width))
+    return d, lo.value, hi.value
+
+
+def intensity(data):
+    d = f32(data)
+    nt = d.shape[-1]
+    img = np.empty(d.shape[:-1], np.float32)
+    lib().thz_oracle_intensity(_p(d), C.c_size_t(d.size // nt), C.c_int(nt), _p(img))
+    return img
+
+
+def subtract_bias(data):
+    d = f32(data).copy()
+    nt = d.shape[-1]
+    lib().thz_oracle_subtract_bias(_p(d), C.c_size_t(d.size // nt), C.c_int(nt))
+    return d
+
+
+def pixel_mean(arr, ncomp=1):
+    """arr (nx,ny,len[,2]) -> (len[,2]) in the reference's summation order"""
+    a = f32(arr)
+    nx, ny, ln = a.shape[0], a.shape[1], a.shape[2]
+    out = np.empty(ln * ncomp, np.float32)
+    lib().thz_oracle_pixel_mean(_p(a), nx, ny, ln, ncomp, _p(out))
+    return out.reshape(ln, 2) if ncomp == 2 else out
+
+
+def roi_mask(poly_xy, scaling, shape0, shape1):
+    poly = np.ascontiguousarray(poly_xy, np.uint64).reshape(-1, 2)
+    mask = np.zeros((shape0, shape1), np.uint8)
+    panic = C.c_int(0)
+    lib().thz_oracle_roi_mask(_p(poly), C.c_int(poly.shape[0]), C.c_uint64(scaling), shape0, shape1,
+                              _p(mask), C.byref(panic))
+    return mask, bool(panic.value)
+
+
+def average_polygon_roi(data, poly_xy, scaling=1):
+    d = f32(data)
+    s0, s1, ln = d.shape
+    poly = np.ascontiguousarray(poly_xy, np.uint64).reshape(-1, 2)
+    out = np.empty(ln, np.float32)
+    panic = C.c_int(0)
+    lib().thz_oracle_average_polygon_roi(_p(d), s0, s1, ln, _p(poly), C.c_int(poly.shape[0]),
+                                         C.c_uint64(scaling), _p(out), C.byref(panic))
+    return out
+
+
+def ifft_stage(fft, nt, nthreads=0):
+    f = f32(fft)
+    nx, ny = f.shape[0], f.shape[1]
+    out = np.empty((nx, ny, nt), np.float32)
+    nerr = lib().thz_oracle_ifft_stage(_p(f), nx, ny, nt, _p(out), C.c_int(nthreads))
+    return out, int(nerr)
+
+
+def polar_irfft(amp, phase, nt, zero_dc_imag=False):
+    a, p = f32(amp), f32(phase)
+    out = np.empty(nt, np.float32)
+    lib().thz_oracle_polar_irfft(_p(a), _p(p), C.c_int(nt), C.c_int(int(zero_dc_imag)), _p(out))
+    return out
+
+
+def scale3d(arr, s, ncomp=1):
+    a = f32(arr)
+    nx, ny, ln = a.shape[0], a.shape[1], a.shape[2]
+    out = np.empty((nx // s, ny // s, ln) + ((2,) if ncomp == 2 else ()), np.float32)
+    lib().thz_oracle_scale3d(_p(a), nx, ny, ln, ncomp, s, _p(out))
+    return out
+
+
+def max_threads():
+    return int(lib().thz_oracle_max_threads())
+
+
+def run_pipeline(cube, time, chain, nthreads=0):
+    """Default chain, stage-fused per trace (thz_oracle_pipeline).  `chain` is
+    the dict built by synth.default_chain()."""
+    d = f32(cube)
+    nx, ny, nt = d.shape
+    nf = nt // 2 + 1
+    t = f32(time)
+    fft = np.empty((nx, ny, nf, 2), np.float32)
+    amp = np.empty((nx, ny, nf), np.float32)
+    ph = np.empty((nx, ny, nf), np.float32)
+    out = np.empty((nx, ny, nt), np.float32)
+    img = np.empty((nx, ny), np.float32)
+    tilt = None if chain.get("w_tilt") is None else f32(chain["w_tilt"])
+    lib().thz_oracle_pipeline(_p(d), _p(t), nx, ny, nt, _p(tilt), _p(f32(chain["w_td_before"])),
+                              C.c_int(chain["window_type"]),
+                              C.c_float(chain["fft_window"][0]), C.c_float(chain["fft_window"][1]),
+                              _p(f32(chain["fd_mask"])), _p(f32(chain["w_post"])), _p(fft), _p(amp),
+                              _p(ph), _p(out), _p(img), C.c_int(nthreads))
+    return dict(fft=fft, amplitudes=amp, phases=ph, data=out, img=img)

@@ -1,0 +1,106 @@
+"""Index arithmetic of the HIP kernels, checked on the CPU: the product's
+csrc/kernels.hip is compiled with -DTHZ_EMU (every lane a host thread, see
+tests/emu/hip_emu.h) and compared with the oracle.  This does not replace the
+`-m gpu` parity tests; it catches lane/bin mapping and LDS exchange bugs in a
+container that has no GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_SO = os.path.join(HERE, "emu", "libthz_emu.so")
+_P = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def emu():
+    src = os.path.join(HERE, "..", "thz_image_explorer_amd", "csrc", "kernels.hip")
+    if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < os.path.getmtime(src):
+        subprocess.check_call(["bash", os.path.join(HERE, "emu", "build_emu.sh")])
+    return C.CDLL(EMU_SO)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _fwd(emu, x, wa, mask, nt):
+    npix = x.shape[0]
+    nf = nt // 2 + 1
+    dout = np.zeros_like(x)
+    fft = np.zeros((npix, nf, 2), np.float32)
+    amp = np.zeros((npix, nf), np.float32)
+    ph = np.zeros((npix, nf), np.float32)
+    rc = emu.emu_fft_fwd(nt, C.c_size_t(npix), _p(x), _p(wa), None, _p(dout), _p(fft), _p(amp), _p(ph), _p(mask))
+    assert rc == 0
+    return dout, fft, amp, ph
+
+
+@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 4096, 1001, 30])
+def test_forward_inverse_vs_oracle(emu, nt):
+    npix = 6  # > waves per block: exercises the grid-stride loop and a ragged last block
+    rng = np.random.default_rng(nt)
+    time = synth.make_time(nt)
+    x = synth.make_traces(np.arange(npix) + 7, nt) + 0.05 * rng.standard_normal((npix, nt)).astype(np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    wa = ob.apply_window(0, np.ones(nt, np.float32), time, 1.0, 7.0) if nt >= 256 else np.ones(nt, np.float32)
+    freq = ob.frequency_axis(time)
+    mask = ob.fd_bandpass_window(freq, 0.2, 5.0, 0.1)[0] if nt >= 256 else np.ones(nt // 2 + 1, np.float32)
+    dout, fft, amp, ph = _fwd(emu, x, wa, mask, nt)
+    st = ob.fft_stage((x * wa).reshape(1, npix, nt), time, 0, 0.0, 0.0)
+    scale = np.abs(st["fft"]).max()
+    assert np.array_equal(dout, x * wa)
+    ref_f, ref_a = st["fft"][0] * mask[None, :, None], st["amplitudes"][0] * mask[None, :]
+    assert np.abs(fft - ref_f).max() / scale < 1e-5
+    assert np.abs(amp - ref_a).max() / scale < 1e-5
+    d = ph - st["phases"][0]
+    assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi))).max() < 2e-3
+    out = np.zeros_like(x)
+    img = np.zeros(npix, np.float32)
+    win = ob.td_bandpass_window(time, float(time[0]), float(time[-1]), 0.1)[0]
+    assert emu.emu_fft_inv(nt, C.c_size_t(npix), _p(np.ascontiguousarray(ref_f)), _p(win), _p(out), _p(img)) == 0
+    back, _ = ob.ifft_stage(ref_f.reshape(1, npix, -1, 2), nt)
+    ref_t = back[0] * win
+    assert np.abs(out - ref_t).max() / np.abs(ref_t).max() < 1e-5
+    assert np.abs(img - (ref_t.astype(np.float64) ** 2).sum(1)).max() / img.max() < 1e-5
+
+
+@pytest.mark.parametrize("nt", [256, 1024])
+def test_fused_pipeline_vs_oracle(emu, nt):
+    nx, ny = 2, 5
+    time, cube = synth.make_cube(nx, ny, nt)
+    chain = synth.default_chain(time)
+    npix = nx * ny
+    nf = nt // 2 + 1
+    fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+    ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+    rc = emu.emu_pipeline(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]),
+                          _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img))
+    assert rc == 0
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+    assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+    assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / np.abs(ref["data"]).max() < 1e-5
+    assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / ref["img"].max() < 1e-5
+
+
+def test_roi_mask_kernel_bit_exact(emu):
+    g = np.load(os.path.join(HERE, "golden", "roi_masks.npz"))
+    for name in ("concave", "outside_clamped", "convex_cw"):
+        poly = (g[name + "_poly"] // np.uint64(1)).astype(np.uint64)
+        s0, s1 = 32, 32
+        xs, ys = poly[:, 0], poly[:, 1]
+        clamp = lambda v, m: min(int(v), m - 1)
+        mask = np.zeros((s0, s1), np.uint8)
+        emu.emu_roi_mask(_p(np.ascontiguousarray(poly)), poly.shape[0],
+                         C.c_uint64(clamp(xs.min(), s1)), C.c_uint64(clamp(xs.max(), s1)),
+                         C.c_uint64(clamp(ys.min(), s0)), C.c_uint64(clamp(ys.max(), s0)),
+                         C.c_uint64(s1), C.c_uint64(s0), _p(mask))
+        assert np.array_equal(mask, g[f"{name}_32x32_s1_mask"]), name

@@ -1,0 +1,380 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the
+committed golden vectors.  Tolerances: north_star — bit-exact for index/ROI
+masks, <= 1e-5 relative (max-norm, per cube) on fp32 spectra and traces."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+import thz_image_explorer_amd as pkg
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def rel(a, b, scale=None):
+    scale = np.abs(b).max() if scale is None else scale
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / scale)
+
+
+def phase_ok(ph, ref, amp_ref):
+    """unwrapped phase: equal modulo 2*pi-decision flips on noise bins; no flip
+    while the amplitude is above 5 % of the trace maximum"""
+    d = ph.astype(np.float64) - ref
+    jumps = np.round(d / (2 * np.pi))
+    if np.abs(d - 2 * np.pi * jumps).max() > 3e-3:
+        return False
+    strong = amp_ref > 0.05 * amp_ref.max(axis=-1, keepdims=True)
+    flat_j = jumps.reshape(-1, jumps.shape[-1])
+    flat_s = strong.reshape(-1, strong.shape[-1])
+    for j, s in zip(flat_j, flat_s):
+        weak = np.nonzero(~s[3:])[0]
+        end = (weak[0] + 3) if weak.size else s.size
+        if np.any(j[:end] != 0):
+            return False
+    return True
+
+
+def gpu_fft_stage(eng, cube, w, mask=None, want_data=True):
+    nx, ny, nt = cube.shape
+    npix, nf = nx * ny, nt // 2 + 1
+    d_in = eng.to_device(cube); d_w = eng.to_device(w)
+    d_mask = eng.to_device(mask) if mask is not None else None
+    d_dat = eng.empty((npix, nt)) if want_data else None
+    d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf))
+    eng.fft(npix, d_in, d_w, None, d_dat, d_fft, d_amp, d_ph, d_mask)
+    out = dict(fft=d_fft.download((nx, ny, nf, 2), np.float32), amplitudes=d_amp.download((nx, ny, nf), np.float32),
+               phases=d_ph.download((nx, ny, nf), np.float32))
+    if want_data:
+        out["data"] = d_dat.download((nx, ny, nt), np.float32)
+    for b in (d_in, d_w, d_mask, d_dat, d_fft, d_amp, d_ph):
+        if b is not None:
+            b.free()
+    return out
+
+
+@pytest.mark.parametrize("nt", [64, 128, 256, 1024, 2048, 4096, 1001, 1000])
+@pytest.mark.parametrize("wtype", [0, 2])
+def test_fft_stage_vs_oracle(engine, nt, wtype):
+    nx, ny = 3, 7
+    time, cube = synth.make_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    assert engine.kernel_variant() != ""
+    w = pkg.host_fft_window(time, wtype, 1.0, 7.0)
+    got = gpu_fft_stage(engine, cube, w)
+    ref = ob.fft_stage(cube, time, wtype, 1.0, 7.0)
+    assert np.array_equal(got["data"], ref["data"])  # one f32 multiply: bit-exact
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"], ref["amplitudes"], scale) < TOL
+    assert phase_ok(got["phases"], ref["phases"], ref["amplitudes"])
+
+
+@pytest.mark.parametrize("nt", [128, 1000, 1001, 1024, 4096])
+def test_golden_vectors(engine, nt):
+    """GPU vs numpy-fp64 truth (tests/golden/fft_vectors.npz)"""
+    v = np.load(os.path.join(GOLD, "fft_vectors.npz"))
+    time, raw, freq = v[f"nt{nt}_time"], v[f"nt{nt}_raw"], v[f"nt{nt}_freq"]
+    engine.set_time_axis(time)
+    assert np.array_equal(engine.frequency(), freq)
+    cube = raw.reshape(1, -1, nt)
+    for kind in range(5):
+        w = pkg.host_fft_window(time, kind, 1.0, 7.0)
+        got = gpu_fft_stage(engine, cube, w, want_data=False)
+        X = got["fft"][0, ..., 0] + 1j * got["fft"][0, ..., 1]
+        ref = v[f"nt{nt}_w{kind}_fft"]
+        assert np.abs(X - ref).max() / np.abs(ref).max() < TOL
+    w = pkg.host_fft_window(time, 0, 1.0, 7.0)
+    mask, lo, up = pkg.host_fd_bandpass(freq, 0.2, 5.0, 0.1)
+    assert (lo, up) == tuple(v[f"nt{nt}_fd_idx"])
+    got = gpu_fft_stage(engine, cube, w, mask, want_data=False)
+    amp_ref = v[f"nt{nt}_w0_amp"]
+    assert rel(got["amplitudes"][0], amp_ref * mask) < TOL
+    assert phase_ok(got["phases"][0], v[f"nt{nt}_w0_phase"], amp_ref)
+    npix = raw.shape[0]
+    d_fft = engine.to_device(got["fft"]); d_out = engine.empty((npix, nt))
+    engine.ifft(npix, d_fft, None, d_out, None)
+    back = d_out.download((npix, nt), np.float32)
+    assert rel(back, v[f"nt{nt}_w0_irfft_bp"]) < TOL
+    d_fft.free(); d_out.free()
+
+
+@pytest.mark.parametrize("nt", [256, 1024, 4096, 1001])
+def test_stagewise_chain_vs_oracle(engine, nt):
+    """scaling(1) -> tilt taper -> Time Band Pass -> fft -> Frequency Band Pass ->
+    ifft -> Time Band Pass, one C-ABI call per stage like data_thread.rs:1108-1191"""
+    nx, ny = 4, 6
+    time, cube = synth.make_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    chain = synth.default_chain(time)
+    npix, nf = nx * ny, nt // 2 + 1
+    e = engine
+    d = e.to_device(cube)
+    d_tilt = e.to_device(chain["w_tilt"]); d_tdb = e.to_device(chain["w_td_before"])
+    d_wfft = e.to_device(chain["w_fft"]); d_fd = e.to_device(chain["fd_mask"]); d_post = e.to_device(chain["w_post"])
+    s1 = e.empty((npix, nt)); s2 = e.empty((npix, nt)); s3 = e.empty((npix, nt))
+    d_fft = e.empty((npix, nf, 2)); d_amp = e.empty((npix, nf)); d_ph = e.empty((npix, nf))
+    s4 = e.empty((npix, nt)); s5 = e.empty((npix, nt)); d_img = e.empty((npix,))
+    e.apply_td_window(npix, d, d_tilt, s1)
+    e.apply_td_window(npix, s1, d_tdb, s2)
+    e.fft(npix, s2, d_wfft, None, s3, d_fft, d_amp, d_ph, None)
+    fft_unmasked = d_fft.download((nx, ny, nf, 2), np.float32)
+    e.apply_fd_mask(npix, d_fft, d_amp, d_fd)
+    e.ifft(npix, d_fft, None, s4, None)
+    e.apply_td_window(npix, s4, d_post, s5)
+    e.intensity(npix, s5, d_img)
+    # oracle, stage by stage
+    o1 = cube * chain["w_tilt"]
+    o2, _, _ = ob.td_bandpass(o1, time, float(time[0]), float(time[-1]), 2.0)
+    assert np.array_equal(s2.download((nx, ny, nt), np.float32), o2)
+    st = ob.fft_stage(o2, time, 0, 1.0, 7.0)
+    assert np.array_equal(s3.download((nx, ny, nt), np.float32), st["data"])
+    scale = np.abs(st["fft"]).max()
+    assert rel(fft_unmasked, st["fft"], scale) < TOL
+    of, oa = ob.fd_bandpass(st["fft"], st["amplitudes"], chain["frequency"], 0.2, 5.0, 0.1)
+    assert rel(d_fft.download((nx, ny, nf, 2), np.float32), of, scale) < TOL
+    assert rel(d_amp.download((nx, ny, nf), np.float32), oa, scale) < TOL
+    assert phase_ok(d_ph.download((nx, ny, nf), np.float32), st["phases"], st["amplitudes"])
+    ot, nerr = ob.ifft_stage(of, nt)
+    assert nerr == 0
+    assert rel(s4.download((nx, ny, nt), np.float32), ot) < TOL
+    o5, _, _ = ob.td_bandpass(ot, time, float(time[0]), float(time[-1]), 0.1)
+    assert rel(s5.download((nx, ny, nt), np.float32), o5) < TOL
+    assert rel(d_img.download((nx, ny), np.float32), ob.intensity(o5)) < TOL
+    for b in (d, d_tilt, d_tdb, d_wfft, d_fd, d_post, s1, s2, s3, d_fft, d_amp, d_ph, s4, s5, d_img):
+        b.free()
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (2, 3, 4096), (5, 5, 256), (4, 4, 1001), (1, 1, 128)])
+def test_fused_pipeline_vs_oracle(engine, shape):
+    nx, ny, nt = shape
+    time, cube = synth.make_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    chain = synth.default_chain(time)
+    got = synth.run_gpu_pipeline(engine, cube, chain)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"], ref["amplitudes"], scale) < TOL
+    assert rel(got["data"], ref["data"]) < TOL
+    assert rel(got["img"], ref["img"]) < TOL
+    # phases are taken before the band-pass; compare against the un-masked amplitude
+    st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(got["phases"], ref["phases"], st["amplitudes"])
+
+
+def test_knife_edge_real_traces(engine):
+    """16 real traces, Nt = 1001 (Bluestein path), default chain vs oracle and numpy fp64"""
+    k = np.load(os.path.join(GOLD, "knife_edge.npz"))
+    time = k["time"]
+    cube = ob.subtract_bias(k["traces"].reshape(4, 4, 1001))
+    engine.set_time_axis(time)
+    assert "bluestein" in engine.kernel_variant()
+    chain = synth.default_chain(time)
+    got = synth.run_gpu_pipeline(engine, cube, chain)
+    ref = ob.run_pipeline(cube, time, chain)
+    assert rel(got["fft"], ref["fft"], np.abs(ref["fft"]).max()) < TOL
+    assert rel(got["data"], ref["data"]) < TOL
+    X = np.fft.rfft(cube.astype(np.float64) * chain["w_pre"], axis=-1) * chain["fd_mask"]
+    G = got["fft"][..., 0] + 1j * got["fft"][..., 1]
+    assert np.abs(G - X).max() / np.abs(X).max() < TOL
+
+
+# ---- the reference's unit tests, through the C ABI --------------------------
+def test_reference_fft_roundtrip(engine):
+    """math_tools.rs:843-897"""
+    u = np.load(os.path.join(GOLD, "unit_signals.npz"))
+    sig, time = u["roundtrip_signal"], u["roundtrip_time"]
+    n = sig.size
+    engine.set_time_axis(time)
+    w = pkg.host_fft_window(time, 0, 0.0, 0.0)
+    assert np.all(w == 1.0)
+    got = gpu_fft_stage(engine, sig.reshape(1, 1, n), w)
+    d_fft = engine.to_device(got["fft"]); d_out = engine.empty((1, n))
+    engine.ifft(1, d_fft, None, d_out, None)
+    back = d_out.download((n,), np.float32)
+    assert np.abs(back - got["data"].ravel()).max() <= 1e-4
+    X = got["fft"][0, 0, :, 0] + 1j * got["fft"][0, 0, :, 1]
+    assert np.abs(X - u["roundtrip_fft"]).max() / np.abs(u["roundtrip_fft"]).max() < TOL
+    d_fft.free(); d_out.free()
+
+
+def test_reference_fd_bandpass_exact_zeros(engine):
+    """band_pass_fd.rs:475-567"""
+    u = np.load(os.path.join(GOLD, "unit_signals.npz"))
+    sig, freq = u["fd_signal"], u["fd_freq"]
+    n, k = sig.size, 9
+    time = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    engine.set_time_axis(time)
+    mask, lower, upper = pkg.host_fd_bandpass(freq, float(freq[k - 2]), float(freq[k + 2]), 0.0)
+    got = gpu_fft_stage(engine, sig.reshape(1, 1, n), np.ones(n, np.float32))
+    d_fft = engine.to_device(got["fft"]); d_amp = engine.to_device(got["amplitudes"]); d_m = engine.to_device(mask)
+    engine.apply_fd_mask(1, d_fft, d_amp, d_m)
+    amp = d_amp.download((n // 2 + 1,), np.float32)
+    fft = d_fft.download((n // 2 + 1, 2), np.float32)
+    assert np.all(amp[:lower] == 0.0) and np.all(amp[upper:] == 0.0)
+    assert np.all(fft[:lower] == 0.0) and np.all(fft[upper:] == 0.0)
+    assert amp[lower:upper].sum() > 0
+    for b in (d_fft, d_amp, d_m):
+        b.free()
+
+
+def test_reference_td_bandpass_exact_zeros(engine):
+    """band_pass_td_before_fft.rs:390-443"""
+    u = np.load(os.path.join(GOLD, "unit_signals.npz"))
+    time, sig = u["td_time"], u["td_signal"]
+    n = sig.size
+    engine.set_time_axis(time)
+    w, lo, hi, lower, upper = pkg.host_td_bandpass(time, 0.25, 0.55, 0.0)
+    assert (lower, upper) == tuple(u["td_idx"])
+    d = engine.to_device(sig); d_w = engine.to_device(w); d_o = engine.empty((n,))
+    engine.apply_td_window(1, d, d_w, d_o)
+    out = d_o.download((n,), np.float32)
+    assert np.all(out[:lower] == 0.0) and np.all(out[upper:] == 0.0)
+    assert np.array_equal(out[lower:upper], sig[lower:upper])
+    for b in (d, d_w, d_o):
+        b.free()
+
+
+# ---- reductions, ROI, scaling: bit-exact ---------------------------------
+def test_pixel_mean_bit_exact(engine):
+    rng = np.random.default_rng(0)
+    nx, ny, nf = 9, 13, 129
+    engine.set_time_axis(synth.make_time(256))
+    a = rng.standard_normal((nx, ny, nf)).astype(np.float32)
+    c = rng.standard_normal((nx, ny, nf, 2)).astype(np.float32)
+    for arr, ncomp in ((a, 1), (c, 2)):
+        d = engine.to_device(arr); o = engine.empty((nf * ncomp,))
+        engine.pixel_mean(nx, ny, nf, ncomp, d, o)
+        got = o.download((nf * ncomp,), np.float32)
+        assert np.array_equal(got, ob.pixel_mean(arr, ncomp).ravel())
+        s = engine.empty((nf * ncomp,))
+        engine.pixel_sum(nx * ny, nf, ncomp, d, s)
+        tot = s.download((nf * ncomp,), np.float32)
+        assert np.allclose(tot, arr.reshape(nx * ny, -1).astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+        d.free(); o.free(); s.free()
+
+
+def test_roi_masks_and_means_bit_exact(engine):
+    g = np.load(os.path.join(GOLD, "roi_masks.npz"))
+    names = sorted({k[: -len("_poly")] for k in g.files if k.endswith("_poly")})
+    rng = np.random.default_rng(2)
+    engine.set_time_axis(synth.make_time(64))
+    for (s0, s1) in ((32, 32), (129, 257)):
+        data = rng.standard_normal((s0, s1, 33)).astype(np.float32)
+        d_data = engine.to_device(data)
+        for name in names:
+            poly = g[name + "_poly"]
+            for scaling in (1, 2):
+                d_mask = engine.empty((s0, s1), np.uint8)
+                engine.roi_mask(poly, scaling, s0, s1, d_mask)
+                mask = d_mask.download((s0, s1), np.uint8)
+                assert np.array_equal(mask, g[f"{name}_{s0}x{s1}_s{scaling}_mask"]), (name, s0, scaling)
+                d_out = engine.empty((33,)); d_cnt = engine.empty((1,), np.uint32)
+                engine.roi_mean(d_data, s0, s1, 33, d_mask, d_out, d_cnt)
+                got = d_out.download((33,), np.float32)
+                assert np.array_equal(got, ob.average_polygon_roi(data, poly, scaling)), (name, s0, scaling)
+                assert int(d_cnt.download((1,), np.uint32)[0]) == int(mask.sum())
+                d_mask.free(); d_out.free(); d_cnt.free()
+        d_data.free()
+
+
+def test_roi_empty_mask_gives_zeros(engine):
+    engine.set_time_axis(synth.make_time(64))
+    data = np.ones((8, 8, 5), np.float32)
+    d = engine.to_device(data); m = engine.empty((8, 8), np.uint8); o = engine.to_device(np.full(5, 7, np.float32))
+    engine.roi_mask(np.array([[2, 2], [2, 2], [2, 2]], np.uint64), 1, 8, 8, m)
+    engine.roi_mean(d, 8, 8, 5, m, o)
+    assert np.all(o.download((5,), np.float32) == 0)
+    for b in (d, m, o):
+        b.free()
+
+
+@pytest.mark.parametrize("s", [2, 3])
+def test_scaling_bit_exact(engine, s):
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((7, 9, 40)).astype(np.float32)
+    c = rng.standard_normal((7, 9, 21, 2)).astype(np.float32)
+    for arr, ncomp, ln in ((a, 1, 40), (c, 2, 21)):
+        d = engine.to_device(arr); o = engine.empty((7 // s, 9 // s, ln * ncomp))
+        engine.scale3d(d, 7, 9, ln, ncomp, s, o)
+        got = o.download(ob.scale3d(arr, s, ncomp).shape, np.float32)
+        assert np.array_equal(got, ob.scale3d(arr, s, ncomp))
+        d.free(); o.free()
+
+
+def test_bias_and_intensity(engine):
+    nt = 1024
+    time = synth.make_time(nt)
+    engine.set_time_axis(time)
+    raw = synth.make_traces(np.arange(40), nt, subtract_bias=False)
+    d = engine.to_device(raw); img = engine.empty((40,))
+    engine.subtract_bias(40, d, img)
+    got = d.download((40, nt), np.float32)
+    ref = ob.subtract_bias(raw)
+    assert np.array_equal(got, ref)
+    assert rel(img.download((40,), np.float32), ob.intensity(ref)) < TOL
+    d.free(); img.free()
+
+
+def test_device_synth_matches_host(engine):
+    nt = 1024
+    time = synth.make_time(nt)
+    engine.set_time_axis(time)
+    d_t = engine.to_device(time); d = engine.empty((50, nt))
+    engine.synth_cube(d, 50, 12345, d_t)
+    got = d.download((50, nt), np.float32)
+    ref = synth.make_traces(np.arange(50) + 12345, nt)
+    assert np.abs(got - ref).max() < 1e-5  # expf/logf/sincos ulps, amplitudes ~1
+    d_t.free(); d.free()
+
+
+# ---- edge cases ------------------------------------------------------------
+def test_edge_cases(engine):
+    e = engine
+    with pytest.raises(pkg.ThzError) as ei:
+        e.set_time_axis(np.arange(5000, dtype=np.float32))  # non-pow2 > 4096
+    assert ei.value.code == -2
+    with pytest.raises(pkg.ThzError):
+        e.set_time_axis(np.zeros(1, np.float32))
+    e.set_time_axis(synth.make_time(256))
+    with pytest.raises(pkg.ThzError) as ei:
+        e.fft(4, None)
+    assert ei.value.code == -1
+    buf = e.empty((4, 256))
+    e.fft(0, buf, None, None, None, None, None, None, None)  # empty input: no-op
+    # ragged trace counts around the wave/block granularity
+    for npix in (1, 3, 4, 5, 257):
+        x = synth.make_traces(np.arange(npix), 256)
+        d = e.to_device(x); f = e.empty((npix, 129, 2))
+        e.fft(npix, d, None, None, None, f, None, None, None)
+        X = f.download((npix, 129, 2), np.float32)
+        ref = np.fft.rfft(x.astype(np.float64), axis=1)
+        assert np.abs((X[..., 0] + 1j * X[..., 1]) - ref).max() / np.abs(ref).max() < TOL
+        d.free(); f.free()
+    buf.free()
+    # largest supported power of two
+    nt = 16384
+    e.set_time_axis(synth.make_time(nt))
+    x = synth.make_traces(np.arange(3), nt)
+    d = e.to_device(x); f = e.empty((3, nt // 2 + 1, 2)); o = e.empty((3, nt))
+    e.fft(3, d, None, None, None, f, None, None, None)
+    e.ifft(3, f, None, o, None)
+    assert rel(o.download((3, nt), np.float32), x) < TOL
+    for b in (d, f, o):
+        b.free()
+
+
+def test_stage_timing_reports_device_time(engine):
+    engine.set_time_axis(synth.make_time(1024))
+    engine.enable_timing(True)
+    x = synth.make_traces(np.arange(64), 1024)
+    d = engine.to_device(x); f = engine.empty((64, 513, 2))
+    engine.fft(64, d, None, None, None, f, None, None, None)
+    assert engine.stage_time_ns(pkg.binding.STAGE_FFT) > 0
+    engine.enable_timing(False)
+    d.free(); f.free()

@@ -1,0 +1,68 @@
+"""Product host-side multiplier vectors (csrc/host_windows.cpp through the C
+ABI, no GPU) against the oracle's restatement and the reference test
+properties."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import thz_image_explorer_amd as pkg
+
+
+def _axes():
+    yield (1000 + 0.05 * np.arange(1024)).astype(np.float32)
+    yield (1879 + 0.05 * np.arange(1001)).astype(np.float32)
+    yield np.linspace(0.0, 1.0, 128, dtype=np.float32)
+    yield np.linspace(-3.0, 40.0, 77, dtype=np.float32)
+
+
+@pytest.mark.parametrize("wtype", range(5))
+def test_fft_window_matches_oracle_bitwise(wtype):
+    for time in _axes():
+        got = pkg.host_fft_window(time, wtype, 1.0, 7.0)
+        ref = ob.apply_window(wtype, np.ones(time.size, np.float32), time, 1.0, 7.0)
+        assert np.array_equal(got, ref)
+
+
+def test_window_properties_reference_test():
+    """math_tools.rs:757-840 through the product code"""
+    size = 128
+    time = np.linspace(0.0, 1.0, size, dtype=np.float32)
+    for k in range(5):
+        w = pkg.host_fft_window(time, k, 0.1, 0.1)
+        assert np.abs(w - w[::-1]).max() <= 1e-5
+        if k == 3:
+            assert abs(w[0] - 0.08) <= 1e-5
+        else:
+            assert w[0] <= 1e-5 and w[-1] <= 1e-5
+    assert abs(pkg.host_fft_window(time, 0, 0.1, 0.1)[size // 2] - 1.0) <= 1e-5
+    assert np.all(pkg.host_fft_window(time, 0, 0.0, 0.0) == 1.0)  # NaN -> 1: identity
+
+
+@pytest.mark.parametrize("low,high,width", [(0.2, 5.0, 0.1), (0.0, 100.0, 0.0), (-1.0, 3.0, 0.5),
+                                            (2.0, 2.05, 0.1), (9.0, 1.0, 0.1)])
+def test_fd_bandpass_matches_oracle(low, high, width):
+    for time in _axes():
+        freq = pkg.host_frequency_axis(time)
+        assert np.array_equal(freq, ob.frequency_axis(time))
+        got, l, u = pkg.host_fd_bandpass(freq, low, high, width)
+        ref, lr, ur = ob.fd_bandpass_window(freq, low, high, width)
+        assert (l, u) == (lr, ur)
+        assert np.array_equal(got, ref)
+        assert np.all(got[:l] == 0) and np.all(got[u:] == 0)
+
+
+@pytest.mark.parametrize("width", [2.0, 0.1, 0.0])
+def test_td_bandpass_matches_oracle(width):
+    for time in _axes():
+        for low, high in ((float(time[0]), float(time[-1])), (float(time[5]), float(time[40])),
+                          (-1e9, 1e9), (float(time[30]), float(time[10]))):
+            got, lo, hi, l, u = pkg.host_td_bandpass(time, low, high, width)
+            ref, lor, hir, lr, ur = ob.td_bandpass_window(time, low, high, width)
+            assert (lo, hi, l, u) == (lor, hir, lr, ur)
+            assert np.array_equal(got, ref)
+
+
+def test_default_td_bandpass_zeroes_last_sample():
+    time = (1000 + 0.05 * np.arange(4096)).astype(np.float32)
+    w, lo, hi, l, u = pkg.host_td_bandpass(time, float(time[0]), float(time[-1]), 2.0)
+    assert (l, u) == (0, 4095) and w[-1] == 0.0

@@ -54,12 +54,13 @@ SYMBOLS = [
     ("thz_nt", _SZ, [_P]),
     ("thz_nf", _SZ, [_P]),
     ("thz_get_frequency", C.c_int, [_P, _P]),
-    ("thz_make_fft_window", C.c_int, [_P, C.POINTER(WindowCfg), _P]),
-    ("thz_make_td_bandpass", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
-                                       _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    ("thz_make_fd_bandpass", C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P,
+    ("thz_host_frequency_axis", C.c_int, [_P, _SZ, _P]),
+    ("thz_host_fft_window", C.c_int, [_P, _SZ, C.POINTER(WindowCfg), _P]),
+    ("thz_host_adapted_blackman", C.c_int, [_P, _SZ, C.c_float, C.c_float, _P]),
+    ("thz_host_td_bandpass", C.c_int, [_P, _SZ, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.c_double, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("thz_host_fd_bandpass", C.c_int, [_P, _SZ, C.c_double, C.c_double, C.c_double, _P,
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    ("thz_make_tilt_taper", C.c_int, [_P, _P]),
     ("thz_fft", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("thz_apply_fd_mask", C.c_int, [_P, _SZ, _P, _P, _P]),
     ("thz_apply_fd_cmask", C.c_int, [_P, _SZ, _P, _P, _P]),
@@ -73,8 +74,10 @@ SYMBOLS = [
     ("thz_roi_mask", C.c_int, [_P, _P, _SZ, C.c_uint64, _SZ, _SZ, _P]),
     ("thz_roi_mean", C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _P, _P, C.c_int]),
     ("thz_scale3d", C.c_int, [_P, _P, _SZ, _SZ, _SZ, C.c_int, _SZ, _P]),
+    ("thz_synth_cube", C.c_int, [_P, _P, _SZ, C.c_uint64, _P, C.c_uint32, C.c_int]),
     ("thz_enable_timing", C.c_int, [_P, C.c_int]),
     ("thz_stage_time_ns", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
+    ("thz_timing_collect", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("thz_kernel_variant", C.c_char_p, [_P]),
 ]
 
@@ -97,6 +100,56 @@ def load_library() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _rc(rc: int, what: str):
+    if rc != THZ_OK:
+        raise ThzError(rc, what)
+
+
+# -- host multipliers (no GPU, no context) ---------------------------------
+def host_frequency_axis(time: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(time, np.float32)
+    out = np.empty(t.size // 2 + 1, np.float32)
+    _rc(load_library().thz_host_frequency_axis(t.ctypes.data, t.size, out.ctypes.data), "frequency_axis")
+    return out
+
+
+def host_fft_window(time, wtype=WIN_ADAPTED_BLACKMAN, lower=1.0, upper=7.0) -> np.ndarray:
+    t = np.ascontiguousarray(time, np.float32)
+    cfg = WindowCfg(int(wtype), float(lower), float(upper))
+    out = np.empty(t.size, np.float32)
+    _rc(load_library().thz_host_fft_window(t.ctypes.data, t.size, C.byref(cfg), out.ctypes.data), "fft_window")
+    return out
+
+
+def host_adapted_blackman(axis, lower: float, upper: float) -> np.ndarray:
+    a = np.ascontiguousarray(axis, np.float32)
+    out = np.empty(a.size, np.float32)
+    _rc(load_library().thz_host_adapted_blackman(a.ctypes.data, a.size, lower, upper, out.ctypes.data),
+        "adapted_blackman")
+    return out
+
+
+def host_td_bandpass(time, low: float, high: float, width: float):
+    """-> (multiplier, clamped_low, clamped_high, lower_idx, upper_idx)"""
+    t = np.ascontiguousarray(time, np.float32)
+    lo, hi = C.c_double(low), C.c_double(high)
+    l, u = C.c_int64(), C.c_int64()
+    out = np.empty(t.size, np.float32)
+    _rc(load_library().thz_host_td_bandpass(t.ctypes.data, t.size, C.byref(lo), C.byref(hi), width,
+                                            out.ctypes.data, C.byref(l), C.byref(u)), "td_bandpass")
+    return out, lo.value, hi.value, l.value, u.value
+
+
+def host_fd_bandpass(frequency, low: float, high: float, width: float):
+    """-> (multiplier, lower_idx, upper_idx)"""
+    f = np.ascontiguousarray(frequency, np.float32)
+    l, u = C.c_int64(), C.c_int64()
+    out = np.empty(f.size, np.float32)
+    _rc(load_library().thz_host_fd_bandpass(f.ctypes.data, f.size, low, high, width, out.ctypes.data,
+                                            C.byref(l), C.byref(u)), "fd_bandpass")
+    return out, l.value, u.value
 
 
 class DevBuf:
@@ -204,33 +257,6 @@ class Engine:
     def kernel_variant(self) -> str:
         return self.lib.thz_kernel_variant(self.ctx).decode()
 
-    # -- host multipliers
-    def make_fft_window(self, wtype=WIN_ADAPTED_BLACKMAN, lower=1.0, upper=7.0) -> np.ndarray:
-        cfg = WindowCfg(int(wtype), float(lower), float(upper))
-        out = np.empty(self.nt, np.float32)
-        self._check(self.lib.thz_make_fft_window(self.ctx, C.byref(cfg), out.ctypes.data))
-        return out
-
-    def make_td_bandpass(self, low: float, high: float, width: float):
-        lo, hi = C.c_double(low), C.c_double(high)
-        l, u = C.c_int64(), C.c_int64()
-        out = np.empty(self.nt, np.float32)
-        self._check(self.lib.thz_make_td_bandpass(self.ctx, C.byref(lo), C.byref(hi), width,
-                                                  out.ctypes.data, C.byref(l), C.byref(u)))
-        return out, lo.value, hi.value, l.value, u.value
-
-    def make_fd_bandpass(self, low: float, high: float, width: float):
-        l, u = C.c_int64(), C.c_int64()
-        out = np.empty(self.nf, np.float32)
-        self._check(self.lib.thz_make_fd_bandpass(self.ctx, low, high, width, out.ctypes.data,
-                                                  C.byref(l), C.byref(u)))
-        return out, l.value, u.value
-
-    def make_tilt_taper(self) -> np.ndarray:
-        out = np.empty(self.nt, np.float32)
-        self._check(self.lib.thz_make_tilt_taper(self.ctx, out.ctypes.data))
-        return out
-
     # -- stages
     def fft(self, npix, d_in, win_a=None, win_b=None, data_out=None, fft=None, amp=None,
             phase=None, fd_mask=None):
@@ -278,8 +304,18 @@ class Engine:
     def scale3d(self, arr, nx, ny, length, ncomp, s, out):
         self._check(self.lib.thz_scale3d(self.ctx, _dp(arr), nx, ny, length, ncomp, s, _dp(out)))
 
-    def enable_timing(self, on=True):
-        self._check(self.lib.thz_enable_timing(self.ctx, int(on)))
+    def synth_cube(self, d_out, ntraces, first_trace, d_time, seed=0x7A3D2026, subtract_bias=True):
+        self._check(self.lib.thz_synth_cube(self.ctx, _dp(d_out), ntraces, first_trace, _dp(d_time),
+                                            seed, int(subtract_bias)))
+
+    def enable_timing(self, mode=1):
+        self._check(self.lib.thz_enable_timing(self.ctx, int(mode)))
+
+    def timing_collect(self, stage: int):
+        """-> (total_ns, calls) of `stage` since the last collect (deferred mode)"""
+        t, n = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.thz_timing_collect(self.ctx, stage, C.byref(t), C.byref(n)))
+        return t.value, n.value
 
     def stage_time_ns(self, stage: int) -> int:
         v = C.c_uint64()

@@ -29,9 +29,15 @@ struct thz_ctx {
     bool have_plan = false;
     void *ws = nullptr;  // scratch workspace (pixel means, ROI lists)
     size_t ws_bytes = 0;
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 immediate (host waits per call), 2 deferred (no host wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t stage_ns[THZ_STAGE_COUNT] = {0};
+    struct Rec {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;        // deferred records awaiting thz_timing_collect
+    std::vector<hipEvent_t> pool;  // recycled events
 };
 
 namespace {
@@ -69,21 +75,44 @@ int ensure_ws(thz_ctx *ctx, size_t bytes)
     return THZ_OK;
 }
 
+hipEvent_t pool_event(thz_ctx *ctx)
+{
+    if (!ctx->pool.empty()) {
+        hipEvent_t e = ctx->pool.back();
+        ctx->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Brackets one stage call with events on the context's stream.
 struct StageTimer {
     thz_ctx *ctx;
     int stage;
+    hipEvent_t a = nullptr, b = nullptr;
     StageTimer(thz_ctx *c, int s) : ctx(c), stage(s)
     {
-        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (ctx->timing == 1) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (ctx->timing == 2) {
+            a = pool_event(ctx);
+            b = pool_event(ctx);
+            if (a) (void)hipEventRecord(a, ctx->stream);
+        }
     }
     ~StageTimer()
     {
-        if (!ctx->timing) return;
-        (void)hipEventRecord(ctx->ev1, ctx->stream);
-        if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
-                ctx->stage_ns[stage] = (uint64_t)((double)ms * 1e6);
+        if (ctx->timing == 1) {
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+            if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
+                    ctx->stage_ns[stage] = (uint64_t)((double)ms * 1e6);
+            }
+        } else if (ctx->timing == 2 && a && b) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->recs.push_back({stage, a, b});
         }
     }
 };
@@ -132,6 +161,8 @@ void thz_destroy(thz_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -235,10 +266,8 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     ctx->plan_d = plan_dev(H, d, n_sp ? d + n_tw : nullptr, n_ch ? d + n_tw + n_sp : nullptr,
                            n_bf ? d + n_tw + n_sp + n_ch : nullptr);
     ctx->time.assign(time, time + nt);
-    // frequency axis, io.rs:614-621: i / (t_last - t_first)
-    const float rng = time[nt - 1] - time[0];
     ctx->freq.resize(nt / 2 + 1);
-    for (size_t i = 0; i < ctx->freq.size(); ++i) ctx->freq[i] = (float)i / rng;
+    (void)thz_host_frequency_axis(time, nt, ctx->freq.data());
     ctx->have_plan = true;
     return THZ_OK;
 }
@@ -261,38 +290,41 @@ const char *thz_kernel_variant(const thz_ctx *ctx)
 
 /* ------------------------------------------------------ host multipliers */
 
-int thz_make_fft_window(const thz_ctx *ctx, const thz_window_cfg *cfg, float *out)
+int thz_host_frequency_axis(const float *time, size_t nt, float *frequency)
 {
-    if (!ctx || !cfg || !out) return THZ_ERR_INVALID;
-    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
-    if (cfg->type < 0 || cfg->type > 4) return THZ_ERR_INVALID;
-    fft_window(cfg->type, ctx->time.data(), ctx->time.size(), cfg->lower, cfg->upper, out);
+    if (!time || !frequency || nt < 2) return THZ_ERR_INVALID;
+    const float rng = time[nt - 1] - time[0];
+    for (size_t i = 0; i < nt / 2 + 1; ++i) frequency[i] = (float)i / rng;
     return THZ_OK;
 }
 
-int thz_make_td_bandpass(const thz_ctx *ctx, double *low, double *high, double window_width,
-                         float *out, int64_t *lower, int64_t *upper)
+int thz_host_fft_window(const float *time, size_t nt, const thz_window_cfg *cfg, float *out)
 {
-    if (!ctx || !low || !high || !out) return THZ_ERR_INVALID;
-    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
-    td_bandpass(ctx->time.data(), ctx->time.size(), low, high, window_width, out, lower, upper);
+    if (!time || !cfg || !out || cfg->type < 0 || cfg->type > 4) return THZ_ERR_INVALID;
+    fft_window(cfg->type, time, nt, cfg->lower, cfg->upper, out);
     return THZ_OK;
 }
 
-int thz_make_fd_bandpass(const thz_ctx *ctx, double low, double high, double window_width,
-                         float *out, int64_t *lower, int64_t *upper)
+int thz_host_adapted_blackman(const float *axis, size_t len, float lower, float upper, float *out)
 {
-    if (!ctx || !out) return THZ_ERR_INVALID;
-    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
-    fd_bandpass(ctx->freq.data(), ctx->freq.size(), low, high, window_width, out, lower, upper);
+    if (!axis || !out) return THZ_ERR_INVALID;
+    adapted_blackman(axis, len, lower, upper, out);
     return THZ_OK;
 }
 
-int thz_make_tilt_taper(const thz_ctx *ctx, float *out)
+int thz_host_td_bandpass(const float *time, size_t nt, double *low, double *high,
+                         double window_width, float *out, int64_t *lower, int64_t *upper)
 {
-    if (!ctx || !out) return THZ_ERR_INVALID;
-    if (!ctx->have_plan) return THZ_ERR_NOT_READY;
-    adapted_blackman(ctx->time.data(), ctx->time.size(), 0.0f, 7.0f, out);
+    if (!time || !low || !high || !out) return THZ_ERR_INVALID;
+    td_bandpass(time, nt, low, high, window_width, out, lower, upper);
+    return THZ_OK;
+}
+
+int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double high,
+                         double window_width, float *out, int64_t *lower, int64_t *upper)
+{
+    if (!frequency || !out) return THZ_ERR_INVALID;
+    fd_bandpass(frequency, nf, low, high, window_width, out, lower, upper);
     return THZ_OK;
 }
 
@@ -527,10 +559,48 @@ int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t l
     return check_launch(ctx);
 }
 
+int thz_synth_cube(thz_ctx *ctx, float *d_out, size_t ntraces, uint64_t first_trace,
+                   const float *d_time, uint32_t seed, int subtract_bias)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!d_out || !d_time) return fail(ctx, THZ_ERR_INVALID, "thz_synth_cube: null pointer");
+    if (ntraces == 0) return THZ_OK;
+    launch_synth(ctx->stream, d_out, ntraces, ctx->plan_d.nt, first_trace, d_time, seed,
+                 subtract_bias);
+    return check_launch(ctx);
+}
+
 int thz_enable_timing(thz_ctx *ctx, int enable)
 {
     if (!ctx) return THZ_ERR_INVALID;
-    ctx->timing = enable != 0;
+    if (enable < 0 || enable > 2) return THZ_ERR_INVALID;
+    ctx->timing = enable;
+    return THZ_OK;
+}
+
+int thz_timing_collect(thz_ctx *ctx, int stage, uint64_t *total_ns, uint64_t *count)
+{
+    if (!ctx || !total_ns || !count || stage < 0 || stage >= THZ_STAGE_COUNT) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t tot = 0, n = 0;
+    std::vector<thz_ctx::Rec> keep;
+    for (auto &r : ctx->recs) {
+        if (r.stage != stage) {
+            keep.push_back(r);
+            continue;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            tot += (uint64_t)((double)ms * 1e6);
+            ++n;
+        }
+        ctx->pool.push_back(r.a);
+        ctx->pool.push_back(r.b);
+    }
+    ctx->recs.swap(keep);
+    *total_ns = tot;
+    *count = n;
     return THZ_OK;
 }
 

@@ -564,6 +564,75 @@ __global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, 
 }
 
 // ---------------------------------------------------------------------------
+// Synthetic cube generator (bench / test input): counter-based
+// Philox4x32-10 so any tile is reproducible on host (tests/synth.py) or device.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    for (int r = 0; r < 10; ++r) {
+        if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01_24(uint32_t r)
+{
+    return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float synth_pulse(float tt)
+{
+    const float z = tt / 0.35f;
+    return -z * expf(-(z * z));
+}
+
+__device__ __forceinline__ float synth_sample(uint64_t trace, int i, int nt,
+                                              const float *__restrict__ time, uint32_t seed,
+                                              float A, float tc, float delta)
+{
+    const float tt = time[i];
+    const float s = A * synth_pulse(tt - tc) + (0.3f * A) * synth_pulse(tt - tc - delta);
+    const uint64_t g = trace * (uint64_t)nt + (uint64_t)i;
+    const uint64_t blk = g >> 2;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, seed, 0u, w);
+    const int l = (int)(g & 3);
+    const float ua = u01_24(l < 2 ? w[0] : w[2]), ub = u01_24(l < 2 ? w[1] : w[3]);
+    const float rad = sqrtf(-2.0f * logf(ua));
+    const float ang = 6.28318548202514648438f * ub;
+    const float nrm = (l & 1) ? rad * sinf(ang) : rad * cosf(ang);
+    return s + (0.01f * A) * nrm;
+}
+
+__global__ __launch_bounds__(256) void k_synth(float *__restrict__ out, size_t ntraces, int nt,
+                                               uint64_t first_trace,
+                                               const float *__restrict__ time, uint32_t seed,
+                                               int subtract_bias)
+{
+    const size_t total = ntraces * (size_t)nt;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t trace = first_trace + idx / nt;
+        const int i = (int)(idx % nt);
+        uint32_t w[4];
+        philox4x32_10((uint32_t)trace, (uint32_t)(trace >> 32), 0u, 1u, seed, 0u, w);
+        const float A = 1.0f + 0.5f * u01_24(w[0]);
+        const float tc = time[0] + 10.0f + 2.0f * u01_24(w[1]);
+        const float delta = 3.0f + 17.0f * u01_24(w[2]);
+        float v = synth_sample(trace, i, nt, time, seed, A, tc, delta);
+        if (subtract_bias) v -= synth_sample(trace, 0, nt, time, seed, A, tc, delta);
+        out[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline unsigned grid_1d(size_t total, unsigned block, unsigned cap)
@@ -695,6 +764,13 @@ void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size
 {
     const size_t total = (nx / s) * (ny / s) * L;
     THZ_LAUNCH(k_scale3d, grid_1d(total, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+}
+
+void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,
+                  const float *time, uint32_t seed, int subtract_bias)
+{
+    THZ_LAUNCH(k_synth, grid_1d(ntraces * nt, 256, kNumCU * 16), 256, 0, st, out, ntraces, nt,
+               first_trace, time, seed, subtract_bias);
 }
 
 }  // namespace thz
