@@ -86,7 +86,7 @@ def main():
                              f"(got WORLD_SIZE={world})")
     import torch
 
-    from thz_image_explorer_amd import Engine, binding
+    from thz_image_explorer_amd import Engine, binding, shard
     import synth
 
     dist = None
@@ -103,8 +103,7 @@ def main():
     nx, ny, nt = args.nx, args.ny, args.nt
     nf = nt // 2 + 1
     if args.scaling == "strong":
-        assert nx % world == 0, "nx must divide by the number of GPUs"
-        nx_loc, x0 = nx // world, rank * (nx // world)
+        x0, nx_loc = shard.slab(nx, world, rank)  # contiguous x rows, like rayon over Axis(0)
         nx_tot = nx
     else:
         nx_loc, x0 = nx, rank * nx
@@ -124,7 +123,6 @@ def main():
     # small products live in torch tensors so RCCL can move them
     t_img = torch.empty((nx_loc, ny), dtype=torch.float32, device=dev)
     t_sums = torch.empty(4 * nf, dtype=torch.float32, device=dev)  # [fft re/im interleaved | amp | phase]
-    t_img_all = torch.empty((world, nx_loc, ny), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     ext = torch.cuda.ExternalStream(eng.stream, device=dev)
     p_img, p_sums = t_img.data_ptr(), t_sums.data_ptr()
 
@@ -137,8 +135,8 @@ def main():
         if world > 1:
             with torch.cuda.stream(ext):  # collectives ordered after the kernels, no host sync
                 if not args.no_means:
-                    dist.all_reduce(t_sums)
-                dist.gather(t_img, list(t_img_all.unbind(0)) if rank == 0 else None, dst=0)
+                    shard.all_reduce_sums(t_sums, dist)      # C2
+                shard.gather_image(t_img, nx_tot, dist)      # C1
 
     def fence():
         eng.sync()

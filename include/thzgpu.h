@@ -96,6 +96,11 @@ int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes);
  * Supported nt: powers of two 4..8192 (Stockham path) and any other
  * 2 <= nt <= 4096 (Bluestein path over the same kernels). */
 int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
+/* Kernel family selection: 0 = automatic (register-resident three-pass "F"
+ * kernels for nt = 1024/2048/4096, LDS Stockham / Bluestein "G" kernels
+ * otherwise), 1 = G kernels for every length (A/B measurements, tests).
+ * Re-plans if a time axis is already set. */
+int thz_set_kernel_family(thz_ctx *ctx, int family);
 size_t thz_nt(const thz_ctx *ctx);
 size_t thz_nf(const thz_ctx *ctx);
 int thz_get_frequency(const thz_ctx *ctx, float *frequency /* nf */);

@@ -57,27 +57,30 @@ for nt in [4, 8, 64, 128, 256, 1024, 2048, 4096, 8192, 1001, 1000, 97, 3000]:
     eng._bufs = []
 
 # timing
-for (nx, ny, nt) in [(256, 256, 1024), (512, 512, 4096)]:
-    npix = nx * ny
-    time_ax = (1000 + 0.05 * np.arange(nt)).astype(np.float32)
-    eng.set_time_axis(time_ax); nf = eng.nf
-    x = rng.standard_normal((npix, nt)).astype(np.float32)
-    d_x = eng.to_device(x)
-    w = eng.to_device(np.ones(nt, np.float32)); m = eng.to_device(np.ones(nf, np.float32))
-    d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
-    for name, fn, bytes_per in [
-        ("fwd(M_fwd)", lambda: eng.fft(npix, d_x, w, None, None, d_fft, None, None, m), 8 * nt + 8),
-        ("fwd(all)", lambda: eng.fft(npix, d_x, w, None, None, d_fft, d_amp, d_ph, m), 4 * nt + 16 * nf),
-        ("inv", lambda: eng.ifft(npix, d_fft, w, d_out, d_img), 8 * nf + 4 * nt + 4),
-        ("pipeline(M_full)", lambda: eng.pipeline(npix, d_x, w, m, w, d_fft, d_amp, d_ph, d_out, d_img), 16 * nt + 20),
-    ]:
-        fn(); eng.sync()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps): fn()
-        eng.sync()
-        dt = (time.perf_counter() - t0) / reps
-        print(f"{nx}x{ny}x{nt} {name:18s} {dt*1e3:8.3f} ms  {npix/dt/1e6:8.2f} Mtraces/s  {npix*bytes_per/dt/1e9:8.1f} GB/s ({npix*bytes_per/dt/8e12*100:.1f}% of 8TB/s)", flush=True)
-    for b in list(eng._bufs): b.free()
-    eng._bufs = []
+import sys as _sys
+for fam in (0, 1):
+  eng.set_kernel_family(fam)
+  for (nx, ny, nt) in [(256, 256, 1024), (1024, 256, 1024), (512, 512, 2048), (512, 512, 4096)]:
+      npix = nx * ny
+      time_ax = (1000 + 0.05 * np.arange(nt)).astype(np.float32)
+      eng.set_time_axis(time_ax); nf = eng.nf
+      x = rng.standard_normal((npix, nt)).astype(np.float32)
+      d_x = eng.to_device(x)
+      w = eng.to_device(np.ones(nt, np.float32)); m = eng.to_device(np.ones(nf, np.float32))
+      d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
+      for name, fn, bytes_per in [
+          ("fwd(M_fwd)", lambda: eng.fft(npix, d_x, w, None, None, d_fft, None, None, m), 8 * nt + 8),
+          ("fwd(all)", lambda: eng.fft(npix, d_x, w, None, None, d_fft, d_amp, d_ph, m), 4 * nt + 16 * nf),
+          ("inv", lambda: eng.ifft(npix, d_fft, w, d_out, d_img), 8 * nf + 4 * nt + 4),
+          ("pipeline(M_full)", lambda: eng.pipeline(npix, d_x, w, m, w, d_fft, d_amp, d_ph, d_out, d_img), 16 * nt + 20),
+      ]:
+          fn(); eng.sync()
+          t0 = time.perf_counter()
+          reps = 5
+          for _ in range(reps): fn()
+          eng.sync()
+          dt = (time.perf_counter() - t0) / reps
+          print(f"fam={fam} {eng.kernel_variant():28s} {nx}x{ny}x{nt} {name:18s} {dt*1e3:8.3f} ms  {npix/dt/1e6:8.2f} Mtraces/s  {npix*bytes_per/dt/1e9:8.1f} GB/s ({npix*bytes_per/dt/8e12*100:.1f}% of 8TB/s)", flush=True)
+      for b in list(eng._bufs): b.free()
+      eng._bufs = []
 eng.close()

@@ -100,6 +100,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, F body)
 #define blockDim thz_emu::g_blockDim
 #define gridDim thz_emu::g_gridDim
 
+static inline unsigned int atomicOr(unsigned int *p, unsigned int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline void __syncthreads() { pthread_barrier_wait(&thz_emu::g_sync->block); }
 
 namespace thz {
@@ -127,6 +128,13 @@ inline float wave_shfl_xor(float v, int m) { return wave_shfl(v, lane_id() ^ m);
 }  // namespace thz
 
 #define THZ_DYN_LDS(name) unsigned char *name = thz_emu::g_dyn_lds
+namespace thz {
+template <class T>
+inline const T *launder_uniform(const T *p) { return p; }
+inline int launder_v(int x) { return x; }
+}  // namespace thz
+#define THZ_UNIFORM(x) (x)
+#define THZ_SCHED_FENCE() ((void)0)
 
 #define THZ_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
     thz_emu::run_grid((unsigned)(grid), (unsigned)(block), (size_t)(lds_bytes), [&]() { kernel(__VA_ARGS__); })

@@ -42,9 +42,14 @@ def _fwd(emu, x, wa, mask, nt):
     return dout, fft, amp, ph
 
 
-@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 4096, 1001, 30])
-def test_forward_inverse_vs_oracle(emu, nt):
-    npix = 6  # > waves per block: exercises the grid-stride loop and a ragged last block
+@pytest.mark.parametrize("family", ["auto", "g"])
+@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 30])
+def test_forward_inverse_vs_oracle(emu, nt, family):
+    emu.emu_allow_f(1 if family == "auto" else 0)
+    if family == "g" and nt not in (1024, 2048, 4096):
+        pytest.skip("only one family exists for this length")
+    assert emu.emu_family(nt) == (1 if (family == "auto" and nt in (1024, 2048, 4096)) else 0)
+    npix = 11  # > waves per block: exercises the grid-stride loop and a ragged last block
     rng = np.random.default_rng(nt)
     time = synth.make_time(nt)
     x = synth.make_traces(np.arange(npix) + 7, nt) + 0.05 * rng.standard_normal((npix, nt)).astype(np.float32)
@@ -71,9 +76,10 @@ def test_forward_inverse_vs_oracle(emu, nt):
     assert np.abs(img - (ref_t.astype(np.float64) ** 2).sum(1)).max() / img.max() < 1e-5
 
 
-@pytest.mark.parametrize("nt", [256, 1024])
+@pytest.mark.parametrize("nt", [256, 1024, 2048, 4096])
 def test_fused_pipeline_vs_oracle(emu, nt):
-    nx, ny = 2, 5
+    emu.emu_allow_f(1)
+    nx, ny = 3, 5
     time, cube = synth.make_cube(nx, ny, nt)
     chain = synth.default_chain(time)
     npix = nx * ny
@@ -89,6 +95,28 @@ def test_fused_pipeline_vs_oracle(emu, nt):
     assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
     assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / np.abs(ref["data"]).max() < 1e-5
     assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / ref["img"].max() < 1e-5
+
+
+@pytest.mark.parametrize("nt", [1024, 4096])
+def test_f_kernels_full_window_and_data_out(emu, nt):
+    """non-edge windows (Hann: every block != 1) take the F kernels' "full" path;
+    asking for the windowed trace splits the multiply into its own launch"""
+    emu.emu_allow_f(1)
+    npix = 9
+    time = synth.make_time(nt)
+    x = synth.make_traces(np.arange(npix) + 3, nt)
+    w = ob.apply_window(2, np.ones(nt, np.float32), time)
+    dout, fft, amp, ph = _fwd(emu, x, w, np.ones(nt // 2 + 1, np.float32), nt)
+    st = ob.fft_stage(x.reshape(1, npix, nt), time, 2)
+    assert np.array_equal(dout, st["data"][0])
+    scale = np.abs(st["fft"]).max()
+    assert np.abs(fft - st["fft"][0]).max() / scale < 1e-5
+    assert np.abs(amp - st["amplitudes"][0]).max() / scale < 1e-5
+    out = np.zeros_like(x)
+    img = np.zeros(npix, np.float32)
+    assert emu.emu_fft_inv(nt, C.c_size_t(npix), _p(np.ascontiguousarray(st["fft"][0])), _p(w), _p(out), _p(img)) == 0
+    back, _ = ob.ifft_stage(st["fft"], nt)
+    assert np.abs(out - back[0] * w).max() / np.abs(back).max() < 1e-5
 
 
 def test_roi_mask_kernel_bit_exact(emu):

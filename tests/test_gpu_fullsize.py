@@ -34,16 +34,18 @@ def test_fullsize_properties(engine, shape):
     d_out = e.empty((npix, nt)); d_img = e.empty((npix,))
     e.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img)
 
-    # (1) fused == stage-by-stage (same kernels' arithmetic, different launch structure)
+    # (1) fused == stage-by-stage: the spectrum is bit-identical (same epilogue
+    # code); the fused kernel feeds its inverse from registers/LDS in another lane
+    # layout, so the time trace agrees to rounding, not bitwise
     f2 = e.empty((npix, nf, 2)); a2 = e.empty((npix, nf)); p2 = e.empty((npix, nf)); o2 = e.empty((npix, nt)); i2 = e.empty((npix,))
     e.fft(npix, d_raw, d_pre, None, None, f2, a2, p2, d_fd)
     e.ifft(npix, f2, d_post, o2, i2)
     fft = d_fft.download((npix, nf, 2), np.float32)
     assert np.array_equal(fft, f2.download((npix, nf, 2), np.float32))
     out = d_out.download((npix, nt), np.float32)
-    assert np.array_equal(out, o2.download((npix, nt), np.float32))
+    assert np.abs(out - o2.download((npix, nt), np.float32)).max() / np.abs(out).max() < 2e-6
     img = d_img.download((npix,), np.float32)
-    assert np.array_equal(img, i2.download((npix,), np.float32))
+    assert np.abs(img - i2.download((npix,), np.float32)).max() / img.max() < 2e-6
 
     # (2) Parseval on the un-masked transform: sum x^2 = (|X0|^2 + 2 sum |Xk|^2 + |XN|^2)/nt
     e.fft(npix, d_raw, d_pre, None, o2, f2, a2, None, None)

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("thz_memcpy_d2d", C.c_int, [_P, _P, _P, _SZ]),
     ("thz_memset", C.c_int, [_P, _P, C.c_int, _SZ]),
     ("thz_set_time_axis", C.c_int, [_P, _P, _SZ]),
+    ("thz_set_kernel_family", C.c_int, [_P, C.c_int]),
     ("thz_nt", _SZ, [_P]),
     ("thz_nf", _SZ, [_P]),
     ("thz_get_frequency", C.c_int, [_P, _P]),
@@ -248,6 +249,10 @@ class Engine:
         self._check(self.lib.thz_set_time_axis(self.ctx, t.ctypes.data, t.size))
         self.nt = int(self.lib.thz_nt(self.ctx))
         self.nf = int(self.lib.thz_nf(self.ctx))
+
+    def set_kernel_family(self, family: int):
+        """0 = auto (F kernels where available), 1 = G kernels everywhere"""
+        self._check(self.lib.thz_set_kernel_family(self.ctx, int(family)))
 
     def frequency(self) -> np.ndarray:
         f = np.empty(self.nf, np.float32)

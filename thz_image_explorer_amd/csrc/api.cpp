@@ -27,6 +27,7 @@ struct thz_ctx {
     PlanDev plan_d{};
     c32 *d_tables = nullptr;  // one allocation: tw | tw_split | chirp_conj | bfft
     bool have_plan = false;
+    bool allow_f = true;  // thz_set_kernel_family
     void *ws = nullptr;  // scratch workspace (pixel means, ROI lists)
     size_t ws_bytes = 0;
     int timing = 0;  // 0 off, 1 immediate (host waits per call), 2 deferred (no host wait)
@@ -239,13 +240,15 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     if (!ctx || !time || nt < 2) return fail(ctx, THZ_ERR_INVALID, "time axis needs >= 2 samples");
     if (int rc = use_device(ctx)) return rc;
     PlanHost H;
-    if (!build_plan(nt, H))
+    if (!build_plan(nt, H, ctx->allow_f))
         return fail(ctx, THZ_ERR_UNSUPPORTED,
                     "unsupported trace length " + std::to_string(nt) +
                         " (powers of two 4..16384, or any length 2..4096)");
     const size_t n_tw = H.tw.size(), n_sp = H.tw_split.size(), n_ch = H.chirp_conj.size(),
                  n_bf = H.bfft.size();
-    const size_t total = n_tw + n_sp + n_ch + n_bf;
+    const size_t n_f1 = H.f_t1.size(), n_f2 = H.f_t2.size(), n_fw = H.f_w2n.size();
+    const size_t n_ones = (size_t)(H.nf + 1) / 2;  // nf floats of 1.0, counted in c32 units
+    const size_t total = n_tw + n_sp + n_ch + n_bf + n_f1 + n_f2 + n_fw + n_ones;
     c32 *d = nullptr;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMalloc((void **)&d, total * sizeof(c32)));
@@ -255,6 +258,10 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     pack.insert(pack.end(), H.tw_split.begin(), H.tw_split.end());
     pack.insert(pack.end(), H.chirp_conj.begin(), H.chirp_conj.end());
     pack.insert(pack.end(), H.bfft.begin(), H.bfft.end());
+    pack.insert(pack.end(), H.f_t1.begin(), H.f_t1.end());
+    pack.insert(pack.end(), H.f_t2.begin(), H.f_t2.end());
+    pack.insert(pack.end(), H.f_w2n.begin(), H.f_w2n.end());
+    pack.insert(pack.end(), n_ones, c32{1.0f, 1.0f});
     hipError_t e = hipMemcpy(d, pack.data(), total * sizeof(c32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(d);
@@ -263,12 +270,26 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     ctx->d_tables = d;
     ctx->plan_h = H;
+    const size_t o_f = n_tw + n_sp + n_ch + n_bf;
     ctx->plan_d = plan_dev(H, d, n_sp ? d + n_tw : nullptr, n_ch ? d + n_tw + n_sp : nullptr,
-                           n_bf ? d + n_tw + n_sp + n_ch : nullptr);
+                           n_bf ? d + n_tw + n_sp + n_ch : nullptr, n_f1 ? d + o_f : nullptr,
+                           n_f2 ? d + o_f + n_f1 : nullptr, n_fw ? d + o_f + n_f1 + n_f2 : nullptr,
+                           reinterpret_cast<const float *>(d + o_f + n_f1 + n_f2 + n_fw));
     ctx->time.assign(time, time + nt);
     ctx->freq.resize(nt / 2 + 1);
     (void)thz_host_frequency_axis(time, nt, ctx->freq.data());
     ctx->have_plan = true;
+    return THZ_OK;
+}
+
+int thz_set_kernel_family(thz_ctx *ctx, int family)
+{
+    if (!ctx || family < 0 || family > 1) return THZ_ERR_INVALID;
+    ctx->allow_f = family == 0;
+    if (ctx->have_plan) {
+        std::vector<float> t = ctx->time;
+        return thz_set_time_axis(ctx, t.data(), t.size());
+    }
     return THZ_OK;
 }
 

@@ -1,0 +1,723 @@
+// fft_f.hpp — "F" family: register-resident three-pass FFT, one trace per
+// wavefront, for the trace lengths the benchmarks are quoted on
+// (nt = 1024, 2048, 4096  ->  complex N = 512, 1024, 2048).
+//
+// Decomposition (decimation in frequency, N = R1*R2*R3):
+//     n = (N/R1) j1 + m,          m = R3 j2 + j3
+//     k = k1 + R1 k2 + R1 R2 k3
+//   pass 1  radix-R1 over j1, in registers straight from the coalesced global
+//           loads (lane l holds m = C1*l + b), twiddle W_N^(m k1)
+//   LDS exchange E1 (XOR-swizzled, conflict free both ways)
+//   pass 2  radix-R2 over j2, twiddle W_(R2 R3)^(j3 k2)
+//   LDS exchange E2 (XOR-swizzled)
+//   pass 3  radix-R3 over j3 -> natural order in LDS
+// Each wave owns N c32 of LDS (16 KiB at nt = 4096) and never meets a
+// workgroup barrier inside its trace loop; the block shares the twiddle
+// tables, staged once.  The inverse transform runs through the same passes
+// on re<->im swapped data.
+#pragma once
+
+#include "thz_device.hpp"
+
+namespace thz {
+
+// ---------------------------------------------------------------- butterflies
+// forward (exp(-i...)) DFTs of 4 / 8 / 16 points, natural order in and out
+
+__device__ __forceinline__ void bfly4(c32 &a0, c32 &a1, c32 &a2, c32 &a3)
+{
+    const c32 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    const c32 s13 = cadd(a1, a3), d13 = csub(a1, a3);
+    a0 = cadd(s02, s13);
+    a1 = c32{d02.re + d13.im, d02.im - d13.re};
+    a2 = csub(s02, s13);
+    a3 = c32{d02.re - d13.im, d02.im + d13.re};
+}
+
+// multiply by exp(-2*pi*i*e/16), e compile-time
+template <int E>
+__device__ __forceinline__ c32 mul_w16(c32 v)
+{
+    constexpr float C1 = 0.92387953251128673848f;  // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f;  // sin(pi/8)
+    constexpr float H = 0.70710678118654752440f;   // cos(pi/4)
+    constexpr int e = ((E % 16) + 16) % 16;
+    if constexpr (e == 0) return v;
+    else if constexpr (e == 1) return c32{v.re * C1 + v.im * S1, v.im * C1 - v.re * S1};
+    else if constexpr (e == 2) return c32{(v.re + v.im) * H, (v.im - v.re) * H};
+    else if constexpr (e == 3) return c32{v.re * S1 + v.im * C1, v.im * S1 - v.re * C1};
+    else if constexpr (e == 4) return c32{v.im, -v.re};
+    else if constexpr (e == 5) return c32{-v.re * S1 + v.im * C1, -v.im * S1 - v.re * C1};
+    else if constexpr (e == 6) return c32{(v.im - v.re) * H, -(v.re + v.im) * H};
+    else if constexpr (e == 7) return c32{-v.re * C1 + v.im * S1, -v.im * C1 - v.re * S1};
+    else if constexpr (e == 8) return c32{-v.re, -v.im};
+    else if constexpr (e == 9) return c32{-v.re * C1 - v.im * S1, -v.im * C1 + v.re * S1};
+    else if constexpr (e == 10) return c32{-(v.re + v.im) * H, (v.re - v.im) * H};
+    else if constexpr (e == 11) return c32{-v.re * S1 - v.im * C1, -v.im * S1 + v.re * C1};
+    else if constexpr (e == 12) return c32{-v.im, v.re};
+    else if constexpr (e == 13) return c32{v.re * S1 - v.im * C1, v.im * S1 + v.re * C1};
+    else if constexpr (e == 14) return c32{(v.re - v.im) * H, (v.re + v.im) * H};
+    else return c32{v.re * C1 - v.im * S1, v.im * C1 + v.re * S1};
+}
+
+__device__ __forceinline__ void dft4(c32 (&v)[4]) { bfly4(v[0], v[1], v[2], v[3]); }
+
+__device__ __forceinline__ void dft8(c32 (&v)[8])
+{
+    c32 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    c32 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    bfly4(e0, e1, e2, e3);
+    bfly4(o0, o1, o2, o3);
+    o1 = mul_w16<2>(o1);
+    o2 = mul_w16<4>(o2);
+    o3 = mul_w16<6>(o3);
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+__device__ __forceinline__ void dft16(c32 (&v)[16])
+{
+    // A_r[q] = sum_j x[r + 4j] W4^(jq)
+    bfly4(v[0], v[4], v[8], v[12]);
+    bfly4(v[1], v[5], v[9], v[13]);
+    bfly4(v[2], v[6], v[10], v[14]);
+    bfly4(v[3], v[7], v[11], v[15]);
+    // now v[r + 4q] = A_r[q]; twiddle W16^(r q)
+    v[5] = mul_w16<1>(v[5]);   v[6] = mul_w16<2>(v[6]);    v[7] = mul_w16<3>(v[7]);
+    v[9] = mul_w16<2>(v[9]);   v[10] = mul_w16<4>(v[10]);  v[11] = mul_w16<6>(v[11]);
+    v[13] = mul_w16<3>(v[13]); v[14] = mul_w16<6>(v[14]);  v[15] = mul_w16<9>(v[15]);
+    // y[q + 4p] = sum_r W4^(rp) (W16^(rq) A_r[q]) : radix-4 over r inside each q group
+    bfly4(v[0], v[1], v[2], v[3]);
+    bfly4(v[4], v[5], v[6], v[7]);
+    bfly4(v[8], v[9], v[10], v[11]);
+    bfly4(v[12], v[13], v[14], v[15]);
+    // v[4q + p] = y[q + 4p]  -> transpose to natural order
+    c32 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+template <int R>
+__device__ __forceinline__ void dftR(c32 (&v)[R])
+{
+    static_assert(R == 4 || R == 8 || R == 16, "radix");
+    if constexpr (R == 4) dft4(v);
+    else if constexpr (R == 8) dft8(v);
+    else dft16(v);
+}
+
+// ------------------------------------------------------------------- the plan
+template <int R1_, int R2_, int R3_>
+struct FPlan {
+    static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
+    static constexpr int N = R1 * R2 * R3;       // complex length
+    static constexpr int NT = 2 * N;             // real trace length
+    static constexpr int M1 = R2 * R3;           // N / R1
+    static constexpr int C1 = M1 / kWave;        // m values per lane in pass 1 (1 or 2)
+    static constexpr int C2 = R1 * R3 / kWave;   // radix-R2 butterflies per lane
+    static constexpr int C3 = R1 * R2 / kWave;   // radix-R3 butterflies per lane
+    static constexpr int NG = N / 256;           // 256-bin groups in the store layout
+    static_assert(R3 == 8, "pass-2 lane map assumes R3 = 8");
+    static_assert(C1 == 1 || C1 == 2, "C1");
+    static_assert(C2 >= 1 && C3 >= 1, "lanes must all own a butterfly");
+    // LDS per block, in c32: [T1: R1*M1][T2: R2*R3][mask: nf floats][per wave: N + 2]
+    static constexpr int T1_ENTRIES = R1 * M1;
+    static constexpr int T2_ENTRIES = R2 * R3;
+    static constexpr int MASK_ENTRIES = (N + 4) / 2;  // N + 1 floats, padded to 16 bytes
+    static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
+    static constexpr size_t lds_bytes(int waves)
+    {
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + waves * WAVE_ENTRIES) * sizeof(c32);
+    }
+
+    // E1[k1][m]: column bits 3..4 XORed with k1's low bits
+    __device__ static __forceinline__ int e1(int k1, int m) { return k1 * M1 + (m ^ ((k1 & 3) << 3)); }
+    // E2 row r = k2*R1 + k1 holds j3 = 0..7; 16-byte unit t of a row sits at t ^ ((r>>2)&3)
+    __device__ static __forceinline__ int e2(int r, int j3)
+    {
+        return r * 8 + ((((j3 >> 1) ^ ((r >> 2) & 3)) << 1) | (j3 & 1));
+    }
+};
+
+using FPlan4096 = FPlan<16, 16, 8>;
+using FPlan2048 = FPlan<8, 16, 8>;
+using FPlan1024 = FPlan<8, 8, 8>;
+
+// Host-built tables for one plan (c32 arrays in global memory):
+//   t1[k1*M1 + C1*l + b ... ] laid out [k1][m]      : W_N^(m k1)
+//   t2[k2*8 + j3]                                   : W_(R2*8)^(j3 k2)
+//   tl[]  lane constants, see FTables
+struct FTables {
+    const c32 *t1;
+    const c32 *t2;
+    const c32 *w2n;  // exp(-i*pi*k/N), k in [0, N): R2C / C2R split twiddles
+};
+
+// ------------------------------------------------------------------ the core
+// Lane-dependent LDS base indices (c32 units), computed once per kernel.  Every
+// LDS access of the core is base[...] + compile-time constant, so that it
+// becomes one ds_read/ds_write with an immediate offset and no per-access
+// address VGPR (without this the ~160 distinct addresses get hoisted out of the
+// trace loop and spill).
+template <class P>
+struct FAddr {
+    int w1[4];   // E1 write:  (C1*lane) ^ (q << 3),                q = k1 & 3
+    int r1[4];   // E1 read :  (lane>>3)*M1 + (lane&7) + 8*(s ^ q), s = j2 & 3, q = (lane>>3)&3
+    int w2[2];   // E2 write:  k1*8 + swz(j3, variant)              (k1 of c2 = 0)
+    int r3[4];   // E2 read :  lane*8 + 2*(u ^ ((lane>>2)&3)),      u = j >> 1
+    __device__ __forceinline__ void init(int lane)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w1[q] = (P::C1 * lane) ^ (q << 3);
+        const int ql = (lane >> 3) & 3;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) r1[s_] = (lane >> 3) * P::M1 + (lane & 7) + 8 * (s_ ^ ql);
+        // E2 swizzle operand of row r = k2*R1 + k1 is ((k2*R1/4) + (k1>>2)) & 3; with
+        // k1 = (lane>>3) + 8*c2 the lane part is ((lane>>5) + 2*c2) and the k2 part is
+        // 0 (R1 = 16) or 2*(k2&1) (R1 = 8): two variants cover everything.
+        const int j3 = lane & 7;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int sw = ((lane >> 5) + 2 * v) & 3;
+            w2[v] = (lane >> 3) * 8 + ((((j3 >> 1) ^ sw) << 1) | (j3 & 1));
+        }
+        const int q3 = (lane >> 2) & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r3[u] = lane * 8 + 2 * (u ^ q3);
+    }
+    // once per trace: keep the bases opaque (see launder_v)
+    __device__ __forceinline__ void refresh()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w1[i] = launder_v(w1[i]); r1[i] = launder_v(r1[i]); r3[i] = launder_v(r3[i]); }
+        w2[0] = launder_v(w2[0]);
+        w2[1] = launder_v(w2[1]);
+    }
+};
+
+// In:  r[c][j1] = z[(N/R1) j1 + C1*lane + c]   (forward data, or swapped data for
+//      the inverse).  Out: natural-order spectrum Z[0..N] in `buf` (Z[N] = Z[0]).
+// t1/t2 point to the block's LDS copies of the tables.  Ends with wave_sync().
+template <class P>
+__device__ __forceinline__ void f_core_pass1(c32 (&r)[P::C1][P::R1], c32 *buf, const c32 *t1,
+                                             const FAddr<P> &ad, int lane)
+{
+    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    // ---- pass 1
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+        dftR<R1>(r[c]);
+        THZ_SCHED_FENCE();
+    }
+    const c32 *t1l = t1 + launder_v(C1 * lane);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            c32 v = r[c][k1];
+            if (k1 > 0) v = cmul(v, t1l[k1 * M1 + c]);
+            buf[ad.w1[k1 & 3] + (k1 * M1 + c)] = v;  // = e1(k1, C1*lane + c)
+        }
+        if ((k1 & 3) == 3) THZ_SCHED_FENCE();
+    }
+    wave_sync();
+}
+
+template <class P>
+__device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAddr<P> &ad, int lane)
+{
+    constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, C2 = P::C2, C3 = P::C3;
+    constexpr int M1 = P::M1;
+    // ---- pass 2: lane owns (k1, j3) = ((lane>>3) + 8*c2, lane&7)
+    c32 b[C2][R2];
+#pragma unroll
+    for (int c2 = 0; c2 < C2; ++c2) {
+#pragma unroll
+        for (int j2 = 0; j2 < R2; ++j2)
+            b[c2][j2] = buf[ad.r1[j2 & 3] + (8 * (j2 & ~3) + 8 * c2 * M1)];  // = e1(k1, 8*j2 + j3)
+        THZ_SCHED_FENCE();
+    }
+    wave_sync();
+    const c32 *t2l = t2 + launder_v(lane & 7);
+#pragma unroll
+    for (int c2 = 0; c2 < C2; ++c2) {
+        dftR<R2>(b[c2]);
+        THZ_SCHED_FENCE();
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            c32 v = b[c2][k2];
+            if (k2 > 0) v = cmul(v, t2l[k2 * 8]);
+            // row = k2*R1 + k1, k1 = (lane>>3) + 8*c2
+            constexpr int kq = R1 / 4;
+            const int variant = (((k2 * kq) & 3) >> 1) ^ c2;  // ((k2*R1/4) + 2*c2) & 3 is 0 or 2
+            buf[ad.w2[variant & 1] + (k2 * R1 * 8 + 8 * c2 * 8)] = v;  // = e2(row, j3)
+            if ((k2 & 3) == 3) THZ_SCHED_FENCE();
+        }
+    }
+    wave_sync();
+    // ---- pass 3: lane owns row r3 = lane + 64*c3  (k1 = r3 % R1, k2 = r3 / R1)
+    c32 d[C3][R3];
+#pragma unroll
+    for (int c3 = 0; c3 < C3; ++c3) {
+#pragma unroll
+        for (int j = 0; j < R3; ++j) d[c3][j] = buf[ad.r3[j >> 1] + ((j & 1) + 512 * c3)];  // = e2(row, j)
+        THZ_SCHED_FENCE();
+    }
+    wave_sync();
+    const int nb = launder_v(lane);
+#pragma unroll
+    for (int c3 = 0; c3 < C3; ++c3) {
+        dftR<R3>(d[c3]);
+#pragma unroll
+        for (int k3 = 0; k3 < R3; ++k3) buf[nb + (kWave * c3 + R1 * R2 * k3)] = d[c3][k3];
+        THZ_SCHED_FENCE();
+    }
+    if (lane == 0) buf[P::N] = d[0][0];  // Z[N] := Z[0], so that Z[N-k] needs no wrap at k = 0
+    wave_sync();
+}
+
+// --------------------------------------------------------- R2C / C2R algebra
+// X[k] and conj(X[N-k]) from Z[k], Z[N-k]  (w = exp(-i*pi*k/N))
+__device__ __forceinline__ void r2c_pair(c32 a, c32 b, c32 w, c32 &xk, c32 &xnk_conj)
+{
+    const c32 E = c32{0.5f * (a.re + b.re), 0.5f * (a.im - b.im)};
+    const c32 O = c32{0.5f * (a.im + b.im), -0.5f * (a.re - b.re)};
+    const c32 t = cmul(O, w);
+    xk = cadd(E, t);
+    xnk_conj = csub(E, t);
+}
+
+// Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k])
+__device__ __forceinline__ c32 c2r_elem(c32 xk, c32 xnk_conj, c32 w)
+{
+    const c32 E = cadd(xk, xnk_conj);
+    const c32 D = csub(xk, xnk_conj);
+    const c32 O = c32{D.re * w.re + D.im * w.im, D.im * w.re - D.re * w.im};  // D * conj(w)
+    return c32{E.re - O.im, E.im + O.re};
+}
+
+}  // namespace thz
+
+// ----------------------------------------------------------------------------
+// F kernels
+// ----------------------------------------------------------------------------
+namespace thz {
+
+#ifdef THZ_EMU
+__device__ __forceinline__ void store_f4(float *p, float a, float b, float c, float d)
+{
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+}
+__device__ __forceinline__ void load_f4(const float *p, float &a, float &b, float &c, float &d)
+{
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+}
+#else
+// 16-byte vector access that only promises 4-byte alignment: spectrum rows are
+// nf = nt/2+1 elements long, so their starts are not 16-byte aligned.  gfx950
+// runs with unaligned access mode on; this still issues one dwordx4.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void store_f4(float *p, float a, float b, float c, float d)
+{
+    f4u v = {a, b, c, d};
+    *reinterpret_cast<f4u *>(p) = v;
+}
+__device__ __forceinline__ void load_f4(const float *p, float &a, float &b, float &c, float &d)
+{
+    const f4u v = *reinterpret_cast<const f4u *>(p);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+}
+#endif
+
+struct FArgs {
+    size_t npix;
+    const float *in;        // (npix, nt) raw traces            [fwd, pipeline]
+    const float *pre_win;   // (nt); may be null only when pre_blocks == 0
+    c32 *fft_out;           // (npix, nf), required
+    float *amp_out;         // (npix, nf), required when the kernel is built with AMP_PHASE
+    float *ph_out;          // (npix, nf), required when the kernel is built with AMP_PHASE
+    const float *mask;      // (nf), required (a vector of ones when no band-pass is wanted)
+    const c32 *fft_in;      // (npix, nf)                        [inv only]
+    const float *post_win;  // (nt); may be null only when post_blocks == 0
+    float *data_out;        // (npix, nt) final trace            [inv, pipeline]
+    float *img;             // (npix) or null
+};
+
+// Compile-time configuration bits of k_f.  Runtime null checks inside the fully
+// unrolled passes turn into dozens of tiny basic blocks and make the register
+// allocator spill, so everything optional is a template flag instead.
+enum : int {
+    kCfgAmpPhase = 1  // also write |X| and the unwrapped phase
+};
+
+enum : int { kFwd = 0, kInv = 1, kPipe = 2 };
+
+// Loads one trace's samples for this lane: raw[j1][4] (C1 = 2) or raw[j1][2].
+template <class P>
+__device__ __forceinline__ void f_load_raw(const float *__restrict__ x, int lane,
+                                           float (&raw)[P::R1][2 * P::C1])
+{
+#pragma unroll
+    for (int j1 = 0; j1 < P::R1; ++j1) {
+        if constexpr (P::C1 == 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + 4 * (kWave * j1 + lane));
+            raw[j1][0] = v.x; raw[j1][1] = v.y; raw[j1][2] = v.z; raw[j1][3] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(x + 2 * (kWave * j1 + lane));
+            raw[j1][0] = v.x; raw[j1][1] = v.y;
+        }
+    }
+}
+
+template <class P>
+__device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane, int j1,
+                                           float (&out)[2 * P::C1])
+{
+    if constexpr (P::C1 == 2) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + 4 * (kWave * j1 + lane));
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+        const float2 v = *reinterpret_cast<const float2 *>(w + 2 * (kWave * j1 + lane));
+        out[0] = v.x; out[1] = v.y;
+    }
+}
+
+// Spectrum epilogue in the store layout: lane owns bins k = 256 g + 4 lane + c.
+// buf holds Z[0..N) in natural order.
+template <class P, bool AMP_PHASE>
+__device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *__restrict__ w2n,
+                                                    const float *mask, size_t p, const FArgs &A,
+                                                    int lane)
+{
+    constexpr int N = P::N, NG = P::NG;
+    const int nf = N + 1;
+    const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
+    constexpr bool want_phase = AMP_PHASE;
+    c32 wl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wl[c] = w2n[4 * lane + c];
+    float carry = 0.0f;       // sum of adjusted differences of all previous groups
+    float prev_tail = 0.0f;   // raw phase of the last bin of the previous group
+    float first = 0.0f;       // raw phase of bin 0
+    float last_unwrapped = 0.0f, last_raw = 0.0f;
+    c32 x_nyq = c32{0.0f, 0.0f};
+    const int kb = launder_v(4 * lane);           // first bin of this lane in group 0
+    const int rb = launder_v(N - 3 - 4 * lane);   // index of Z[N - (kb + 3)]
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const int k0 = 256 * g + kb;
+        const c32 wg = w2n[256 * g];  // wave-uniform
+        const c32 *zf = buf + k0;            // Z[k0 + c]      = zf[c]
+        const c32 *zr = buf + (rb - 256 * g);  // Z[N - (k0 + c)] = zr[3 - c]
+        c32 X[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const c32 a = zf[c], b = zr[3 - c];
+            c32 xk, xn;
+            r2c_pair(a, b, g == 0 ? wl[c] : cmul(wl[c], wg), xk, xn);
+            X[c] = xk;
+            if (g == 0 && c == 0) x_nyq = xn;  // lane 0: conj(X[N]) = X[N] (real)
+        }
+        float m[4];
+        {
+            const float4 mv = *reinterpret_cast<const float4 *>(mask + k0);  // LDS copy
+            m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
+        }
+        if constexpr (AMP_PHASE) {
+            float a[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = sqrtf(fmaf(X[c].re, X[c].re, X[c].im * X[c].im)) * m[c];
+            store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
+        }
+        {
+            float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
+            store_f4(f, X[0].re * m[0], X[0].im * m[0], X[1].re * m[1], X[1].im * m[1]);
+            store_f4(f + 4, X[2].re * m[2], X[2].im * m[2], X[3].re * m[3], X[3].im * m[3]);
+        }
+        if constexpr (want_phase) {
+            float ph[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ph[c] = atan2f(X[c].im, X[c].re);
+            if (g == 0) first = wave_shfl(ph[0], 0);
+            float prev = wave_shfl_up(ph[3], 1);
+            if (lane == 0) prev = prev_tail;
+            float s[4];
+            float run = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float d = ph[c] - (c == 0 ? prev : ph[c - 1]);
+                if (d > kPi) d -= kTwoPi;
+                else if (d < -kPi) d += kTwoPi;
+                if (g == 0 && c == 0 && lane == 0) d = 0.0f;
+                run += d;
+                s[c] = run;
+            }
+            const float incl = wave_scan_add(run);
+            float excl = wave_shfl_up(incl, 1);
+            if (lane == 0) excl = 0.0f;
+            const float base = carry + excl;
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = first + (base + s[c]);
+            store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
+            carry += wave_shfl(incl, kWave - 1);
+            prev_tail = wave_shfl(ph[3], kWave - 1);
+            if (g == NG - 1) {
+                last_unwrapped = wave_shfl(y[3], kWave - 1);
+                last_raw = prev_tail;
+            }
+        }
+    }
+    // Nyquist bin k = N (real): lane 0
+    if (lane == 0) {
+        const float mN = mask[N];
+        const float xr = x_nyq.re;
+        A.fft_out[p * nf + N] = c32{xr * mN, 0.0f};
+        if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = fabsf(xr) * mN;
+        if constexpr (want_phase) {
+            const float phn = atan2f(0.0f, xr);
+            float d = phn - last_raw;
+            if (d > kPi) d -= kTwoPi;
+            else if (d < -kPi) d += kTwoPi;
+            A.ph_out[p * nf + N] = last_unwrapped + d;
+        }
+    }
+}
+
+// Builds the (swapped) input of the inverse core in the core layout
+// r[c][j1] <- swap(Z'[n]), n = M1 j1 + C1 lane + c.
+//   FROM_Z: buf holds the forward transform Z (fused pipeline); X is derived
+//           on the fly and masked.
+//   else  : buf holds the spectrum X[0..N) itself and x_n = X[N].re.
+template <class P, bool FROM_Z>
+__device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__restrict__ w2n,
+                                                const float *__restrict__ mask, float x_n, int lane,
+                                                c32 (&r)[P::C1][P::R1])
+{
+    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    c32 wl[C1];
+#pragma unroll
+    for (int c = 0; c < C1; ++c) wl[c] = w2n[C1 * lane + c];
+    // n = M1 j1 + C1 lane + c: forward index fb + (M1 j1 + c); the mirrored index
+    // N - n is written as rbase + (TOP - (M1 j1 + c)) so that it, too, is a base
+    // plus a non-negative immediate
+    constexpr int TOP = M1 * (R1 - 1) + C1 - 1;
+    const int fb = launder_v(C1 * lane);
+    const int rbase = launder_v(N - TOP - C1 * lane);
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) {
+        const c32 wg = w2n[M1 * j1];  // wave-uniform
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            const int off = M1 * j1 + c;
+            const c32 w = j1 == 0 ? wl[c] : cmul(wl[c], wg);
+            c32 xk, xnc;  // X[n], conj(X[N-n])
+            if constexpr (FROM_Z) {
+                r2c_pair(buf[fb + off], buf[rbase + (TOP - off)], w, xk, xnc);
+                const float mk = mask[fb + off], mn = mask[rbase + (TOP - off)];
+                xk = c32{xk.re * mk, xk.im * mk};
+                xnc = c32{xnc.re * mn, xnc.im * mn};
+            } else {
+                xk = buf[fb + off];
+                if (off == 0) {
+                    // n == 0 only in lane 0; elsewhere X[N - n] is a regular bin
+                    const c32 mirror = buf[(rbase + TOP) & (N - 1)];
+                    if (lane == 0) {
+                        xk.im = 0.0f;  // realfft ignores / rejects these imaginary parts (a'-4)
+                        xnc = c32{x_n, 0.0f};
+                    } else {
+                        xnc = cconj(mirror);
+                    }
+                } else {
+                    xnc = cconj(buf[rbase + (TOP - off)]);
+                }
+            }
+            const c32 z = c2r_elem(xk, xnc, w);
+            r[c][j1] = c32{z.im, z.re};
+        }
+        if ((j1 & 1) == 1) THZ_SCHED_FENCE();
+    }
+}
+
+// Final stage of the inverse: buf holds the swapped result R in natural order.
+// Window block bits: bit j set <=> samples [j*NT/R1, (j+1)*NT/R1) of a time
+// multiplier hold a value != 1.  Each block scans the (L2-resident) vector once
+// in its prologue.  The usual multipliers are edge tapers (the reference's
+// adapted-Blackman windows and Time Band Pass), i.e. only block 0 and the last
+// two blocks are set: those launches read 3 small pieces of the table per trace
+// instead of all of it.  Anything else takes the "full" path.
+template <class P>
+__device__ __forceinline__ bool f_edge_only(uint32_t blocks)
+{
+    constexpr uint32_t edge = 1u | (1u << (P::R1 - 1)) | (1u << (P::R1 - 2));
+    return (blocks & ~edge) == 0;
+}
+
+// does block j need its multiply?  (wave-uniform; FULL is a compile-time copy)
+template <class P, bool FULL>
+__device__ __forceinline__ bool f_block_on(uint32_t blocks, int j)
+{
+    if constexpr (FULL) return true;
+    else if (j == 0 || j >= P::R1 - 2) return ((blocks >> j) & 1u) != 0;
+    else return false;
+}
+
+template <class P, bool WIN_FULL>
+__device__ __forceinline__ void f_time_epilogue(const c32 *buf, size_t p, const FArgs &A,
+                                                uint32_t post_blocks, int lane)
+{
+    constexpr int NT = P::NT, R1 = P::R1, C1 = P::C1;
+    const float fnt = (float)NT;
+    const float *post_w = launder_uniform(A.post_win);
+    const int ob = launder_v(C1 * lane);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R1; ++j) {
+        float v[2 * C1];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            const c32 rr = buf[ob + (C1 * kWave * j + c)];
+            v[2 * c] = rr.im / fnt;
+            v[2 * c + 1] = rr.re / fnt;
+        }
+        if (f_block_on<P, WIN_FULL>(post_blocks, j)) {
+            float w[2 * C1];
+            f_load_win<P>(post_w, lane, j, w);
+#pragma unroll
+            for (int i = 0; i < 2 * C1; ++i) v[i] *= w[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * C1; ++i) acc += v[i] * v[i];
+        float *o = A.data_out + p * NT;
+        if constexpr (C1 == 2)
+            *reinterpret_cast<float4 *>(o + 4 * (kWave * j + lane)) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            *reinterpret_cast<float2 *>(o + 2 * (kWave * j + lane)) = make_float2(v[0], v[1]);
+        if ((j & 1) == 1) THZ_SCHED_FENCE();
+    }
+    if (A.img) {
+        acc = wave_reduce_add(acc);
+        if (lane == 0) A.img[p] = acc;
+    }
+}
+
+template <class P, int MODE, int CFG>
+__global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int N = P::N, NT = P::NT, R1 = P::R1, C1 = P::C1;
+    constexpr bool AMP_PHASE = (CFG & kCfgAmpPhase) != 0;
+    const int nf = N + 1;
+    const int lane = lane_id();
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    c32 *t1 = reinterpret_cast<c32 *>(lds);
+    c32 *t2 = t1 + P::T1_ENTRIES;
+    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES);
+    c32 *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    if (MODE != kInv)
+        for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    // window block bits (see f_edge_only), kept in the two pad floats behind the mask
+    unsigned int *bits = reinterpret_cast<unsigned int *>(mask_s + (2 * P::MASK_ENTRIES - 2));
+    if (threadIdx.x < 2) bits[threadIdx.x] = 0u;
+    __syncthreads();
+    {
+        constexpr int BLK = NT / R1;
+        unsigned int mine_pre = 0u, mine_post = 0u;
+        for (int i = (int)threadIdx.x; i < NT; i += (int)blockDim.x) {
+            if (MODE != kInv && A.pre_win && A.pre_win[i] != 1.0f) mine_pre |= 1u << (i / BLK);
+            if (MODE != kFwd && A.post_win && A.post_win[i] != 1.0f) mine_post |= 1u << (i / BLK);
+        }
+        if (mine_pre) atomicOr(&bits[0], mine_pre);
+        if (mine_post) atomicOr(&bits[1], mine_post);
+    }
+    __syncthreads();
+    const uint32_t pre_blocks = THZ_UNIFORM((int)bits[0]);
+    const uint32_t post_blocks = THZ_UNIFORM((int)bits[1]);
+    const bool pre_edge = f_edge_only<P>(pre_blocks);
+    const bool post_edge = f_edge_only<P>(post_blocks);
+
+    FAddr<P> ad;
+    ad.init(lane);
+    const size_t stride = (size_t)gridDim.x * wpb;
+    size_t p = (size_t)blockIdx.x * wpb + wib;
+    float raw[R1][2 * C1];
+    if (MODE != kInv && p < A.npix) f_load_raw<P>(A.in + p * NT, lane, raw);
+
+    for (; p < A.npix; p += stride) {
+        c32 r[C1][R1];
+        ad.refresh();
+        if constexpr (MODE != kInv) {
+            const float *pre_w = launder_uniform(A.pre_win);
+            const float *mask_l = launder_uniform((const float *)mask_s);
+            // window, then hand the samples to pass 1
+            if (pre_edge) {
+#pragma unroll
+                for (int j1 = 0; j1 < R1; ++j1) {
+                    if (f_block_on<P, false>(pre_blocks, j1)) {
+                        float w[2 * C1];
+                        f_load_win<P>(pre_w, lane, j1, w);
+#pragma unroll
+                        for (int i = 0; i < 2 * C1; ++i) raw[j1][i] *= w[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j1 = 0; j1 < R1; ++j1) {
+                    float w[2 * C1];
+                    f_load_win<P>(pre_w, lane, j1, w);
+#pragma unroll
+                    for (int i = 0; i < 2 * C1; ++i) raw[j1][i] *= w[i];
+                    if ((j1 & 3) == 3) THZ_SCHED_FENCE();
+                }
+            }
+#pragma unroll
+            for (int j1 = 0; j1 < R1; ++j1) {
+#pragma unroll
+                for (int c = 0; c < C1; ++c) r[c][j1] = c32{raw[j1][2 * c], raw[j1][2 * c + 1]};
+            }
+            // The next trace of this wave is prefetched into registers right
+            // after pass 1 (of the inverse transform in the fused chain): `r` is dead
+            // by then, so the 16 KiB of prefetch registers never coexist with it.
+            f_core_pass1<P>(r, buf, t1, ad, lane);
+            if (MODE == kFwd && p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
+            f_core_pass23<P>(buf, t2, ad, lane);
+            f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform(T.w2n), mask_l, p, A, lane);
+            if constexpr (MODE == kPipe) {
+                f_inverse_input<P, true>(buf, launder_uniform(T.w2n), mask_l, 0.0f, lane, r);
+                wave_sync();  // every lane has read Z before the core overwrites buf
+                f_core_pass1<P>(r, buf, t1, ad, lane);
+                if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
+                f_core_pass23<P>(buf, t2, ad, lane);
+                if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);
+                else f_time_epilogue<P, true>(buf, p, A, post_blocks, lane);
+                wave_sync();
+            } else {
+                wave_sync();
+            }
+        } else {
+            // spectrum -> LDS in natural order (X[N] is real and travels in a register)
+            const c32 *Xg = A.fft_in + p * nf;
+            for (int k = lane; k < N; k += kWave) buf[k] = Xg[k];
+            const float x_n = Xg[N].re;
+            wave_sync();
+            f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, x_n, lane, r);
+            wave_sync();
+            f_core_pass1<P>(r, buf, t1, ad, lane);
+            f_core_pass23<P>(buf, t2, ad, lane);
+            if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);
+            else f_time_epilogue<P, true>(buf, p, A, post_blocks, lane);
+            wave_sync();
+        }
+    }
+}
+
+}  // namespace thz

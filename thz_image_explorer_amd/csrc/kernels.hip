@@ -18,6 +18,7 @@
 //   block-mean scaling                  src/math_tools.rs:273-301
 //   load-time bias subtraction          src/io.rs:578-596
 #include "kernels.hpp"
+#include "fft_f.hpp"
 
 namespace thz {
 
@@ -677,10 +678,64 @@ static inline void wave_launch_geometry(const PlanDev &P, size_t npix, unsigned 
     *grid = (unsigned)g;
 }
 
+void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
+                      float *out);
+
+// F family: 8 waves per block share the twiddle tables in LDS; persistent grid.
+template <class PL, int MODE, int CFG>
+static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
+{
+    constexpr unsigned kBlock = 512, kWpb = kBlock / kWave;
+    const size_t lds = PL::lds_bytes(kWpb);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    size_t g = (A.npix + kWpb - 1) / kWpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (g < 1) g = 1;
+    FTables T{P.f_t1, P.f_t2, P.f_w2n};
+    allow_dynamic_lds(k_f<PL, MODE, CFG>, lds);
+    THZ_LAUNCH((k_f<PL, MODE, CFG>), (unsigned)g, kBlock, lds, st, A, T);
+}
+
+template <int MODE, int CFG>
+static void dispatch_f_size(hipStream_t st, const PlanDev &P, const FArgs &A)
+{
+    switch (P.nt) {
+    case 4096: launch_f<FPlan4096, MODE, CFG>(st, P, A); break;
+    case 2048: launch_f<FPlan2048, MODE, CFG>(st, P, A); break;
+    default: launch_f<FPlan1024, MODE, CFG>(st, P, A); break;
+    }
+}
+
+template <int MODE>
+static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool amp_phase)
+{
+    if (MODE == kInv || !amp_phase) dispatch_f_size<MODE, 0>(st, P, A);
+    else dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A);
+}
+
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
                     float *amp_out, float *ph_out, const float *mask)
 {
+    // F kernels: one window, spectrum required, |X| and phase both or neither,
+    // no windowed-trace output.  When the stage's `data` output is wanted the
+    // multiply runs as its own elementwise launch first (bit-identical: the
+    // same single f32 multiply per window).
+    if (P.family == kFamilyF && data_out && wa && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
+        launch_td_window(st, npix, P.nt, in, wa, data_out);
+        if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
+        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        return;
+    }
+    if (P.family == kFamilyF && !wb && !data_out && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
+        FArgs A{};
+        A.npix = npix; A.in = in; A.pre_win = wa; A.fft_out = fft_out; A.amp_out = amp_out;
+        A.ph_out = ph_out; A.mask = mask ? mask : P.ones;
+        dispatch_f<kFwd>(st, P, A, amp_out != nullptr);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
@@ -692,6 +747,12 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
 void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *fft_in,
                     const float *win, float *out, float *img)
 {
+    if (P.family == kFamilyF) {
+        FArgs A{};
+        A.npix = npix; A.fft_in = fft_in; A.post_win = win; A.data_out = out; A.img = img;
+        dispatch_f<kInv>(st, P, A, false);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
@@ -703,6 +764,14 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img)
 {
+    if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
+        FArgs A{};
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = fft_out; A.amp_out = amp_out;
+        A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.post_win = post_win;
+        A.data_out = data_out; A.img = img;
+        dispatch_f<kPipe>(st, P, A, true);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);

@@ -27,7 +27,16 @@ struct PlanDev {
     const c32 *tw_split;  // pow2: exp(-2*pi*i*k/nt), k in [0, N/2]
     const c32 *chirp_conj;  // bluestein: exp(-i*pi*n^2/nt), n in [0, nt)
     const c32 *bfft;        // bluestein: FFT_N(chirp filter)/N, N entries
+    // "F" family (register-resident three-pass transform, fft_f.hpp); used when
+    // family == kFamilyF (nt = 1024 / 2048 / 4096)
+    int family;
+    const c32 *f_t1;   // [k1][m]    W_N^(m k1)
+    const c32 *f_t2;   // [k2][j3]   W_(8 R2)^(j3 k2)
+    const c32 *f_w2n;  // [k]        exp(-i*pi*k/N), k in [0, N)
+    const float *ones; // nf floats of 1.0 (stand-in mask)
 };
+
+enum : int { kFamilyG = 0, kFamilyF = 1 };
 
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,

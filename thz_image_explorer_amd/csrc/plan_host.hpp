@@ -17,8 +17,21 @@ struct PlanHost {
     int nt = 0, nf = 0, mode = kModePow2, log2n = 0;
     int buf_entries = 0, lds_per_wave = 0, waves_per_block = 1;
     std::vector<c32> tw, tw_split, chirp_conj, bfft;
+    int family = kFamilyG;
+    std::vector<c32> f_t1, f_t2, f_w2n;
     const char *variant = "";
 };
+
+// F-family factorisation of the half-length complex transform (fft_f.hpp)
+inline bool f_factors(size_t nt, int &r1, int &r2, int &r3)
+{
+    switch (nt) {
+    case 4096: r1 = 16; r2 = 16; r3 = 8; return true;
+    case 2048: r1 = 8; r2 = 16; r3 = 8; return true;
+    case 1024: r1 = 8; r2 = 8; r3 = 8; return true;
+    default: return false;
+    }
+}
 
 inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
 
@@ -46,7 +59,7 @@ inline void host_fft_pow2(std::vector<std::complex<double>> &a)
 }
 
 // Returns false when nt is outside the supported range.
-inline bool build_plan(size_t nt, PlanHost &P)
+inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
 {
     const double pi = 3.14159265358979323846;
     if (nt < 2) return false;
@@ -111,11 +124,38 @@ inline bool build_plan(size_t nt, PlanHost &P)
         for (size_t m = 0; m < N; ++m)
             P.bfft[m] = c32{(float)(b[m].real() / (double)N), (float)(b[m].imag() / (double)N)};
     }
+    P.family = kFamilyG;
+    P.f_t1.clear(); P.f_t2.clear(); P.f_w2n.clear();
+    int r1, r2, r3;
+    if (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3)) {
+        P.family = kFamilyF;
+        P.variant = "f-regs-3pass-lds-xor";
+        const size_t Nc = nt / 2, m1 = (size_t)r2 * r3;
+        P.f_t1.resize((size_t)r1 * m1);
+        for (int k1 = 0; k1 < r1; ++k1)
+            for (size_t m = 0; m < m1; ++m) {
+                const double a = -2.0 * pi * (double)((m * (size_t)k1) % Nc) / (double)Nc;
+                P.f_t1[(size_t)k1 * m1 + m] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+        P.f_t2.resize((size_t)r2 * 8);
+        for (int k2 = 0; k2 < r2; ++k2)
+            for (int j3 = 0; j3 < 8; ++j3) {
+                const double a = -2.0 * pi * (double)((j3 * k2) % (r2 * 8)) / (double)(r2 * 8);
+                P.f_t2[(size_t)k2 * 8 + j3] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+        P.f_w2n.resize(Nc);
+        for (size_t k = 0; k < Nc; ++k) {
+            const double a = -pi * (double)k / (double)Nc;
+            P.f_w2n[k] = c32{(float)std::cos(a), (float)std::sin(a)};
+        }
+    }
     return true;
 }
 
 inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
-                        const c32 *chirp_conj, const c32 *bfft)
+                        const c32 *chirp_conj, const c32 *bfft, const c32 *f_t1 = nullptr,
+                        const c32 *f_t2 = nullptr, const c32 *f_w2n = nullptr,
+                        const float *ones = nullptr)
 {
     PlanDev D;
     D.nt = H.nt;
@@ -129,6 +169,11 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     D.tw_split = tw_split;
     D.chirp_conj = chirp_conj;
     D.bfft = bfft;
+    D.family = (f_t1 && f_t2 && f_w2n && ones) ? H.family : kFamilyG;
+    D.ones = ones;
+    D.f_t1 = f_t1;
+    D.f_t2 = f_t2;
+    D.f_w2n = f_w2n;
     return D;
 }
 

@@ -41,6 +41,33 @@ __device__ __forceinline__ float wave_shfl_xor(float v, int m) { return __shfl_x
 
 #define THZ_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]
 
+// Stops the machine scheduler from moving instructions across this point: the
+// fully unrolled passes otherwise get all their LDS/global loads hoisted to the
+// top, which blows the VGPR budget of 256 (2 waves per SIMD) and spills.
+#define THZ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Hides a (wave-uniform) pointer's value from the optimiser for one loop
+// iteration, so that loads of trace-invariant tables (windows) stay inside the
+// trace loop instead of being hoisted into dozens of permanently live VGPRs.
+template <class T>
+__device__ __forceinline__ const T *launder_uniform(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Same for a per-lane integer: makes a lane-dependent base index opaque, so that
+// (a) every access becomes base + immediate offset and (b) the optimiser cannot
+// pre-compute (and keep live, or spill) one address VGPR per unrolled access.
+__device__ __forceinline__ int launder_v(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// value known to be the same in every lane of the wave -> keep it in an SGPR
+#define THZ_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+
 #define THZ_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (stream), __VA_ARGS__)
 
