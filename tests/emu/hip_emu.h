@@ -124,6 +124,23 @@ inline float wave_shfl_up(float v, int d)
     return r;
 }
 inline float wave_shfl_xor(float v, int m) { return wave_shfl(v, lane_id() ^ m); }
+inline float wave_shr1(float v)
+{
+    float r = wave_shfl(v, lane_id() > 0 ? lane_id() - 1 : 0);
+    return lane_id() > 0 ? r : 0.0f;
+}
+template <int LANE>
+inline float wave_bcast(float v) { return wave_shfl(v, LANE); }
+inline float wave_scan_add(float v)
+{
+    const int l = lane_id();
+    for (int d = 1; d < 64; d <<= 1) {
+        float t = wave_shfl_up(v, d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+inline float wave_reduce_add(float v) { return wave_bcast<63>(wave_scan_add(v)); }
 
 }  // namespace thz
 

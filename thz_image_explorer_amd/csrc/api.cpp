@@ -476,26 +476,18 @@ int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float 
     if (!d_arr || !d_out || npix == 0 || len == 0 || (ncomp != 1 && ncomp != 2))
         return fail(ctx, THZ_ERR_INVALID, "thz_pixel_sum: bad argument");
     const size_t L = len * (size_t)ncomp;
-    // two-level: 256 partial rows, then one
-    const size_t rows = npix < 256 ? 1 : 256;
     StageTimer t(ctx, THZ_STAGE_MEAN);
-    if (rows == 1) {
+    if (npix < 64) {
         launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
         return check_launch(ctx);
     }
-    if (int rc = ensure_ws(ctx, (rows + 1) * L * sizeof(float))) return rc;
+    // two-level: row groups x column tiles with 4 rows of loads in flight per
+    // thread, then one small pass over the partial rows
+    const size_t max_groups = 1024;
+    if (int rc = ensure_ws(ctx, max_groups * L * sizeof(float))) return rc;
     float *part = reinterpret_cast<float *>(ctx->ws);
-    const size_t per = npix / rows;  // first rows*per pixels, strided view: row r = pixels r, r+rows, ...
-    // view arr as (per, rows*L): summing axis 0 gives rows*L partials over pixels r + rows*a
-    launch_sum_axis0(ctx->stream, d_arr, per, rows * L, 0.0f, part);
-    const size_t rem = npix - per * rows;
-    if (rem) {
-        // tail pixels: add into one extra partial row
-        launch_sum_axis0(ctx->stream, d_arr + per * rows * L, rem, L, 0.0f, part + rows * L);
-        launch_sum_axis0(ctx->stream, part, rows + 1, L, 0.0f, d_out);
-    } else {
-        launch_sum_axis0(ctx->stream, part, rows, L, 0.0f, d_out);
-    }
+    const size_t groups = launch_colsum_partial(ctx->stream, d_arr, npix, L, part, max_groups);
+    launch_sum_axis0(ctx->stream, part, groups, L, 0.0f, d_out);
     return check_launch(ctx);
 }
 

@@ -112,6 +112,10 @@ __device__ __forceinline__ void dftR(c32 (&v)[R])
     else dft16(v);
 }
 
+// 16-byte LDS accesses (ds_read_b128 / ds_write_b128): index must be even
+__device__ __forceinline__ c32x2 ld2(const c32 *p) { return *reinterpret_cast<const c32x2 *>(p); }
+__device__ __forceinline__ void st2(c32 *p, c32 a, c32 b) { *reinterpret_cast<c32x2 *>(p) = c32x2{a, b}; }
+
 // ------------------------------------------------------------------- the plan
 template <int R1_, int R2_, int R3_>
 struct FPlan {
@@ -218,11 +222,18 @@ __device__ __forceinline__ void f_core_pass1(c32 (&r)[P::C1][P::R1], c32 *buf, c
     const c32 *t1l = t1 + launder_v(C1 * lane);
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
-#pragma unroll
-        for (int c = 0; c < C1; ++c) {
-            c32 v = r[c][k1];
-            if (k1 > 0) v = cmul(v, t1l[k1 * M1 + c]);
-            buf[ad.w1[k1 & 3] + (k1 * M1 + c)] = v;  // = e1(k1, C1*lane + c)
+        if constexpr (C1 == 2) {
+            c32 v0 = r[0][k1], v1 = r[1][k1];
+            if (k1 > 0) {
+                const c32x2 w = ld2(t1l + k1 * M1);
+                v0 = cmul(v0, w.a);
+                v1 = cmul(v1, w.b);
+            }
+            st2(buf + ad.w1[k1 & 3] + k1 * M1, v0, v1);  // = e1(k1, 2*lane + {0,1})
+        } else {
+            c32 v = r[0][k1];
+            if (k1 > 0) v = cmul(v, t1l[k1 * M1]);
+            buf[ad.w1[k1 & 3] + k1 * M1] = v;  // = e1(k1, lane)
         }
         if ((k1 & 3) == 3) THZ_SCHED_FENCE();
     }
@@ -266,7 +277,11 @@ __device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAd
 #pragma unroll
     for (int c3 = 0; c3 < C3; ++c3) {
 #pragma unroll
-        for (int j = 0; j < R3; ++j) d[c3][j] = buf[ad.r3[j >> 1] + ((j & 1) + 512 * c3)];  // = e2(row, j)
+        for (int u = 0; u < R3 / 2; ++u) {
+            const c32x2 v = ld2(buf + ad.r3[u] + 512 * c3);  // = e2(row, 2u), e2(row, 2u + 1)
+            d[c3][2 * u] = v.a;
+            d[c3][2 * u + 1] = v.b;
+        }
         THZ_SCHED_FENCE();
     }
     wave_sync();
@@ -375,6 +390,24 @@ __device__ __forceinline__ void f_load_raw(const float *__restrict__ x, int lane
     }
 }
 
+// Same register layout for a spectrum row (inverse kernel): raw[j][..] = X[C1*(64 j + lane) + c]
+// as {re, im} pairs.  Rows are only 8-byte aligned (nf is odd).
+template <class P>
+__device__ __forceinline__ void f_load_spec(const c32 *__restrict__ X, int lane,
+                                            float (&raw)[P::R1][2 * P::C1])
+{
+#pragma unroll
+    for (int j = 0; j < P::R1; ++j) {
+        const float *src = reinterpret_cast<const float *>(X + P::C1 * (kWave * j + lane));
+        if constexpr (P::C1 == 2) {
+            load_f4(src, raw[j][0], raw[j][1], raw[j][2], raw[j][3]);
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(src);
+            raw[j][0] = v.x; raw[j][1] = v.y;
+        }
+    }
+}
+
 template <class P>
 __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane, int j1,
                                            float (&out)[2 * P::C1])
@@ -444,8 +477,8 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
             float ph[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) ph[c] = atan2f(X[c].im, X[c].re);
-            if (g == 0) first = wave_shfl(ph[0], 0);
-            float prev = wave_shfl_up(ph[3], 1);
+            if (g == 0) first = wave_bcast<0>(ph[0]);
+            float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;
             float s[4];
             float run = 0.0f;
@@ -459,17 +492,16 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
                 s[c] = run;
             }
             const float incl = wave_scan_add(run);
-            float excl = wave_shfl_up(incl, 1);
-            if (lane == 0) excl = 0.0f;
+            const float excl = wave_shr1(incl);
             const float base = carry + excl;
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = first + (base + s[c]);
             store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
-            carry += wave_shfl(incl, kWave - 1);
-            prev_tail = wave_shfl(ph[3], kWave - 1);
+            carry += wave_bcast<kWave - 1>(incl);
+            prev_tail = wave_bcast<kWave - 1>(ph[3]);
             if (g == NG - 1) {
-                last_unwrapped = wave_shfl(y[3], kWave - 1);
+                last_unwrapped = wave_bcast<kWave - 1>(y[3]);
                 last_raw = prev_tail;
             }
         }
@@ -580,11 +612,14 @@ __device__ __forceinline__ void f_time_epilogue(const c32 *buf, size_t p, const 
 #pragma unroll
     for (int j = 0; j < R1; ++j) {
         float v[2 * C1];
-#pragma unroll
-        for (int c = 0; c < C1; ++c) {
-            const c32 rr = buf[ob + (C1 * kWave * j + c)];
-            v[2 * c] = rr.im / fnt;
-            v[2 * c + 1] = rr.re / fnt;
+        if constexpr (C1 == 2) {
+            const c32x2 rr = ld2(buf + ob + 2 * kWave * j);
+            v[0] = rr.a.im / fnt; v[1] = rr.a.re / fnt;
+            v[2] = rr.b.im / fnt; v[3] = rr.b.re / fnt;
+        } else {
+            const c32 rr = buf[ob + kWave * j];
+            v[0] = rr.im / fnt;
+            v[1] = rr.re / fnt;
         }
         if (f_block_on<P, WIN_FULL>(post_blocks, j)) {
             float w[2 * C1];
@@ -650,7 +685,15 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     const size_t stride = (size_t)gridDim.x * wpb;
     size_t p = (size_t)blockIdx.x * wpb + wib;
     float raw[R1][2 * C1];
-    if (MODE != kInv && p < A.npix) f_load_raw<P>(A.in + p * NT, lane, raw);
+    float x_nyq_next = 0.0f;
+    if (p < A.npix) {
+        if constexpr (MODE != kInv) {
+            f_load_raw<P>(A.in + p * NT, lane, raw);
+        } else {
+            f_load_spec<P>(A.fft_in + p * nf, lane, raw);
+            x_nyq_next = A.fft_in[p * nf + N].re;
+        }
+    }
 
     for (; p < A.npix; p += stride) {
         c32 r[C1][R1];
@@ -704,14 +747,26 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 wave_sync();
             }
         } else {
-            // spectrum -> LDS in natural order (X[N] is real and travels in a register)
-            const c32 *Xg = A.fft_in + p * nf;
-            for (int k = lane; k < N; k += kWave) buf[k] = Xg[k];
-            const float x_n = Xg[N].re;
+            // prefetched spectrum -> LDS in natural order (X[N] is real and travels in a register)
+            const float x_n = x_nyq_next;
+            {
+                const int sb = launder_v(C1 * lane);
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    if constexpr (C1 == 2)
+                        st2(buf + sb + 2 * kWave * j, c32{raw[j][0], raw[j][1]}, c32{raw[j][2], raw[j][3]});
+                    else
+                        buf[sb + kWave * j] = c32{raw[j][0], raw[j][1]};
+                }
+            }
             wave_sync();
             f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, x_n, lane, r);
             wave_sync();
             f_core_pass1<P>(r, buf, t1, ad, lane);
+            if (p + stride < A.npix) {
+                f_load_spec<P>(A.fft_in + (p + stride) * nf, lane, raw);
+                x_nyq_next = A.fft_in[(p + stride) * nf + N].re;
+            }
             f_core_pass23<P>(buf, t2, ad, lane);
             if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);
             else f_time_epilogue<P, true>(buf, p, A, post_blocks, lane);

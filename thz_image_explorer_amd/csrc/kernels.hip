@@ -20,6 +20,8 @@
 #include "kernels.hpp"
 #include "fft_f.hpp"
 
+#include <cstdlib>
+
 namespace thz {
 
 // ---------------------------------------------------------------------------
@@ -149,8 +151,7 @@ __device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int n
         scratch[i] = s;
     }
     const float incl = wave_scan_add(s);
-    float excl = wave_shfl_up(incl, 1);
-    if (lane == 0) excl = 0.0f;
+    const float excl = wave_shr1(incl);
     for (int i = start; i < end; ++i) scratch[i] = first + (excl + scratch[i]);
     wave_sync();
     for (int k = lane; k < nf; k += kWave) ph_out[p * nf + k] = scratch[k];
@@ -500,6 +501,50 @@ __global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr
     }
 }
 
+// Column sums with memory-level parallelism (pixel-mean partials of big cubes):
+// block = (column tile of 1024 floats) x (row group); every thread keeps 4 rows of
+// 16-byte loads in flight.  Rows are only 4-byte aligned (L = 2*nf or nf).
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ arr,
+                                                        size_t nrows, size_t L, size_t ntiles,
+                                                        size_t rows_per_group,
+                                                        float *__restrict__ partial)
+{
+    const size_t tile = blockIdx.x % ntiles, rg = blockIdx.x / ntiles;
+    const size_t col0 = tile * 1024 + (size_t)threadIdx.x * 4;
+    const size_t r0 = rg * rows_per_group;
+    size_t r1 = r0 + rows_per_group;
+    if (r1 > nrows) r1 = nrows;
+    float acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[u][i] = 0.0f;
+    if (col0 + 3 < L) {
+        size_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float a, b, c, d;
+                load_f4(arr + (r + u) * L + col0, a, b, c, d);
+                acc[u][0] += a; acc[u][1] += b; acc[u][2] += c; acc[u][3] += d;
+            }
+        }
+        for (; r < r1; ++r) {
+            float a, b, c, d;
+            load_f4(arr + r * L + col0, a, b, c, d);
+            acc[0][0] += a; acc[0][1] += b; acc[0][2] += c; acc[0][3] += d;
+        }
+    } else {
+        for (size_t r = r0; r < r1; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (col0 + i < L) acc[0][i] += arr[r * L + col0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (col0 + i < L) partial[rg * L + col0 + i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+}
+
 // ROI mask, bit-exact u64 restatement of math_tools.rs:574-591, 604-652
 __global__ __launch_bounds__(256) void k_roi_mask(const uint64_t *__restrict__ poly, int n,
                                                   uint64_t x_min, uint64_t x_max, uint64_t y_min,
@@ -685,7 +730,11 @@ void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, cons
 template <class PL, int MODE, int CFG>
 static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
 {
-    constexpr unsigned kBlock = 512, kWpb = kBlock / kWave;
+    unsigned kBlock = 512;
+#ifndef THZ_EMU
+    if (const char *e = getenv("THZ_F_BLOCK")) kBlock = (unsigned)atoi(e);  // developer knob
+#endif
+    const unsigned kWpb = kBlock / kWave;
     const size_t lds = PL::lds_bytes(kWpb);
     size_t per_cu = kLdsBytesPerCU / lds;
     if (per_cu < 1) per_cu = 1;
@@ -811,6 +860,22 @@ void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner,
                       float *out)
 {
     THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out);
+}
+
+// returns the number of partial rows written to `partial` (each L floats)
+size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,
+                             float *partial, size_t max_groups)
+{
+    const size_t ntiles = (L + 1023) / 1024;
+    size_t groups = ((size_t)kNumCU * 8 + ntiles - 1) / ntiles;
+    if (groups > max_groups) groups = max_groups;
+    if (groups > nrows) groups = nrows;
+    if (groups < 1) groups = 1;
+    const size_t rows_per_group = (nrows + groups - 1) / groups;
+    groups = (nrows + rows_per_group - 1) / rows_per_group;
+    THZ_LAUNCH(k_colsum_partial, (unsigned)(ntiles * groups), 256, 0, st, arr, nrows, L, ntiles,
+               rows_per_group, partial);
+    return groups;
 }
 
 void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_min, uint64_t x_max,

@@ -39,6 +39,37 @@ __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, 
 __device__ __forceinline__ float wave_shfl_up(float v, int d) { return __shfl_up(v, d, kWave); }
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, kWave); }
 
+// ---- cross-lane moves on the DPP path (no LDS crossbar traffic, unlike __shfl)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v)
+{
+    // lanes whose source is out of range, or whose row is masked off, read 0
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+// value of lane-1 (0 in lane 0)
+__device__ __forceinline__ float wave_shr1(float v) { return dpp_or_zero<0x138, 0xf>(v); }
+// value of a fixed lane, in every lane (wave-uniform result)
+template <int LANE>
+__device__ __forceinline__ float wave_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), LANE));
+}
+// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each row of 16,
+// then row_bcast:15 / row_bcast:31 (the GFX9 wave64 scan)
+__device__ __forceinline__ float wave_scan_add(float v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// sum over the 64 lanes, result in every lane
+__device__ __forceinline__ float wave_reduce_add(float v) { return wave_bcast<kWave - 1>(wave_scan_add(v)); }
+
 #define THZ_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]
 
 // Stops the machine scheduler from moving instructions across this point: the
@@ -73,28 +104,12 @@ __device__ __forceinline__ int launder_v(int x)
 
 #endif  // !THZ_EMU
 
-// sum over the 64 lanes, result in every lane
-__device__ __forceinline__ float wave_reduce_add(float v)
-{
-#pragma unroll
-    for (int m = kWave / 2; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
-    return v;
-}
-
-// inclusive prefix sum over lanes
-__device__ __forceinline__ float wave_scan_add(float v)
-{
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        float t = wave_shfl_up(v, d);
-        if (l >= d) v += t;
-    }
-    return v;
-}
-
-struct c32 {
+struct alignas(8) c32 {
     float re, im;
+};
+// two adjacent complex values: the unit of every 16-byte LDS access
+struct alignas(16) c32x2 {
+    c32 a, b;
 };
 
 __device__ __forceinline__ c32 cmul(c32 a, c32 b)
