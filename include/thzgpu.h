@@ -141,6 +141,17 @@ int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double h
                          double window_width, float *out /* nf */, int64_t *lower,
                          int64_t *upper);
 
+/* TiltCompensation::filter geometry, tilt_compensation.rs:104-175 (K11): the
+ * time extension (floor((|cx*tx| + |cy*ty|)/c/0.05)*0.05 with the reference's
+ * hard-coded dt = 0.05 ps), the extended time axis (front/back linspaces) and,
+ * per pixel, the index at which the tapered trace is inserted.  Returns
+ * num_steps; the new length is nt + 2*num_steps.  new_time / insert_index may
+ * be NULL (sizing call). */
+size_t thz_host_tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
+                          double tilt_y_deg, float dx, float dy,
+                          float *new_time /* nt + 2*num_steps */,
+                          int32_t *insert_index /* nx*ny */);
+
 /* ------------------------------------------------------------------ */
 /* stage kernels (device pointers)                                     */
 /* ------------------------------------------------------------------ */
@@ -228,6 +239,14 @@ int thz_roi_mean(thz_ctx *ctx, const float *d_arr, size_t shape0, size_t shape1,
 /* math_tools::scaling scale_3d helper, math_tools.rs:273-301 (K10). */
 int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t len, int ncomp,
                 size_t s, float *d_out);
+
+/* TiltCompensation::filter per-pixel copy, tilt_compensation.rs:171-201 (K11):
+ * out[p, :ins] = in[p, 0]; out[p, ins:ins+nt_in] = in[p, :] * taper (clipped at
+ * nt_out); zeros behind.  d_taper = thz_host_adapted_blackman(time, 0, 7).
+ * The caller then re-plans with thz_set_time_axis(new_time) exactly as the
+ * reference re-plans after a length change (data_thread.rs:1194-1227). */
+int thz_tilt_apply(thz_ctx *ctx, size_t npix, const float *d_in, size_t nt_in, const float *d_taper,
+                   const int32_t *d_insert_index, size_t nt_out, float *d_out);
 
 /* Synthetic input generator for benchmarks and tests (not a reference
  * function): derivative-of-Gaussian pulse + echo + 1 % noise

@@ -556,6 +556,65 @@ void thz_oracle_scale3d(const float *arr, int nx, int ny, int len, int ncomp, in
 }
 
 /* ---------------------------------------------------------------------------
+ * Tilt compensation — src/filters/tilt_compensation.rs:97-226 (K11).
+ * Returns num_steps; when out != NULL fills new_time (nt + 2*num_steps) and
+ * the extended cube out (nx, ny, nt + 2*num_steps).  dt is the reference's
+ * hard-coded 0.05 (a'-7); ndarray::linspace = start + step*i.
+ * ------------------------------------------------------------------------- */
+static void oracle_linspace(float a, float b, int n, float *out)
+{
+    float step = n > 1 ? (b - a) / (float)(n - 1) : 0.0f;
+    for (int i = 0; i < n; ++i) out[i] = a + step * (float)i;
+}
+
+int thz_oracle_tilt(const float *data, const float *time, int nx, int ny, int nt, double tilt_x_deg,
+                    double tilt_y_deg, float dx, float dy, float *new_time, float *out)
+{
+    const float time_shift_x = (float)tilt_x_deg / 180.0f * PI_F; /* :105 */
+    const float time_shift_y = (float)tilt_y_deg / 180.0f * PI_F;
+    const int width = nx, height = ny;
+    const float center_x = (float)width / 2.0f * dx;              /* :115 */
+    const float center_y = (float)height / 2.0f * dy;
+    const double c = 0.299792458;
+    const float dt = 0.05f;
+    const float max_offset_x = (float)((double)center_x * (double)fabsf(time_shift_x) / c);
+    const float max_offset_y = (float)((double)center_y * (double)fabsf(time_shift_y) / c);
+    float extension = (max_offset_x + max_offset_y) / dt;
+    extension = floorf(extension) * dt;
+    const int num_steps = (int)roundf(extension / dt);
+    const int ext = nt + 2 * num_steps;
+    if (!new_time || !out) return num_steps;
+    const float first = time[0], last = time[nt - 1];
+    oracle_linspace(first - extension, first - dt, num_steps, new_time);
+    memcpy(new_time + num_steps, time, sizeof(float) * (size_t)nt);
+    oracle_linspace(last + dt, last + extension, num_steps, new_time + num_steps + nt);
+    float *win = (float *)malloc(sizeof(float) * (size_t)nt);
+    for (int i = 0; i < width; ++i)
+        for (int j = 0; j < height; ++j) {
+            const float x_offset =
+                (float)((double)(((float)i - (float)width / 2.0f) * dx) * (double)time_shift_x / c);
+            const float y_offset =
+                (float)((double)(((float)j - (float)height / 2.0f) * dy) * (double)time_shift_y / c);
+            const float delta = x_offset + y_offset;
+            const long delta_steps = (long)floorf(delta / dt);
+            long ins = (long)num_steps + delta_steps;
+            if (ins < 0) ins = 0;
+            const float *raw = data + ((size_t)i * height + j) * nt;
+            float *e = out + ((size_t)i * height + j) * ext;
+            long end = ins + nt;
+            if (end > ext) end = ext;
+            if (ins > ext) ins = ext; /* Rust would panic on the slice; not reachable for |tilt| <= 15 deg */
+            for (long k = 0; k < ins; ++k) e[k] = raw[0];
+            memcpy(win, raw, sizeof(float) * (size_t)nt);
+            thz_oracle_apply_adapted_blackman(win, time, nt, 0.0f, 7.0f);
+            for (long k = ins; k < end; ++k) e[k] = win[k - ins];
+            for (long k = end; k < ext; ++k) e[k] = 0.0f;
+        }
+    free(win);
+    return num_steps;
+}
+
+/* ---------------------------------------------------------------------------
  * CPU baseline: the default chain, stage-fused per trace without per-stage
  * container copies (SURVEY §8d variant (i)), OpenMP over Axis(0) like the
  * reference's rayon split.  Composite of the functions above.

@@ -216,6 +216,21 @@ def scale3d(arr, s, ncomp=1):
     return out
 
 
+def tilt(data, time, tilt_x_deg, tilt_y_deg, dx, dy):
+    """TiltCompensation::filter -> (num_steps, new_time, extended cube)"""
+    d = f32(data)
+    nx, ny, nt = d.shape
+    t = f32(time)
+    L = lib()
+    L.thz_oracle_tilt.restype = C.c_int
+    args = [_p(d), _p(t), nx, ny, nt, C.c_double(tilt_x_deg), C.c_double(tilt_y_deg), C.c_float(dx), C.c_float(dy)]
+    steps = L.thz_oracle_tilt(*args, None, None)
+    new_time = np.empty(nt + 2 * steps, np.float32)
+    out = np.empty((nx, ny, nt + 2 * steps), np.float32)
+    L.thz_oracle_tilt(*args, _p(new_time), _p(out))
+    return steps, new_time, out
+
+
 def max_threads():
     return int(lib().thz_oracle_max_threads())
 

@@ -378,3 +378,54 @@ def test_stage_timing_reports_device_time(engine):
     assert engine.stage_time_ns(pkg.binding.STAGE_FFT) > 0
     engine.enable_timing(False)
     d.free(); f.free()
+
+
+# ---- tilt compensation (K11): changes Nt, re-plans ---------------------------
+@pytest.mark.parametrize("tilt", [(10.0, 0.0), (0.0, 0.0), (-6.0, 4.0)])
+def test_tilt_compensation_then_replan(engine, tilt):
+    """tilt_compensation.rs:97-226: extended axis, per-pixel integer shift (bit-exact),
+    then the chain continues on the new (non power-of-two) length like
+    data_thread.rs:1194-1227"""
+    nx, ny, nt = 6, 5, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    dx = dy = 0.5
+    steps, new_time, ins = pkg.host_tilt_plan(time, nx, ny, tilt[0], tilt[1], dx, dy)
+    osteps, otime, oext = ob.tilt(cube, time, tilt[0], tilt[1], dx, dy)
+    assert steps == osteps and np.array_equal(new_time, otime)
+    nt2 = nt + 2 * steps
+    taper = pkg.host_adapted_blackman(time, 0.0, 7.0)
+    e = engine
+    d_in = e.to_device(cube); d_tp = e.to_device(taper); d_ins = e.to_device(ins); d_out = e.empty((nx * ny, nt2))
+    e.tilt_apply(nx * ny, d_in, nt, d_tp, d_ins, nt2, d_out)
+    ext = d_out.download((nx, ny, nt2), np.float32)
+    assert np.array_equal(ext, oext)
+    # re-plan on the extended axis and run the fft stage there
+    e.set_time_axis(new_time)
+    assert e.nt == nt2
+    assert np.array_equal(e.frequency(), ob.frequency_axis(new_time))
+    w = pkg.host_fft_window(new_time, 0, 1.0, 7.0)
+    got = gpu_fft_stage(e, ext, w, want_data=False)
+    ref = ob.fft_stage(oext, new_time, 0, 1.0, 7.0)
+    assert rel(got["fft"], ref["fft"], np.abs(ref["fft"]).max()) < TOL
+    for b in (d_in, d_tp, d_ins, d_out):
+        b.free()
+
+
+def test_reference_tilt_unit_tests(engine):
+    """tilt_compensation.rs:303-389 through the C ABI"""
+    n, impulse_idx = 64, 10
+    data = np.zeros((2, 2, n), np.float32)
+    data[1, 1, impulse_idx] = 1.0
+    time = np.linspace(0.0, np.float32(0.05) * (n - 1), n, dtype=np.float32)
+    for tilt_x, expect_ext in ((10.0, True), (0.0, False)):
+        steps, new_time, ins = pkg.host_tilt_plan(time, 2, 2, tilt_x, 0.0, 1.0, 1.0)
+        assert (steps > 0) == expect_ext
+        assert new_time.size == n + 2 * steps
+        taper = pkg.host_adapted_blackman(time, 0.0, 7.0)
+        d_in = engine.to_device(data); d_tp = engine.to_device(taper); d_ins = engine.to_device(ins)
+        d_out = engine.empty((4, n + 2 * steps))
+        engine.tilt_apply(4, d_in, n, d_tp, d_ins, n + 2 * steps, d_out)
+        out = d_out.download((2, 2, n + 2 * steps), np.float32)
+        assert int(np.argmax(out[1, 1])) == impulse_idx + steps
+        for b in (d_in, d_tp, d_ins, d_out):
+            b.free()

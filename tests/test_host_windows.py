@@ -66,3 +66,19 @@ def test_default_td_bandpass_zeroes_last_sample():
     time = (1000 + 0.05 * np.arange(4096)).astype(np.float32)
     w, lo, hi, l, u = pkg.host_td_bandpass(time, float(time[0]), float(time[-1]), 2.0)
     assert (l, u) == (0, 4095) and w[-1] == 0.0
+
+
+@pytest.mark.parametrize("tilt", [(10.0, 0.0), (0.0, 0.0), (-7.5, 3.25), (15.0, -15.0)])
+def test_tilt_plan_matches_oracle(tilt):
+    """product host geometry (thz_host_tilt_plan) vs the oracle's restatement of
+    tilt_compensation.rs:104-175"""
+    nx, ny, nt = 9, 6, 200
+    time = (1000 + 0.05 * np.arange(nt)).astype(np.float32)
+    data = np.zeros((nx, ny, nt), np.float32)
+    data[:, :, 50] = 1.0
+    steps, new_time, ins = pkg.host_tilt_plan(time, nx, ny, tilt[0], tilt[1], 0.5, 0.25)
+    osteps, otime, out = ob.tilt(data, time, tilt[0], tilt[1], 0.5, 0.25)
+    assert steps == osteps
+    assert np.array_equal(new_time, otime)
+    peak = np.argmax(out.reshape(nx * ny, -1), axis=1)
+    assert np.array_equal(ins, peak - 50)

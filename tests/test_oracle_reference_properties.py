@@ -127,3 +127,39 @@ def test_intensity_and_bias():
     assert np.all(b[..., 0] == 0.0)
     img = ob.intensity(b)
     assert np.allclose(img, (b.astype(np.float64) ** 2).sum(-1), rtol=1e-5)
+
+
+def _expected_tilt_steps(width, height, dx, dy, tx_deg, ty_deg):
+    """compute_expected_num_steps of the reference's test module (tilt_compensation.rs:283-300)"""
+    f = np.float32
+    tsx = f(f(tx_deg) / f(180.0) * f(np.pi)); tsy = f(f(ty_deg) / f(180.0) * f(np.pi))
+    cx = f(f(width) / f(2.0) * f(dx)); cy = f(f(height) / f(2.0) * f(dy))
+    c = 0.299792458
+    mx = f(float(cx) * float(abs(tsx)) / c); my = f(float(cy) * float(abs(tsy)) / c)
+    ext = f(np.floor(f(f(mx + my) / f(0.05)))) * f(0.05)
+    return int(np.round(f(ext / f(0.05))))
+
+
+def test_tilt_extends_time_and_shifts_center_trace():
+    """tilt_compensation.rs:303-346 (known-answer, integer indices)"""
+    n, dt, impulse_idx = 64, np.float32(0.05), 10
+    data = np.zeros((2, 2, n), np.float32)
+    data[1, 1, impulse_idx] = 1.0
+    time = np.linspace(0.0, dt * (n - 1), n, dtype=np.float32)
+    steps, new_time, out = ob.tilt(data, time, 10.0, 0.0, 1.0, 1.0)
+    exp = _expected_tilt_steps(2, 2, 1.0, 1.0, 10.0, 0.0)
+    assert steps == exp and exp > 0
+    assert new_time.size == n + 2 * exp and out.shape[-1] == n + 2 * exp
+    assert int(np.argmax(out[1, 1])) == impulse_idx + exp  # centre pixel: zero geometric shift
+    assert np.all(np.diff(new_time) > 0)
+
+
+def test_tilt_no_tilt_no_extension():
+    """tilt_compensation.rs:349-389"""
+    n, dt, impulse_idx = 64, np.float32(0.05), 12
+    data = np.zeros((2, 2, n), np.float32)
+    data[1, 1, impulse_idx] = 1.0
+    time = np.linspace(0.0, dt * (n - 1), n, dtype=np.float32)
+    steps, new_time, out = ob.tilt(data, time, 0.0, 0.0, 1.0, 1.0)
+    assert steps == 0 and new_time.size == n
+    assert int(np.argmax(out[1, 1])) == impulse_idx

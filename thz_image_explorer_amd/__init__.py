@@ -5,5 +5,5 @@ This package only carries the ctypes binding used by tests and bench.py.
 """
 from .binding import (Engine, DevBuf, ThzError, load_library, LIB_PATH, SYMBOLS,  # noqa: F401
                       host_frequency_axis, host_fft_window, host_adapted_blackman,
-                      host_td_bandpass, host_fd_bandpass)
+                      host_td_bandpass, host_fd_bandpass, host_tilt_plan)
 from . import binding  # noqa: F401

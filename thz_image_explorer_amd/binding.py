@@ -62,6 +62,8 @@ SYMBOLS = [
                                        C.c_double, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("thz_host_fd_bandpass", C.c_int, [_P, _SZ, C.c_double, C.c_double, C.c_double, _P,
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("thz_host_tilt_plan", _SZ, [_P, _SZ, _SZ, _SZ, C.c_double, C.c_double, C.c_float, C.c_float, _P, _P]),
+    ("thz_tilt_apply", C.c_int, [_P, _SZ, _P, _SZ, _P, _P, _SZ, _P]),
     ("thz_fft", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("thz_apply_fd_mask", C.c_int, [_P, _SZ, _P, _P, _P]),
     ("thz_apply_fd_cmask", C.c_int, [_P, _SZ, _P, _P, _P]),
@@ -151,6 +153,18 @@ def host_fd_bandpass(frequency, low: float, high: float, width: float):
     _rc(load_library().thz_host_fd_bandpass(f.ctypes.data, f.size, low, high, width, out.ctypes.data,
                                             C.byref(l), C.byref(u)), "fd_bandpass")
     return out, l.value, u.value
+
+
+def host_tilt_plan(time, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy):
+    """-> (num_steps, new_time, insert_index (nx*ny int32))"""
+    t = np.ascontiguousarray(time, np.float32)
+    L = load_library()
+    steps = int(L.thz_host_tilt_plan(t.ctypes.data, t.size, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy, None, None))
+    new_time = np.empty(t.size + 2 * steps, np.float32)
+    ins = np.empty(nx * ny, np.int32)
+    L.thz_host_tilt_plan(t.ctypes.data, t.size, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy,
+                         new_time.ctypes.data, ins.ctypes.data)
+    return steps, new_time, ins
 
 
 class DevBuf:
@@ -308,6 +322,10 @@ class Engine:
 
     def scale3d(self, arr, nx, ny, length, ncomp, s, out):
         self._check(self.lib.thz_scale3d(self.ctx, _dp(arr), nx, ny, length, ncomp, s, _dp(out)))
+
+    def tilt_apply(self, npix, d_in, nt_in, d_taper, d_insert, nt_out, d_out):
+        self._check(self.lib.thz_tilt_apply(self.ctx, npix, _dp(d_in), nt_in, _dp(d_taper), _dp(d_insert),
+                                            nt_out, _dp(d_out)))
 
     def synth_cube(self, d_out, ntraces, first_trace, d_time, seed=0x7A3D2026, subtract_bias=True):
         self._check(self.lib.thz_synth_cube(self.ctx, _dp(d_out), ntraces, first_trace, _dp(d_time),

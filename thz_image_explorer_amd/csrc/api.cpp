@@ -349,6 +349,14 @@ int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double h
     return THZ_OK;
 }
 
+size_t thz_host_tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
+                          double tilt_y_deg, float dx, float dy, float *new_time,
+                          int32_t *insert_index)
+{
+    if (!time || nt == 0) return 0;
+    return tilt_plan(time, nt, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy, new_time, insert_index);
+}
+
 /* ------------------------------------------------------------ stages */
 
 int thz_fft(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win_a,
@@ -569,6 +577,19 @@ int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t l
         (ncomp != 1 && ncomp != 2))
         return fail(ctx, THZ_ERR_INVALID, "thz_scale3d: bad argument");
     launch_scale3d(ctx->stream, d_arr, nx, ny, len * (size_t)ncomp, s, d_out);
+    return check_launch(ctx);
+}
+
+int thz_tilt_apply(thz_ctx *ctx, size_t npix, const float *d_in, size_t nt_in, const float *d_taper,
+                   const int32_t *d_insert_index, size_t nt_out, float *d_out)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    if (!d_in || !d_taper || !d_insert_index || !d_out || nt_in == 0 || nt_out < nt_in)
+        return fail(ctx, THZ_ERR_INVALID, "thz_tilt_apply: bad argument");
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_TD_WINDOW);
+    launch_tilt(ctx->stream, npix, (int)nt_in, (int)nt_out, d_in, d_taper, d_insert_index, d_out);
     return check_launch(ctx);
 }
 

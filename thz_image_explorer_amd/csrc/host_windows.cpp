@@ -109,4 +109,51 @@ void fd_bandpass(const float *freq, size_t nf, double low, double high, double w
     if (upper_out) *upper_out = (int64_t)upper;
 }
 
+// ndarray::Array1::linspace: start + step * i
+static void linspace(float a, float b, size_t n, float *out)
+{
+    const float step = n > 1 ? (b - a) / (float)(n - 1) : 0.0f;
+    for (size_t i = 0; i < n; ++i) out[i] = a + step * (float)i;
+}
+
+// TiltCompensation::filter geometry, tilt_compensation.rs:104-175: time extension
+// and the per-pixel index at which the trace is inserted into the extended axis.
+size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
+                 double tilt_y_deg, float dx, float dy, float *new_time, int32_t *insert_index)
+{
+    const float time_shift_x = (float)tilt_x_deg / 180.0f * kPiF;
+    const float time_shift_y = (float)tilt_y_deg / 180.0f * kPiF;
+    const float center_x = (float)nx / 2.0f * dx;
+    const float center_y = (float)ny / 2.0f * dy;
+    const double c = 0.299792458;  // mm/ps
+    const float dt = 0.05f;        // hard-coded in the reference (:122)
+    const float max_offset_x = (float)((double)center_x * (double)std::fabs(time_shift_x) / c);
+    const float max_offset_y = (float)((double)center_y * (double)std::fabs(time_shift_y) / c);
+    float extension = (max_offset_x + max_offset_y) / dt;
+    extension = std::floor(extension) * dt;
+    const size_t num_steps = (size_t)std::round(extension / dt);
+    const size_t ext = nt + 2 * num_steps;
+    if (new_time && nt) {
+        linspace(time[0] - extension, time[0] - dt, num_steps, new_time);
+        for (size_t i = 0; i < nt; ++i) new_time[num_steps + i] = time[i];
+        linspace(time[nt - 1] + dt, time[nt - 1] + extension, num_steps, new_time + num_steps + nt);
+    }
+    if (insert_index) {
+        for (size_t i = 0; i < nx; ++i)
+            for (size_t j = 0; j < ny; ++j) {
+                const float x_offset =
+                    (float)((double)(((float)i - (float)nx / 2.0f) * dx) * (double)time_shift_x / c);
+                const float y_offset =
+                    (float)((double)(((float)j - (float)ny / 2.0f) * dy) * (double)time_shift_y / c);
+                const float delta = x_offset + y_offset;
+                const long delta_steps = (long)std::floor(delta / dt);
+                long ins = (long)num_steps + delta_steps;
+                if (ins < 0) ins = 0;
+                if (ins > (long)ext) ins = (long)ext;
+                insert_index[i * ny + j] = (int32_t)ins;
+            }
+    }
+    return num_steps;
+}
+
 }  // namespace thz

@@ -586,6 +586,29 @@ __global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ ar
     }
 }
 
+// TiltCompensation per-pixel copy, tilt_compensation.rs:171-201: front fill with
+// trace[0], tapered trace at insert_index, zeros behind.
+__global__ __launch_bounds__(256) void k_tilt(size_t npix, int nt_in, int nt_out,
+                                              const float *__restrict__ in,
+                                              const float *__restrict__ taper,
+                                              const int *__restrict__ insert_index,
+                                              float *__restrict__ out)
+{
+    const size_t total = npix * (size_t)nt_out;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = idx / nt_out;
+        const int e = (int)(idx % nt_out);
+        const int ins = insert_index[p];
+        const int end = (ins + nt_in < nt_out) ? ins + nt_in : nt_out;
+        const float *raw = in + p * nt_in;
+        float v = 0.0f;
+        if (e < ins) v = raw[0];
+        else if (e < end) v = raw[e - ins] * taper[e - ins];
+        out[idx] = v;
+    }
+}
+
 // scale_3d, math_tools.rs:273-301
 __global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, size_t nx,
                                                  size_t ny, size_t L, size_t s,
@@ -898,6 +921,13 @@ void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size
 {
     const size_t total = (nx / s) * (ny / s) * L;
     THZ_LAUNCH(k_scale3d, grid_1d(total, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+}
+
+void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float *in,
+                 const float *taper, const int *insert_index, float *out)
+{
+    THZ_LAUNCH(k_tilt, grid_1d(npix * nt_out, 256, kNumCU * 8), 256, 0, st, npix, nt_in, nt_out, in,
+               taper, insert_index, out);
 }
 
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,

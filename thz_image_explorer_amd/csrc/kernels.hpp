@@ -65,6 +65,8 @@ void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint3
 void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,
                     float *out);
 
+void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float *in,
+                 const float *taper, const int *insert_index, float *out);
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,
                   const float *time, uint32_t seed, int subtract_bias);
 
