@@ -43,7 +43,8 @@ typedef enum thz_status {
     THZ_ERR_UNSUPPORTED = -2,  /* transform length not supported */
     THZ_ERR_HIP = -3,          /* HIP runtime failure (no GPU, OOM, fault) */
     THZ_ERR_NOT_READY = -4,    /* geometry / cube not set */
-    THZ_ERR_ABORTED = -5       /* abort flag observed between kernel batches */
+    THZ_ERR_ABORTED = -5,      /* abort flag observed between kernel batches */
+    THZ_SKIPPED = 1            /* not an error: a guard of the reference applied, output = input */
 } thz_status;
 
 /* FftWindowType, math_tools.rs:35-46 (same order) */
@@ -247,6 +248,66 @@ int thz_scale3d(thz_ctx *ctx, const float *d_arr, size_t nx, size_t ny, size_t l
  * reference re-plans after a length change (data_thread.rs:1194-1227). */
 int thz_tilt_apply(thz_ctx *ctx, size_t npix, const float *d_in, size_t nt_in, const float *d_taper,
                    const int32_t *d_insert_index, size_t nt_out, float *d_out);
+
+/* ------------------------------------------------------------------ */
+/* Deconvolution (K12), src/filters/deconvolution.rs + src/filters/psf.rs */
+/* ------------------------------------------------------------------ */
+
+/* CubicSplineCoeffs, psf.rs:7-14 (arrays as loaded from psf.npz, io.rs:146-166) */
+typedef struct thz_spline {
+    const float *knots;    /* n_knots   */
+    const float *values;   /* n_knots   */
+    const float *coeff_a;  /* n_knots-1 */
+    const float *coeff_b;
+    const float *coeff_c;
+    const float *coeff_d;
+    size_t n_knots;
+} thz_spline;
+
+/* HybridFit, psf.rs:17-22: a/f + b + spline correction */
+typedef struct thz_hybrid_fit {
+    float base_a, base_b;
+    thz_spline correction;
+} thz_hybrid_fit;
+
+/* PSF, psf.rs:201-207 */
+typedef struct thz_psf {
+    thz_hybrid_fit wx_fit, wy_fit;
+    thz_spline x0_spline, y0_spline;
+} thz_psf;
+
+/* Deconvolution fields, deconvolution.rs:239-253 (defaults 500 / 25 / 0.1 / 10 / 0.5) */
+typedef struct thz_deconv_cfg {
+    uint32_t n_iterations;
+    uint32_t n_filters;
+    float start_freq, end_freq, win_width;
+} thz_deconv_cfg;
+
+/* host pieces, exported for tests and for hosts that want to show them:
+ * HybridFit::eval_single / eval_single_const_extrap (psf.rs:83-131),
+ * create_filter_bank (deconvolution.rs:160-211; filters n_filters x 499),
+ * the per-band 2-D PSF (deconvolution.rs:906-960 + psf.rs:228-313; call with
+ * out = NULL to get rows/cols). */
+int thz_host_psf_eval(const thz_psf *psf, const float *freqs, size_t n, float *wx, float *wy,
+                      float *x0, float *y0);
+int thz_host_filter_bank(const float *time, size_t nt, const thz_deconv_cfg *cfg, float *filters,
+                         float *centers);
+int thz_host_band_psf(const thz_psf *psf, float center_freq, float dx, float dy, size_t img_rows,
+                      size_t img_cols, float *out, size_t *rows, size_t *cols);
+
+/* Deconvolution::filter, deconvolution.rs:766-1041, on the cube (nx, ny, nt) with
+ * nt of the current time axis: FIR bank -> per band energy image ->
+ * Richardson–Lucy against the band's Gaussian PSF -> gain sqrt(max(u,0)/d) ->
+ * sum over bands of gain x filtered trace; d_img (may be NULL) = sum_t out^2.
+ * d_gains_out (may be NULL) receives the (n_filters, nx, ny) gains.
+ * abort_flag (may be NULL) is polled between iteration batches like the
+ * reference's cancellable loops; *progress (may be NULL) is updated in [0,1].
+ * Returns THZ_SKIPPED with out = in when one of the reference's guards applies
+ * (empty PSF, image < 16x16, PSF wider than the image), THZ_ERR_ABORTED (out =
+ * in) when aborted.  Blocking. */
+int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
+                   float dx, float dy, const float *d_in, float *d_out, float *d_img,
+                   float *d_gains_out, volatile const int *abort_flag, float *progress);
 
 /* Synthetic input generator for benchmarks and tests (not a reference
  * function): derivative-of-Gaussian pulse + echo + 1 % noise

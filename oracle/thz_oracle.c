@@ -18,6 +18,7 @@
  * that no FMA is formed where the Rust code has separate mul and add).
  */
 #define _GNU_SOURCE
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -679,6 +680,8 @@ void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny
     }
     rplan_free_f(r);
 }
+
+#include "thz_oracle_deconv.c"
 
 int thz_oracle_max_threads(void)
 {

@@ -231,6 +231,109 @@ def tilt(data, time, tilt_x_deg, tilt_y_deg, dx, dy):
     return steps, new_time, out
 
 
+# ---- deconvolution (oracle/thz_oracle_deconv.c) --------------------------------
+class OSpline(C.Structure):
+    _fields_ = [("n", C.c_int), ("knots", C.c_void_p), ("values", C.c_void_p), ("a", C.c_void_p),
+                ("b", C.c_void_p), ("c", C.c_void_p), ("d", C.c_void_p)]
+
+
+class OHybrid(C.Structure):
+    _fields_ = [("base_a", C.c_float), ("base_b", C.c_float), ("corr", OSpline)]
+
+
+class OPsf(C.Structure):
+    _fields_ = [("wx", OHybrid), ("wy", OHybrid), ("x0", OSpline), ("y0", OSpline)]
+
+
+def psf_from_npz(z):
+    keep = []
+
+    def arr(key):
+        a = np.ascontiguousarray(np.asarray(z[key], np.float64).astype(np.float32))
+        keep.append(a)
+        return a
+
+    def spline(prefix, kk, vk):
+        k, v = arr(kk), arr(vk)
+        co = [arr(f"{prefix}coeff_{c}") for c in "abcd"]
+        return OSpline(k.size, k.ctypes.data, v.ctypes.data, *[c.ctypes.data for c in co])
+
+    p = OPsf()
+    p.wx = OHybrid(float(np.asarray(z["wx_base_a"]).ravel()[0]), float(np.asarray(z["wx_base_b"]).ravel()[0]),
+                   spline("wx_corr_", "wx_corr_knots_thz", "wx_corr_values_mm"))
+    p.wy = OHybrid(float(np.asarray(z["wy_base_a"]).ravel()[0]), float(np.asarray(z["wy_base_b"]).ravel()[0]),
+                   spline("wy_corr_", "wy_corr_knots_thz", "wy_corr_values_mm"))
+    p.x0 = spline("x0_", "x0_knots_thz", "x0_values_mm")
+    p.y0 = spline("y0_", "y0_knots_thz", "y0_values_mm")
+    p._keep = keep
+    return p
+
+
+def psf_eval(psf, freqs):
+    f = f32(freqs)
+    out = [np.empty(f.size, np.float32) for _ in range(4)]
+    lib().thz_oracle_psf_eval(C.byref(psf), _p(f), C.c_int(f.size), *[_p(o) for o in out])
+    return tuple(out)
+
+
+def filter_bank(time, n_filters, start_freq, end_freq, win_width):
+    t = f32(time)
+    filters = np.empty((n_filters, 499), np.float32)
+    centers = np.empty(n_filters, np.float32)
+    # the filter's fields are f32 and widened with `as f64` (deconvolution.rs:823-825)
+    lib().thz_oracle_filter_bank(C.c_int(n_filters), C.c_double(float(np.float32(start_freq))),
+                                 C.c_double(float(np.float32(end_freq))), C.c_double(float(np.float32(win_width))),
+                                 _p(t), _p(filters), _p(centers))
+    return filters, centers
+
+
+def band_psf(psf, center_freq, dx, dy, img_rows, img_cols):
+    r, c, wx = C.c_int(), C.c_int(), C.c_float()
+    L = lib()
+    L.thz_oracle_band_psf(C.byref(psf), C.c_float(center_freq), C.c_float(dx), C.c_float(dy), img_rows, img_cols,
+                          None, C.byref(r), C.byref(c), C.byref(wx))
+    out = np.empty((r.value, c.value), np.float32)
+    L.thz_oracle_band_psf(C.byref(psf), C.c_float(center_freq), C.c_float(dx), C.c_float(dy), img_rows, img_cols,
+                          _p(out), C.byref(r), C.byref(c), C.byref(wx))
+    return out
+
+
+def filter_scan(data, filt):
+    d = f32(data)
+    nt = d.shape[-1]
+    f = f32(filt)
+    out = np.empty_like(d)
+    lib().thz_oracle_filter_scan(_p(d), C.c_size_t(d.size // nt), C.c_int(nt), _p(f), C.c_int(f.size), _p(out))
+    return out
+
+
+def richardson_lucy(image, psf2d, n_iter):
+    im, ps = f32(image), f32(psf2d)
+    out = np.empty_like(im)
+    lib().thz_oracle_richardson_lucy(_p(im), im.shape[0], im.shape[1], _p(ps), ps.shape[0], ps.shape[1],
+                                     C.c_int(n_iter), _p(out))
+    return out
+
+
+def deconvolution(data, time, dx, dy, psf, n_iterations, n_filters, start_freq, end_freq, win_width):
+    """-> (status, out cube, img, gains (n_filters,nx,ny), n_iter per band)"""
+    d = f32(data)
+    nx, ny, nt = d.shape
+    t = f32(time)
+    out = np.empty_like(d)
+    img = np.empty((nx, ny), np.float32)
+    gains = np.zeros((n_filters, nx, ny), np.float32)
+    niter = np.zeros(n_filters, np.int32)
+    L = lib()
+    L.thz_oracle_deconvolution.restype = C.c_int
+    rc = L.thz_oracle_deconvolution(_p(d), _p(t), nx, ny, nt, C.c_float(dx), C.c_float(dy), C.byref(psf),
+                                    C.c_int(n_iterations), C.c_int(n_filters), C.c_double(float(np.float32(start_freq))),
+                                    C.c_double(float(np.float32(end_freq))), C.c_double(float(np.float32(win_width))),
+                                    _p(out), _p(img), _p(gains),
+                                    _p(niter))
+    return rc, out, img, gains, niter
+
+
 def max_threads():
     return int(lib().thz_oracle_max_threads())
 

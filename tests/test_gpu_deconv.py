@@ -1,0 +1,105 @@
+"""Frequency-dependent Richardson–Lucy deconvolution (K12) on the GPU against
+the oracle's restatement of src/filters/deconvolution.rs:766-1041.  The
+reference never runs this math in its own tests (they stop at the 16x16 guard),
+so the oracle is the only checker; both its kernel-size branches are covered."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+import thz_image_explorer_amd as pkg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bar_target_cube(nx, ny, nt):
+    """stand-in for the absent resolution_target_sample.thzimg:
+    synthetic traces x a bar-target transmission mask"""
+    time, cube = synth.make_cube(nx, ny, nt)
+    xx, yy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    mask = 0.35 + 0.65 * (((xx // 3) % 2 == 0) & (yy > ny // 4) & (yy < 3 * ny // 4))
+    mask = mask + 0.3 * (((yy // 5) % 2 == 0) & (xx > nx // 2))
+    return time, (cube * mask[..., None].astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", [
+    dict(nx=32, ny=32, nt=256, dx=0.5, dy=0.5, n_iter=20, n_filters=6, f0=0.4, f1=3.0, mode=0),
+    dict(nx=48, ny=40, nt=128, dx=1.0, dy=1.0, n_iter=12, n_filters=4, f0=0.25, f1=2.0, mode=1),
+])
+def test_deconvolution_vs_oracle(engine, case):
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf, opsf = pkg.psf_from_npz(z), ob.psf_from_npz(z)
+    nx, ny, nt = case["nx"], case["ny"], case["nt"]
+    time, cube = _bar_target_cube(nx, ny, nt)
+    cfg = pkg.DeconvCfg(case["n_iter"], case["n_filters"], case["f0"], case["f1"], 0.5)
+    # the case really exercises the intended convolution branch
+    sizes = [pkg.host_band_psf(psf, f, case["dx"], case["dy"], nx, ny).size
+             for f in pkg.host_filter_bank(time, cfg)[1]]
+    assert (max(sizes) > 256) == (case["mode"] == 1)
+    rc, oref, oimg, ogains, oniter = ob.deconvolution(cube, time, case["dx"], case["dy"], opsf, case["n_iter"],
+                                                      case["n_filters"], case["f0"], case["f1"], 0.5)
+    assert rc == 0 and oniter.max() > 1
+    e = engine
+    e.set_time_axis(time)
+    d_in = e.to_device(cube); d_out = e.empty((nx * ny, nt)); d_img = e.empty((nx * ny,))
+    d_g = e.empty((case["n_filters"], nx * ny))
+    status = e.deconvolve(psf, cfg, nx, ny, case["dx"], case["dy"], d_in, d_out, d_img, d_g)
+    assert status == 0
+    out = d_out.download((nx, ny, nt), np.float32)
+    img = d_img.download((nx, ny), np.float32)
+    gains = d_g.download((case["n_filters"], nx, ny), np.float32)
+    assert np.isfinite(out).all()
+    assert np.abs(gains - ogains).max() / np.abs(ogains).max() < 2e-4
+    assert np.abs(out - oref).max() / np.abs(oref).max() < 2e-4
+    assert np.abs(img - oimg).max() / oimg.max() < 5e-4
+    # the filter does something: it is not the identity
+    assert np.abs(out - cube).max() / np.abs(cube).max() > 1e-2
+    for b in (d_in, d_out, d_img, d_g):
+        b.free()
+
+
+def test_deconvolution_guards_return_input(engine):
+    """deconvolution.rs:1139-1177 (the reference's own test): 2x2 < MIN_IMAGE_SIZE ->
+    input returned unchanged, shape preserved; same for an empty PSF"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nt = 64
+    time = synth.make_time(nt)
+    engine.set_time_axis(time)
+    data = synth.make_traces(np.arange(4), nt).reshape(2, 2, nt)
+    cfg = pkg.DeconvCfg(500, 25, 0.1, 10.0, 0.5)
+    d_in = engine.to_device(data); d_out = engine.empty((4, nt)); d_img = engine.empty((4,))
+    assert engine.deconvolve(psf, cfg, 2, 2, 1.0, 1.0, d_in, d_out, d_img) == 1  # THZ_SKIPPED
+    assert np.array_equal(d_out.download((2, 2, nt), np.float32), data)
+    assert np.allclose(d_img.download((4,), np.float32), (data.reshape(4, nt) ** 2).sum(1), rtol=1e-5)
+    empty = pkg.Psf()
+    big = synth.make_traces(np.arange(20 * 20), nt).reshape(20, 20, nt)
+    d2 = engine.to_device(big); o2 = engine.empty((400, nt))
+    assert engine.deconvolve(empty, cfg, 20, 20, 1.0, 1.0, d2, o2) == 1
+    assert np.array_equal(o2.download((20, 20, nt), np.float32), big)
+    # PSF wider than the image (0.1 THz beam ~ 9 mm on a 20 x 0.5 mm image)
+    assert engine.deconvolve(psf, cfg, 20, 20, 0.5, 0.5, d2, o2) == 1
+    for b in (d_in, d_out, d_img, d2, o2):
+        b.free()
+
+
+def test_unit_gain_bank_reconstructs_input(engine):
+    """the FIR bank sums to a unit impulse, so with zero RL iterations... n_iter >= 1
+    always; instead check linearity: deconvolve(a*x) = a*deconvolve(x) (gains are scale-free)"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nx = ny = 24
+    nt = 128
+    time, cube = _bar_target_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    cfg = pkg.DeconvCfg(5, 3, 0.5, 2.0, 0.5)
+    outs = []
+    for scale in (1.0, 4.0):
+        d_in = engine.to_device((cube * np.float32(scale)).astype(np.float32)); d_out = engine.empty((nx * ny, nt))
+        assert engine.deconvolve(psf, cfg, nx, ny, 0.5, 0.5, d_in, d_out) == 0
+        outs.append(d_out.download((nx, ny, nt), np.float32))
+        d_in.free(); d_out.free()
+    assert np.abs(outs[1] - 4.0 * outs[0]).max() / np.abs(outs[1]).max() < 1e-5

@@ -28,6 +28,51 @@ class WindowCfg(C.Structure):
     _fields_ = [("type", C.c_int32), ("lower", C.c_float), ("upper", C.c_float)]
 
 
+class Spline(C.Structure):
+    _fields_ = [("knots", C.c_void_p), ("values", C.c_void_p), ("coeff_a", C.c_void_p), ("coeff_b", C.c_void_p),
+                ("coeff_c", C.c_void_p), ("coeff_d", C.c_void_p), ("n_knots", C.c_size_t)]
+
+
+class HybridFit(C.Structure):
+    _fields_ = [("base_a", C.c_float), ("base_b", C.c_float), ("correction", Spline)]
+
+
+class Psf(C.Structure):
+    _fields_ = [("wx_fit", HybridFit), ("wy_fit", HybridFit), ("x0_spline", Spline), ("y0_spline", Spline)]
+
+
+class DeconvCfg(C.Structure):
+    _fields_ = [("n_iterations", C.c_uint32), ("n_filters", C.c_uint32), ("start_freq", C.c_float),
+                ("end_freq", C.c_float), ("win_width", C.c_float)]
+
+
+def psf_from_npz(z) -> "Psf":
+    """Builds a thz_psf from the arrays of a psf.npz (keys of io.rs:146-166).
+    The f32 copies are kept alive on the returned object."""
+    keep = []
+
+    def arr(key):
+        a = np.ascontiguousarray(np.asarray(z[key], np.float64).astype(np.float32))
+        keep.append(a)
+        return a
+
+    def spline(prefix, knots_key, values_key):
+        k, v = arr(knots_key), arr(values_key)
+        co = [arr(f"{prefix}coeff_{c}") for c in "abcd"]
+        return Spline(k.ctypes.data, v.ctypes.data, co[0].ctypes.data, co[1].ctypes.data, co[2].ctypes.data,
+                      co[3].ctypes.data, k.size)
+
+    psf = Psf()
+    psf.wx_fit = HybridFit(float(np.asarray(z["wx_base_a"]).ravel()[0]), float(np.asarray(z["wx_base_b"]).ravel()[0]),
+                           spline("wx_corr_", "wx_corr_knots_thz", "wx_corr_values_mm"))
+    psf.wy_fit = HybridFit(float(np.asarray(z["wy_base_a"]).ravel()[0]), float(np.asarray(z["wy_base_b"]).ravel()[0]),
+                           spline("wy_corr_", "wy_corr_knots_thz", "wy_corr_values_mm"))
+    psf.x0_spline = spline("x0_", "x0_knots_thz", "x0_values_mm")
+    psf.y0_spline = spline("y0_", "y0_knots_thz", "y0_values_mm")
+    psf._keep = keep
+    return psf
+
+
 class ThzError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"{STATUS.get(code, code)}: {msg}")
@@ -77,6 +122,12 @@ SYMBOLS = [
     ("thz_roi_mask", C.c_int, [_P, _P, _SZ, C.c_uint64, _SZ, _SZ, _P]),
     ("thz_roi_mean", C.c_int, [_P, _P, _SZ, _SZ, _SZ, _P, _P, _P, C.c_int]),
     ("thz_scale3d", C.c_int, [_P, _P, _SZ, _SZ, _SZ, C.c_int, _SZ, _P]),
+    ("thz_host_psf_eval", C.c_int, [C.POINTER(Psf), _P, _SZ, _P, _P, _P, _P]),
+    ("thz_host_filter_bank", C.c_int, [_P, _SZ, C.POINTER(DeconvCfg), _P, _P]),
+    ("thz_host_band_psf", C.c_int, [C.POINTER(Psf), C.c_float, C.c_float, C.c_float, _SZ, _SZ, _P,
+                                    C.POINTER(_SZ), C.POINTER(_SZ)]),
+    ("thz_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _SZ, _SZ, C.c_float, C.c_float,
+                                 _P, _P, _P, _P, _P, _P]),
     ("thz_synth_cube", C.c_int, [_P, _P, _SZ, C.c_uint64, _P, C.c_uint32, C.c_int]),
     ("thz_enable_timing", C.c_int, [_P, C.c_int]),
     ("thz_stage_time_ns", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
@@ -165,6 +216,32 @@ def host_tilt_plan(time, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy):
     L.thz_host_tilt_plan(t.ctypes.data, t.size, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy,
                          new_time.ctypes.data, ins.ctypes.data)
     return steps, new_time, ins
+
+
+def host_psf_eval(psf: Psf, freqs):
+    f = np.ascontiguousarray(freqs, np.float32)
+    out = [np.empty(f.size, np.float32) for _ in range(4)]
+    _rc(load_library().thz_host_psf_eval(C.byref(psf), f.ctypes.data, f.size, *[o.ctypes.data for o in out]), "psf_eval")
+    return tuple(out)  # wx, wy, x0, y0
+
+
+def host_filter_bank(time, cfg: DeconvCfg):
+    t = np.ascontiguousarray(time, np.float32)
+    filters = np.empty((cfg.n_filters, 499), np.float32)
+    centers = np.empty(cfg.n_filters, np.float32)
+    _rc(load_library().thz_host_filter_bank(t.ctypes.data, t.size, C.byref(cfg), filters.ctypes.data,
+                                            centers.ctypes.data), "filter_bank")
+    return filters, centers
+
+
+def host_band_psf(psf: Psf, center_freq, dx, dy, img_rows, img_cols):
+    r, c = C.c_size_t(), C.c_size_t()
+    L = load_library()
+    _rc(L.thz_host_band_psf(C.byref(psf), center_freq, dx, dy, img_rows, img_cols, None, C.byref(r), C.byref(c)), "band_psf")
+    out = np.empty((r.value, c.value), np.float32)
+    _rc(L.thz_host_band_psf(C.byref(psf), center_freq, dx, dy, img_rows, img_cols, out.ctypes.data,
+                            C.byref(r), C.byref(c)), "band_psf")
+    return out
 
 
 class DevBuf:
@@ -326,6 +403,14 @@ class Engine:
     def tilt_apply(self, npix, d_in, nt_in, d_taper, d_insert, nt_out, d_out):
         self._check(self.lib.thz_tilt_apply(self.ctx, npix, _dp(d_in), nt_in, _dp(d_taper), _dp(d_insert),
                                             nt_out, _dp(d_out)))
+
+    def deconvolve(self, psf: Psf, cfg: DeconvCfg, nx, ny, dx, dy, d_in, d_out, d_img=None, d_gains=None):
+        """-> status (0 applied, 1 skipped by one of the reference's guards)"""
+        rc = self.lib.thz_deconvolve(self.ctx, C.byref(psf), C.byref(cfg), nx, ny, dx, dy, _dp(d_in), _dp(d_out),
+                                     _dp(d_img), _dp(d_gains), None, None)
+        if rc < 0:
+            self._check(rc)
+        return rc
 
     def synth_cube(self, d_out, ntraces, first_trace, d_time, seed=0x7A3D2026, subtract_bias=True):
         self._check(self.lib.thz_synth_cube(self.ctx, _dp(d_out), ntraces, first_trace, _dp(d_time),

@@ -1,0 +1,131 @@
+// ctx.hpp — the context object behind thz_ctx* and small helpers shared by the
+// C-ABI translation units (api.cpp, deconv_api.cpp).
+#pragma once
+#include "../../include/thzgpu.h"
+
+#include "kernels.hpp"
+#include "plan_host.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+using namespace thz;
+
+struct thz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<float> time, freq;
+    PlanHost plan_h;
+    PlanDev plan_d{};
+    c32 *d_tables = nullptr;  // one allocation: tw | tw_split | chirp_conj | bfft
+    bool have_plan = false;
+    bool allow_f = true;  // thz_set_kernel_family
+    void *ws = nullptr;  // scratch workspace (pixel means, ROI lists)
+    size_t ws_bytes = 0;
+    int timing = 0;  // 0 off, 1 immediate (host waits per call), 2 deferred (no host wait)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t stage_ns[THZ_STAGE_COUNT] = {0};
+    struct Rec {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;        // deferred records awaiting thz_timing_collect
+    std::vector<hipEvent_t> pool;  // recycled events
+};
+
+namespace thz_api {
+
+inline int fail(thz_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, THZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline int use_device(thz_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return THZ_OK;
+}
+
+inline int ensure_ws(thz_ctx *ctx, size_t bytes)
+{
+    if (ctx->ws_bytes >= bytes) return THZ_OK;
+    if (ctx->ws) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return THZ_OK;
+}
+
+inline hipEvent_t pool_event(thz_ctx *ctx)
+{
+    if (!ctx->pool.empty()) {
+        hipEvent_t e = ctx->pool.back();
+        ctx->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Brackets one stage call with events on the context's stream.
+struct StageTimer {
+    thz_ctx *ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(thz_ctx *c, int s) : ctx(c), stage(s)
+    {
+        if (ctx->timing == 1) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (ctx->timing == 2) {
+            a = pool_event(ctx);
+            b = pool_event(ctx);
+            if (a) (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~StageTimer()
+    {
+        if (ctx->timing == 1) {
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+            if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
+                    ctx->stage_ns[stage] = (uint64_t)((double)ms * 1e6);
+            }
+        } else if (ctx->timing == 2 && a && b) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->recs.push_back({stage, a, b});
+        }
+    }
+};
+
+inline int check_launch(thz_ctx *ctx)
+{
+    HIP_TRY(ctx, hipGetLastError());
+    return THZ_OK;
+}
+
+inline int need_plan(thz_ctx *ctx)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (!ctx->have_plan) return fail(ctx, THZ_ERR_NOT_READY, "thz_set_time_axis has not been called");
+    return use_device(ctx);
+}
+
+}  // namespace thz_api
+using namespace thz_api;
+

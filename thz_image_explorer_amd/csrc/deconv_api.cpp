@@ -1,0 +1,236 @@
+// deconv_api.cpp — C ABI of the frequency-dependent Richardson–Lucy
+// deconvolution (K12): Deconvolution::filter, src/filters/deconvolution.rs:766-1041.
+#include "ctx.hpp"
+#include "deconv_host.hpp"
+
+#include <cmath>
+#include <cstring>
+
+using namespace thz;
+
+namespace {
+
+struct DevFree {
+    std::vector<void *> ptrs;
+    ~DevFree()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T **out, size_t bytes)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = reinterpret_cast<T *>(p);
+        return e;
+    }
+};
+
+int copy_through(thz_ctx *ctx, const float *d_in, float *d_out, float *d_img, size_t npix, size_t nt)
+{
+    if (d_out != d_in)
+        HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, npix * nt * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_img) {
+        launch_intensity(ctx->stream, npix, (int)nt, d_out, d_img, 0);
+        if (int rc = check_launch(ctx)) return rc;
+    }
+    return THZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thz_host_psf_eval(const thz_psf *psf, const float *freqs, size_t n, float *wx, float *wy,
+                      float *x0, float *y0)
+{
+    if (!psf || !freqs) return THZ_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i) {
+        if (wx) wx[i] = hybrid_eval(psf->wx_fit, freqs[i]);
+        if (wy) wy[i] = hybrid_eval(psf->wy_fit, freqs[i]);
+        if (x0) x0[i] = spline_eval_const(psf->x0_spline, freqs[i]);
+        if (y0) y0[i] = spline_eval_const(psf->y0_spline, freqs[i]);
+    }
+    return THZ_OK;
+}
+
+int thz_host_filter_bank(const float *time, size_t nt, const thz_deconv_cfg *cfg, float *filters,
+                         float *centers)
+{
+    if (!time || nt < 2 || !cfg || !filters || !centers || cfg->n_filters < 2) return THZ_ERR_INVALID;
+    std::vector<float> f, c;
+    filter_bank((int)cfg->n_filters, (double)cfg->start_freq, (double)cfg->end_freq,
+                (double)cfg->win_width, time, f, c);
+    std::memcpy(filters, f.data(), f.size() * sizeof(float));
+    std::memcpy(centers, c.data(), c.size() * sizeof(float));
+    return THZ_OK;
+}
+
+int thz_host_band_psf(const thz_psf *psf, float center_freq, float dx, float dy, size_t img_rows,
+                      size_t img_cols, float *out, size_t *rows, size_t *cols)
+{
+    if (!psf || !rows || !cols) return THZ_ERR_INVALID;
+    const BandPsf b = band_psf(*psf, center_freq, dx, dy, (int)img_rows, (int)img_cols);
+    *rows = (size_t)b.rows;
+    *cols = (size_t)b.cols;
+    if (out) std::memcpy(out, b.v.data(), b.v.size() * sizeof(float));
+    return THZ_OK;
+}
+
+int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
+                   float dx, float dy, const float *d_in, float *d_out, float *d_img,
+                   float *d_gains_out, volatile const int *abort_flag, float *progress)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!psf || !cfg || !d_in || !d_out || nx == 0 || ny == 0)
+        return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad argument");
+    const size_t nt = ctx->time.size(), npix = nx * ny;
+    const int nb = (int)cfg->n_filters;
+    if (progress) *progress = 0.0f;
+    // guards of the reference: each returns the input unchanged (:781-812, :873-885)
+    bool skip = psf->wx_fit.correction.n_knots == 0 || nx < 16 || ny < 16 || nb < 2;
+    std::vector<float> filters, centers;
+    float w_min = 0.0f, w_max = 0.0f;
+    if (!skip) {
+        filter_bank(nb, (double)cfg->start_freq, (double)cfg->end_freq, (double)cfg->win_width,
+                    ctx->time.data(), filters, centers);
+        float wx_min = INFINITY, wx_max = -INFINITY, wy_min = INFINITY, wy_max = -INFINITY;
+        for (int i = 0; i < nb; ++i) {
+            const float wx = hybrid_eval(psf->wx_fit, centers[(size_t)i]);
+            const float wy = hybrid_eval(psf->wy_fit, centers[(size_t)i]);
+            wx_min = std::fmin(wx_min, wx); wx_max = std::fmax(wx_max, wx);
+            wy_min = std::fmin(wy_min, wy); wy_max = std::fmax(wy_max, wy);
+        }
+        w_min = std::fmin(wx_min, wy_min);
+        w_max = std::fmax(wx_max, wy_max);
+        long mpx = (long)std::ceil(wx_max / dx) * 2 + 1, mpy = (long)std::ceil(wy_max / dy) * 2 + 1;
+        if (mpx < 3) mpx = 3;
+        if (mpy < 3) mpy = 3;
+        if (mpx >= (long)ny || mpy >= (long)nx) skip = true;  // img_cols = ny, img_rows = nx
+    }
+    if (skip) {
+        if (int rc = copy_through(ctx, d_in, d_out, d_img, npix, nt)) return rc;
+        if (progress) *progress = 1.0f;
+        return THZ_SKIPPED;
+    }
+
+    // ---- transform plan for the padded length M
+    size_t M = 1;
+    while (M < nt + kDeconvTaps - 1) M <<= 1;
+    PlanHost H;
+    if (M > 16384 || !build_plan(M, H, false))
+        return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
+    const size_t N = M / 2, nk = N + 1;
+    DevFree mem;
+    c32 *d_tw = nullptr, *d_spec = nullptr, *d_H = nullptr;
+    float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
+    RlBand *d_bands = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_tw, (H.tw.size() + H.tw_split.size()) * sizeof(c32)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_tw, H.tw.data(), H.tw.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_tw + H.tw.size(), H.tw_split.data(), H.tw_split.size() * sizeof(c32),
+                                hipMemcpyHostToDevice, ctx->stream));
+    const PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
+
+    // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double
+    std::vector<c32> Hh((size_t)nb * nk);
+    {
+        std::vector<double> cs(M), sn(M);
+        for (size_t m = 0; m < M; ++m) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)M;
+            cs[m] = std::cos(a);
+            sn[m] = std::sin(a);
+        }
+        for (int b = 0; b < nb; ++b)
+            for (size_t k = 0; k < nk; ++k) {
+                double re = 0.0, im = 0.0;
+                size_t idx = 0;
+                for (int j = 0; j < kDeconvTaps; ++j) {
+                    const double h = (double)filters[(size_t)b * kDeconvTaps + j];
+                    re += h * cs[idx];
+                    im += h * sn[idx];
+                    idx += k;
+                    if (idx >= M) idx -= M;
+                }
+                Hh[(size_t)b * nk + k] = c32{(float)(re / (double)M), (float)(im / (double)M)};
+            }
+    }
+    HIP_TRY(ctx, mem.alloc(&d_H, Hh.size() * sizeof(c32)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_H, Hh.data(), Hh.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- per-band PSFs, iteration counts, workspace layout
+    std::vector<RlBand> bands((size_t)nb);
+    std::vector<float> psf_pack;
+    size_t ws_floats = 0;
+    unsigned blk = 0;
+    int max_iter = 0;
+    std::vector<BandPsf> psfs((size_t)nb);
+    for (int b = 0; b < nb; ++b) {
+        psfs[(size_t)b] = band_psf(*psf, centers[(size_t)b], dx, dy, (int)nx, (int)ny);
+        const BandPsf &bp = psfs[(size_t)b];
+        RlBand &B = bands[(size_t)b];
+        B.h = (int)nx; B.w = (int)ny;
+        B.pr = bp.rows; B.pc = bp.cols;
+        B.pad_y = bp.rows / 2; B.pad_x = bp.cols / 2;
+        B.H = B.h + 2 * B.pad_y; B.W = B.w + 2 * B.pad_x;
+        B.mode = (bp.rows * bp.cols <= 256) ? 0 : 1;
+        // n_iter, deconvolution.rs:969-971 (NaN -> 0 through `as usize`)
+        const float fi = std::floor((bp.wx - w_min) / (w_max - w_min) * ((float)cfg->n_iterations - 1.0f) + 1.0f);
+        B.n_iter = (fi != fi || fi < 0.0f) ? 0 : (int)fi;
+        if (B.n_iter > max_iter) max_iter = B.n_iter;
+        B.blk0 = blk;
+        blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
+        const size_t img = (size_t)B.H * B.W;
+        B.off_d = (unsigned)ws_floats; ws_floats += img;
+        B.off_u = (unsigned)ws_floats; ws_floats += img;
+        B.off_t = (unsigned)ws_floats; ws_floats += img;
+    }
+    for (int b = 0; b < nb; ++b) {
+        const BandPsf &bp = psfs[(size_t)b];
+        RlBand &B = bands[(size_t)b];
+        B.off_psf = (unsigned)(ws_floats + psf_pack.size());
+        psf_pack.insert(psf_pack.end(), bp.v.begin(), bp.v.end());
+        B.off_mirror = (unsigned)(ws_floats + psf_pack.size());
+        for (size_t i = bp.v.size(); i-- > 0;) psf_pack.push_back(bp.v[i]);  // psf[::-1, ::-1]
+    }
+    HIP_TRY(ctx, mem.alloc(&d_ws, (ws_floats + psf_pack.size()) * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, mem.alloc(&d_bands, bands.size() * sizeof(RlBand)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_bands, bands.data(), bands.size() * sizeof(RlBand), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, mem.alloc(&d_spec, npix * nk * sizeof(c32)));
+    HIP_TRY(ctx, mem.alloc(&d_energy, (size_t)nb * npix * sizeof(float)));
+    HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nb * npix * sizeof(float)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope below
+
+    const int shift = (kDeconvTaps - 1) / 2;
+    launch_dc_fft(ctx->stream, P, npix, (int)nt, d_in, d_spec);
+    launch_dc_energy(ctx->stream, P, npix, (int)nt, nb, shift, d_spec, d_H, d_energy);
+    launch_rl_init(ctx->stream, d_bands, nb, blk, npix, d_energy, d_ws);
+    if (int rc = check_launch(ctx)) return rc;
+    for (int it = 0; it < max_iter; ++it) {
+        if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (int rc = copy_through(ctx, d_in, d_out, d_img, npix, nt)) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
+        }
+        launch_rl_step(ctx->stream, d_bands, nb, blk, it, 0, d_ws);
+        launch_rl_step(ctx->stream, d_bands, nb, blk, it, 1, d_ws);
+        if ((it & 31) == 31) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
+            if (progress) *progress = (float)(it + 1) / (float)max_iter;
+        }
+    }
+    launch_dc_gain(ctx->stream, d_bands, nb, npix, d_energy, d_ws, d_gain);
+    launch_dc_combine(ctx->stream, P, npix, (int)nt, nb, shift, d_spec, d_H, d_gain, d_out, d_img);
+    if (int rc = check_launch(ctx)) return rc;
+    if (d_gains_out)
+        HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nb * npix * sizeof(float),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // temporaries are freed on return
+    if (progress) *progress = 1.0f;
+    return THZ_OK;
+}
+
+}  // extern "C"

@@ -633,6 +633,241 @@ __global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, 
 }
 
 // ---------------------------------------------------------------------------
+// Frequency-dependent Richardson–Lucy deconvolution (K12),
+// src/filters/deconvolution.rs:766-1041.
+//
+//  k_dc_fft      every trace, zero-padded to M = next_pow2(nt + 498): real FFT,
+//                spectrum kept (one forward transform serves all bands)
+//  k_dc_energy   per trace and band b:  |h_b * x|^2 summed over the "same"
+//                slice [249, 249 + nt) of the linear convolution (:574-609, :966)
+//  k_rl_*        Richardson–Lucy on every band's energy image (:620-712), all
+//                bands batched per iteration
+//  k_dc_gain     g_b = sqrt(max(u_b, 0) / d_b)  (:975, :986-993)
+//  k_dc_combine  out = sum_b g_b (h_b * x) = IFFT(X . sum_b g_b H_b), sliced
+//                (:996-1011; linear in x, so one inverse per trace)
+// The reference convolves in Complex<f64> and rounds to f32; here the FIR runs
+// through the f32 transform (error ~1e-6 of the trace maximum).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dc_fft(PlanDev P, size_t npix, int nt,
+                                                const float *__restrict__ in,
+                                                c32 *__restrict__ spec)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
+    c32 *B = A + P.buf_entries;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = in + p * nt;
+        for (int i = lane; i < N; i += kWave) {
+            const float a = (2 * i < nt) ? x[2 * i] : 0.0f;
+            const float b = (2 * i + 1 < nt) ? x[2 * i + 1] : 0.0f;
+            A[i] = c32{a, b};
+        }
+        wave_sync();
+        c32 *Z = wave_cfft(A, B, P.log2n, P.tw, lane);
+        c32 *Xb = (Z == A) ? B : A;
+        r2c_split(Z, Xb, N, P.tw_split, lane);
+        for (int k = lane; k <= N; k += kWave) spec[p * (size_t)(N + 1) + k] = Xb[k];
+        wave_sync();
+    }
+}
+
+// value i of the real sequence held (swapped) in R: x[2n] = R[n].im, x[2n+1] = R[n].re
+__device__ __forceinline__ float dc_real_at(const c32 *R, int i)
+{
+    const c32 r = R[i >> 1];
+    return (i & 1) ? r.re : r.im;
+}
+
+// LDS per wave: X (N+2) | A (N+2) | B (N+2)
+__global__ __launch_bounds__(256) void k_dc_energy(PlanDev P, size_t npix, int nt, int n_bands,
+                                                   int shift, const c32 *__restrict__ spec,
+                                                   const c32 *__restrict__ H,
+                                                   float *__restrict__ energy)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    c32 *X = reinterpret_cast<c32 *>(lds + (size_t)wib * (size_t)(3 * P.buf_entries) * sizeof(c32));
+    c32 *A = X + P.buf_entries;
+    c32 *B = A + P.buf_entries;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        for (int k = lane; k <= N; k += kWave) X[k] = spec[p * (size_t)(N + 1) + k];
+        wave_sync();
+        for (int b = 0; b < n_bands; ++b) {
+            const c32 *Hb = H + (size_t)b * (N + 1);
+            for (int k = lane; k <= N; k += kWave) A[k] = cmul(X[k], Hb[k]);
+            wave_sync();
+            c2r_merge_swapped(A, B, N, P.tw_split, lane);
+            const c32 *R = wave_cfft(B, A, P.log2n, P.tw, lane);
+            float acc = 0.0f;
+            for (int t = lane; t < nt; t += kWave) {
+                const float v = dc_real_at(R, t + shift);
+                acc += v * v;
+            }
+            acc = wave_reduce_add(acc);
+            if (lane == 0) energy[(size_t)b * npix + p] = acc;
+            wave_sync();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dc_combine(PlanDev P, size_t npix, int nt, int n_bands,
+                                                    int shift, const c32 *__restrict__ spec,
+                                                    const c32 *__restrict__ H,
+                                                    const float *__restrict__ gain,
+                                                    float *__restrict__ out,
+                                                    float *__restrict__ img)
+{
+    THZ_DYN_LDS(lds);
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    const int N = 1 << P.log2n;
+    c32 *X = reinterpret_cast<c32 *>(lds + (size_t)wib * (size_t)(3 * P.buf_entries) * sizeof(c32));
+    c32 *A = X + P.buf_entries;
+    c32 *B = A + P.buf_entries;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        for (int k = lane; k <= N; k += kWave) {
+            c32 hc = c32{0.0f, 0.0f};
+            for (int b = 0; b < n_bands; ++b) {
+                const float g = gain[(size_t)b * npix + p];
+                const c32 h = H[(size_t)b * (N + 1) + k];
+                hc.re += g * h.re;
+                hc.im += g * h.im;
+            }
+            A[k] = cmul(spec[p * (size_t)(N + 1) + k], hc);
+        }
+        wave_sync();
+        c2r_merge_swapped(A, B, N, P.tw_split, lane);
+        const c32 *R = wave_cfft(B, A, P.log2n, P.tw, lane);
+        float acc = 0.0f;
+        for (int t = lane; t < nt; t += kWave) {
+            const float v = dc_real_at(R, t + shift);
+            out[p * nt + t] = v;
+            acc += v * v;
+        }
+        if (img) {
+            acc = wave_reduce_add(acc);
+            if (lane == 0) img[p] = acc;
+        }
+        wave_sync();
+    }
+}
+
+// ---- Richardson–Lucy, batched over bands -----------------------------------
+// index of the first block of band b in the flattened grid is blk0[b]
+__device__ __forceinline__ int rl_find_band(const RlBand *bands, int n_bands, unsigned blk,
+                                            unsigned *local_blk)
+{
+    int b = 0;
+    while (b + 1 < n_bands && blk >= bands[b + 1].blk0) ++b;
+    *local_blk = blk - bands[b].blk0;
+    return b;
+}
+
+// reflect padding of the energy image, deconvolution.rs:629-670; u = d
+__global__ __launch_bounds__(256) void k_rl_init(const RlBand *__restrict__ bands, int n_bands,
+                                                 size_t npix, const float *__restrict__ energy,
+                                                 float *__restrict__ ws)
+{
+    unsigned lb;
+    const int b = rl_find_band(bands, n_bands, blockIdx.x, &lb);
+    const RlBand B = bands[b];
+    const int idx = (int)(lb * blockDim.x + threadIdx.x);
+    if (idx >= B.H * B.W) return;
+    const int Y = idx / B.W, X = idx % B.W;
+    // rows first (from the image), then columns (from the row-padded array)
+    int xs = X - B.pad_x;                 // column in image coordinates
+    if (X < B.pad_x) xs = B.pad_x - X;              // src col pad_x + (pad_x - j), j = X
+    else if (X >= B.pad_x + B.w) xs = B.w - 2 - (X - B.pad_x - B.w);
+    int ys = Y - B.pad_y;
+    if (Y < B.pad_y) ys = B.pad_y - Y;
+    else if (Y >= B.pad_y + B.h) ys = B.h - 2 - (Y - B.pad_y - B.h);
+    const float v = energy[(size_t)b * npix + (size_t)ys * B.w + xs];
+    ws[B.off_d + idx] = v;
+    ws[B.off_u + idx] = v;
+}
+
+// one "same" 2-D convolution value, deconvolution.rs:432-458 (mode 0: kernels of
+// <= 256 elements, correlation-indexed) or the FFT path's intended result
+// (mode 1: true convolution, offset (b-1)/2).  m outer / n inner, no FMA
+// contraction, like the CPU loops.
+__device__ __forceinline__ float rl_conv_at(const float *__restrict__ a, int H, int W,
+                                            const float *__restrict__ k, int pr, int pc, int mode,
+                                            int i, int j)
+{
+#pragma clang fp contract(off)
+    float sum = 0.0f;
+    if (mode == 0) {
+        const int hr = pr / 2, hc = pc / 2;
+        for (int m = 0; m < pr; ++m) {
+            const int x = i + m - hr;
+            if (x < 0 || x >= H) continue;
+            for (int n = 0; n < pc; ++n) {
+                const int y = j + n - hc;
+                if (y >= 0 && y < W) sum += a[(size_t)x * W + y] * k[m * pc + n];
+            }
+        }
+    } else {
+        const int sr = (pr - 1) / 2, sc = (pc - 1) / 2;
+        for (int m = 0; m < pr; ++m) {
+            const int x = i + sr - m;
+            if (x < 0 || x >= H) continue;
+            for (int n = 0; n < pc; ++n) {
+                const int y = j + sc - n;
+                if (y >= 0 && y < W) sum += a[(size_t)x * W + y] * k[m * pc + n];
+            }
+        }
+    }
+    return sum;
+}
+
+// step 1: t = d / (u (*) psf + eps)     step 2: u *= t (*) mirror(psf)
+__global__ __launch_bounds__(256) void k_rl_step(const RlBand *__restrict__ bands, int n_bands,
+                                                 int iteration, int step,
+                                                 float *__restrict__ ws)
+{
+#pragma clang fp contract(off)
+    unsigned lb;
+    const int b = rl_find_band(bands, n_bands, blockIdx.x, &lb);
+    const RlBand B = bands[b];
+    if (iteration >= B.n_iter) return;
+    const int idx = (int)(lb * blockDim.x + threadIdx.x);
+    if (idx >= B.H * B.W) return;
+    const int i = idx / B.W, j = idx % B.W;
+    if (step == 0) {
+        const float c = rl_conv_at(ws + B.off_u, B.H, B.W, ws + B.off_psf, B.pr, B.pc, B.mode, i, j);
+        ws[B.off_t + idx] = ws[B.off_d + idx] / (c + 1e-12f);
+    } else {
+        const float c = rl_conv_at(ws + B.off_t, B.H, B.W, ws + B.off_mirror, B.pr, B.pc, B.mode, i, j);
+        ws[B.off_u + idx] = ws[B.off_u + idx] * c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dc_gain(const RlBand *__restrict__ bands, int n_bands,
+                                                 size_t npix, const float *__restrict__ energy,
+                                                 const float *__restrict__ ws,
+                                                 float *__restrict__ gain)
+{
+    const size_t total = (size_t)n_bands * npix;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / npix);
+        const size_t p = idx % npix;
+        const RlBand B = bands[b];
+        const int y = (int)(p / B.w), x = (int)(p % B.w);
+        const float u = ws[B.off_u + (size_t)(y + B.pad_y) * B.W + (x + B.pad_x)];
+        gain[idx] = sqrtf(fmaxf(u, 0.0f) / energy[idx]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Synthetic cube generator (bench / test input): counter-based
 // Philox4x32-10 so any tile is reproducible on host (tests/synth.py) or device.
 // ---------------------------------------------------------------------------
@@ -928,6 +1163,73 @@ void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float
 {
     THZ_LAUNCH(k_tilt, grid_1d(npix * nt_out, 256, kNumCU * 8), 256, 0, st, npix, nt_in, nt_out, in,
                taper, insert_index, out);
+}
+
+// ---- deconvolution launchers
+static inline void dc_geometry(const PlanDev &P, size_t npix, int bufs, unsigned *grid,
+                               unsigned *block, size_t *lds)
+{
+    const size_t per_wave = (size_t)bufs * P.buf_entries * sizeof(c32);
+    unsigned wpb = (unsigned)(kLdsBytesPerCU / per_wave);
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) wpb = 1;
+    *block = wpb * kWave;
+    *lds = per_wave * wpb;
+    size_t per_cu = kLdsBytesPerCU / *lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * wpb > 32) per_cu = 32 / wpb;
+    size_t g = (npix + wpb - 1) / wpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (g < 1) g = 1;
+    *grid = (unsigned)g;
+}
+
+void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec)
+{
+    unsigned grid, block;
+    size_t lds;
+    wave_launch_geometry(P, npix, &grid, &block, &lds);
+    allow_dynamic_lds(k_dc_fft, lds);
+    THZ_LAUNCH(k_dc_fft, grid, block, lds, st, P, npix, nt, in, spec);
+}
+
+void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
+                      const c32 *spec, const c32 *H, float *energy)
+{
+    unsigned grid, block;
+    size_t lds;
+    dc_geometry(P, npix, 3, &grid, &block, &lds);
+    allow_dynamic_lds(k_dc_energy, lds);
+    THZ_LAUNCH(k_dc_energy, grid, block, lds, st, P, npix, nt, n_bands, shift, spec, H, energy);
+}
+
+void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
+                       const c32 *spec, const c32 *H, const float *gain, float *out, float *img)
+{
+    unsigned grid, block;
+    size_t lds;
+    dc_geometry(P, npix, 3, &grid, &block, &lds);
+    allow_dynamic_lds(k_dc_combine, lds);
+    THZ_LAUNCH(k_dc_combine, grid, block, lds, st, P, npix, nt, n_bands, shift, spec, H, gain, out, img);
+}
+
+void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
+                    size_t npix, const float *energy, float *ws)
+{
+    THZ_LAUNCH(k_rl_init, total_blocks, 256, 0, st, d_bands, n_bands, npix, energy, ws);
+}
+
+void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
+                    int iteration, int step, float *ws)
+{
+    THZ_LAUNCH(k_rl_step, total_blocks, 256, 0, st, d_bands, n_bands, iteration, step, ws);
+}
+
+void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
+                    const float *energy, const float *ws, float *gain)
+{
+    THZ_LAUNCH(k_dc_gain, grid_1d((size_t)n_bands * npix, 256, kNumCU * 8), 256, 0, st, d_bands,
+               n_bands, npix, energy, ws, gain);
 }
 
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,

@@ -38,6 +38,30 @@ struct PlanDev {
 
 enum : int { kFamilyG = 0, kFamilyF = 1 };
 
+// one band of the batched Richardson–Lucy solve (offsets in floats into one workspace)
+struct RlBand {
+    int h, w;           // image (nx, ny)
+    int pr, pc;         // PSF rows (x) / cols (y)
+    int pad_y, pad_x;   // pr/2, pc/2
+    int H, W;           // padded image
+    int n_iter;
+    int mode;           // 0: <= 256-element kernel (correlation-indexed), 1: true "same" convolution
+    unsigned blk0;      // first block of this band in the flattened grid
+    unsigned off_d, off_u, off_t, off_psf, off_mirror;
+};
+
+void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec);
+void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
+                      const c32 *spec, const c32 *H, float *energy);
+void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
+                       const c32 *spec, const c32 *H, const float *gain, float *out, float *img);
+void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
+                    size_t npix, const float *energy, float *ws);
+void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
+                    int iteration, int step, float *ws);
+void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
+                    const float *energy, const float *ws, float *gain);
+
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
                     float *amp_out, float *ph_out, const float *mask);
