@@ -142,6 +142,17 @@ int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double h
                          double window_width, float *out /* nf */, int64_t *lower,
                          int64_t *upper);
 
+/* Build-defined frequency-domain filters (the reference has neither; it only
+ * draws the water lines, gui/center_panel.rs:477-485).  Both
+ * produce per-bin multipliers for thz_apply_fd_mask / thz_apply_fd_cmask.
+ *   water lines (K14): out[k] = prod_i (1 - exp(-((f_k - line_i)/sigma)^2))
+ *   Wiener (K13): out[k] = conj(R[k]) / (|R[k]|^2 + eps_rel * max_j |R[j]|^2),
+ *                 R = spectrum of the reference pulse (interleaved, nf bins) */
+int thz_host_water_line_mask(const float *frequency, size_t nf, const float *lines_thz,
+                             size_t n_lines, float sigma_thz, float *out /* nf */);
+int thz_host_wiener_filter(const float *ref_fft, size_t nf, float eps_rel,
+                           float *out_cmask /* nf interleaved complex */);
+
 /* TiltCompensation::filter geometry, tilt_compensation.rs:104-175 (K11): the
  * time extension (floor((|cx*tx| + |cy*ty|)/c/0.05)*0.05 with the reference's
  * hard-coded dt = 0.05 ps), the extended time axis (front/back linspaces) and,

@@ -429,3 +429,49 @@ def test_reference_tilt_unit_tests(engine):
         assert int(np.argmax(out[1, 1])) == impulse_idx + steps
         for b in (d_in, d_tp, d_ins, d_out):
             b.free()
+
+
+# ---- K13 / K14: build-defined complex / real frequency multipliers ------------
+def test_wiener_and_water_lines_chain(engine):
+    """reference-pulse Wiener deconvolution + water-line notch as Frequency-domain
+    plugins: spectrum * H, then C2R — vs numpy fp64 with the same definitions"""
+    nx, ny, nt = 4, 8, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    e = engine
+    e.set_time_axis(time)
+    freq = e.frequency()
+    nf = e.nf
+    npix = nx * ny
+    # synthetic reference = noise-free pulse template (SURVEY §8d, config 5)
+    z = ((time - time[0] - 11.0) / 0.35).astype(np.float32)
+    ref = (-z * np.exp(-z * z)).astype(np.float32)
+    w = pkg.host_fft_window(time, 0, 1.0, 7.0)
+    d_ref = e.to_device(ref); d_w = e.to_device(w); d_rf = e.empty((nf, 2))
+    e.fft(1, d_ref, d_w, None, None, d_rf, None, None, None)
+    R = d_rf.download((nf, 2), np.float32)
+    H = pkg.host_wiener_filter(R, 1e-2)
+    lines = np.loadtxt(os.path.join(GOLD, "water_lines.csv"), dtype=np.float32)
+    notch = pkg.host_water_line_mask(freq, lines, 0.01)
+    band = pkg.host_fd_bandpass(freq, 0.2, 5.0, 0.1)[0]
+    d_x = e.to_device(cube); d_fft = e.empty((npix, nf, 2)); d_amp = e.empty((npix, nf)); d_ph = e.empty((npix, nf))
+    e.fft(npix, d_x, d_w, None, None, d_fft, d_amp, d_ph, None)
+    amp0 = d_amp.download((npix, nf), np.float32)
+    d_H = e.to_device(H); d_n = e.to_device((notch * band).astype(np.float32))
+    e.apply_fd_cmask(npix, d_fft, d_amp, d_H)
+    e.apply_fd_mask(npix, d_fft, d_amp, d_n)
+    d_out = e.empty((npix, nt))
+    e.ifft(npix, d_fft, None, d_out, None)
+    got = d_out.download((npix, nt), np.float32)
+    X = np.fft.rfft(cube.reshape(npix, nt).astype(np.float64) * w, axis=1)
+    Hc = (H[:, 0].astype(np.float64) + 1j * H[:, 1]) * (notch * band)
+    Y = X * Hc
+    Y[:, 0] = Y[:, 0].real
+    Y[:, -1] = Y[:, -1].real
+    ref_t = np.fft.irfft(Y, n=nt, axis=1)
+    assert np.abs(got - ref_t).max() / np.abs(ref_t).max() < 1e-4
+    amp = d_amp.download((npix, nf), np.float32)
+    assert np.abs(amp - amp0 * np.abs(Hc)).max() / (amp0 * np.abs(Hc)).max() < 1e-4
+    F = d_fft.download((npix, nf, 2), np.float32)
+    assert np.all(F[:, 0, 1] == 0) and np.all(F[:, -1, 1] == 0)  # C2R precondition (SURVEY a'-4)
+    for b in (d_ref, d_w, d_rf, d_x, d_fft, d_amp, d_ph, d_H, d_n, d_out):
+        b.free()

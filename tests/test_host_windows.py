@@ -82,3 +82,31 @@ def test_tilt_plan_matches_oracle(tilt):
     assert np.array_equal(new_time, otime)
     peak = np.argmax(out.reshape(nx * ny, -1), axis=1)
     assert np.array_equal(ins, peak - 50)
+
+
+# ---- build-defined frequency multipliers (K13 / K14; not in the reference) -----
+def test_water_line_mask_definition():
+    import os
+    lines = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "water_lines.csv"), dtype=np.float32)
+    assert lines.size == 135
+    time = (1000 + 0.05 * np.arange(4096)).astype(np.float32)
+    freq = pkg.host_frequency_axis(time)
+    m = pkg.host_water_line_mask(freq, lines, 0.01)
+    ref = np.prod(1.0 - np.exp(-(((freq[:, None].astype(np.float64) - lines[None, :]) / 0.01) ** 2)), axis=1)
+    assert np.abs(m - ref).max() < 1e-5
+    k = np.argmin(np.abs(freq - lines[0]))
+    assert m[k] < 0.2 and 0.0 <= m.min() and m.max() <= 1.0
+    assert m[np.argmin(np.abs(freq - 0.3))] > 0.999  # far from any line: untouched
+
+
+def test_wiener_filter_definition():
+    rng = np.random.default_rng(0)
+    R = (rng.standard_normal(513) + 1j * rng.standard_normal(513)) * np.exp(-np.arange(513) / 100.0)
+    r = np.stack([R.real, R.imag], -1).astype(np.float32)
+    h = pkg.host_wiener_filter(r, 1e-3)
+    H = h[:, 0] + 1j * h[:, 1]
+    Rf = r[:, 0].astype(np.float64) + 1j * r[:, 1]
+    ref = np.conj(Rf) / (np.abs(Rf) ** 2 + 1e-3 * (np.abs(Rf) ** 2).max())
+    assert np.abs(H - ref).max() / np.abs(ref).max() < 1e-5
+    strong = np.abs(Rf) > 0.5 * np.abs(Rf).max()
+    assert np.abs(H[strong] * Rf[strong] - 1).max() < 5e-3  # inverts where the reference has signal

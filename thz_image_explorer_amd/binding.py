@@ -107,6 +107,8 @@ SYMBOLS = [
                                        C.c_double, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("thz_host_fd_bandpass", C.c_int, [_P, _SZ, C.c_double, C.c_double, C.c_double, _P,
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("thz_host_water_line_mask", C.c_int, [_P, _SZ, _P, _SZ, C.c_float, _P]),
+    ("thz_host_wiener_filter", C.c_int, [_P, _SZ, C.c_float, _P]),
     ("thz_host_tilt_plan", _SZ, [_P, _SZ, _SZ, _SZ, C.c_double, C.c_double, C.c_float, C.c_float, _P, _P]),
     ("thz_tilt_apply", C.c_int, [_P, _SZ, _P, _SZ, _P, _P, _SZ, _P]),
     ("thz_fft", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -204,6 +206,23 @@ def host_fd_bandpass(frequency, low: float, high: float, width: float):
     _rc(load_library().thz_host_fd_bandpass(f.ctypes.data, f.size, low, high, width, out.ctypes.data,
                                             C.byref(l), C.byref(u)), "fd_bandpass")
     return out, l.value, u.value
+
+
+def host_water_line_mask(frequency, lines_thz, sigma_thz=0.01) -> np.ndarray:
+    f = np.ascontiguousarray(frequency, np.float32)
+    ln = np.ascontiguousarray(lines_thz, np.float32)
+    out = np.empty(f.size, np.float32)
+    _rc(load_library().thz_host_water_line_mask(f.ctypes.data, f.size, ln.ctypes.data, ln.size, sigma_thz,
+                                                out.ctypes.data), "water_line_mask")
+    return out
+
+
+def host_wiener_filter(ref_fft, eps_rel=1e-3) -> np.ndarray:
+    """ref_fft (nf, 2) f32 -> (nf, 2) complex multiplier"""
+    r = np.ascontiguousarray(ref_fft, np.float32).reshape(-1, 2)
+    out = np.empty_like(r)
+    _rc(load_library().thz_host_wiener_filter(r.ctypes.data, r.shape[0], eps_rel, out.ctypes.data), "wiener_filter")
+    return out
 
 
 def host_tilt_plan(time, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy):

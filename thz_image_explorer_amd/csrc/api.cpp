@@ -236,6 +236,21 @@ int thz_host_fd_bandpass(const float *frequency, size_t nf, double low, double h
     return THZ_OK;
 }
 
+int thz_host_water_line_mask(const float *frequency, size_t nf, const float *lines_thz,
+                             size_t n_lines, float sigma_thz, float *out)
+{
+    if (!frequency || !out || (n_lines && !lines_thz) || !(sigma_thz > 0.0f)) return THZ_ERR_INVALID;
+    water_line_mask(frequency, nf, lines_thz, n_lines, sigma_thz, out);
+    return THZ_OK;
+}
+
+int thz_host_wiener_filter(const float *ref_fft, size_t nf, float eps_rel, float *out_cmask)
+{
+    if (!ref_fft || !out_cmask || !(eps_rel >= 0.0f)) return THZ_ERR_INVALID;
+    wiener_filter(ref_fft, nf, eps_rel, out_cmask);
+    return THZ_OK;
+}
+
 size_t thz_host_tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
                           double tilt_y_deg, float dx, float dy, float *new_time,
                           int32_t *insert_index)

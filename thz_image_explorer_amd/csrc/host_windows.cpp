@@ -109,6 +109,39 @@ void fd_bandpass(const float *freq, size_t nf, double low, double high, double w
     if (upper_out) *upper_out = (int64_t)upper;
 }
 
+// ---- build-defined frequency-domain multipliers (not in the reference)
+
+// K14 water-vapour line notch: prod_i (1 - exp(-((f - f_i)/sigma)^2)), f32
+void water_line_mask(const float *freq, size_t nf, const float *lines, size_t n_lines, float sigma,
+                     float *out)
+{
+    for (size_t k = 0; k < nf; ++k) {
+        float m = 1.0f;
+        for (size_t i = 0; i < n_lines; ++i) {
+            const float z = (freq[k] - lines[i]) / sigma;
+            m *= 1.0f - std::exp(-(z * z));
+        }
+        out[k] = m;
+    }
+}
+
+// K13 reference-pulse Wiener deconvolution: H = conj(R) / (|R|^2 + eps_rel * max|R|^2)
+void wiener_filter(const float *ref_fft, size_t nf, float eps_rel, float *out)
+{
+    float mx = 0.0f;
+    for (size_t k = 0; k < nf; ++k) {
+        const float p = ref_fft[2 * k] * ref_fft[2 * k] + ref_fft[2 * k + 1] * ref_fft[2 * k + 1];
+        if (p > mx) mx = p;
+    }
+    const float eps = eps_rel * mx;
+    for (size_t k = 0; k < nf; ++k) {
+        const float re = ref_fft[2 * k], im = ref_fft[2 * k + 1];
+        const float den = re * re + im * im + eps;
+        out[2 * k] = den > 0.0f ? re / den : 0.0f;
+        out[2 * k + 1] = den > 0.0f ? -im / den : 0.0f;
+    }
+}
+
 // ndarray::Array1::linspace: start + step * i
 static void linspace(float a, float b, size_t n, float *out)
 {

@@ -10,6 +10,9 @@ void td_bandpass(const float *time, size_t nt, double *low, double *high, double
                  int64_t *lower_out, int64_t *upper_out);
 void fd_bandpass(const float *freq, size_t nf, double low, double high, double width, float *out,
                  int64_t *lower_out, int64_t *upper_out);
+void water_line_mask(const float *freq, size_t nf, const float *lines, size_t n_lines, float sigma,
+                     float *out);
+void wiener_filter(const float *ref_fft, size_t nf, float eps_rel, float *out);
 size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
                  double tilt_y_deg, float dx, float dy, float *new_time, int32_t *insert_index);
 }  // namespace thz
