@@ -1,0 +1,62 @@
+"""The C++ host mirror (thz_image_explorer_amd/host: ScannedImageFilterData,
+math_tools::{scaling,fft,ifft}, Filter plugins + registry, the stage walk of
+data_thread.rs:1090-1228) on the GPU: its self-test re-runs the reference's unit
+tests, and its default-chain output is compared with the oracle walking the
+same stages."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "thz_image_explorer_amd", "host_selftest")
+
+
+def test_host_mirror_selftest_and_default_chain():
+    assert os.path.exists(EXE), "build it: make -C thz_image_explorer_amd/host"
+    nx, ny, nt = 8, 8, 1024
+    time = synth.make_time(nt)
+    raw = synth.make_traces(np.arange(nx * ny), nt, subtract_bias=False).reshape(nx, ny, nt)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "cube.bin"), "wb") as f:
+            np.array([nx, ny, nt], np.int32).tofile(f)
+            np.array([0.5, 0.5], np.float32).tofile(f)
+            time.tofile(f)
+            raw.tofile(f)
+        r = subprocess.run([EXE, d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        print(r.stdout)
+        assert r.returncode == 0, r.stdout
+        assert "SELFTEST OK" in r.stdout and "FAIL" not in r.stdout
+        out = np.fromfile(os.path.join(d, "out.bin"), np.float32)
+    nf = nt // 2 + 1
+    npix = nx * ny
+    sizes = [npix * nf * 2, npix * nf, npix * nf, npix * nt, npix, nf, nf, nt]
+    assert out.size == sum(sizes)
+    parts = np.split(out, np.cumsum(sizes)[:-1])
+    fft, amp, ph, data, img, avg_sig, avg_ph, roi = parts
+    # oracle: the same stage walk (bias -> tilt taper -> Time Band Pass -> fft ->
+    # Frequency Band Pass -> ifft -> Time Band Pass -> image)
+    cube = ob.subtract_bias(raw)
+    chain = synth.default_chain(time)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+    assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+    assert np.abs(data.reshape(ref["data"].shape) - ref["data"]).max() / np.abs(ref["data"]).max() < 1e-5
+    assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / ref["img"].max() < 1e-5
+    # K8 means (taken by `ifft` from its input = the band-passed spectra)
+    assert np.abs(avg_sig - ob.pixel_mean(ref["amplitudes"], 1)).max() / scale < 1e-5
+    d = avg_ph - ob.pixel_mean(ref["phases"], 1)
+    assert np.abs(d).max() < 0.2  # a 2*pi flip on one noise bin of one pixel moves the mean by 2*pi/64
+    # K9 ROI mean of the ifft stage's *input* data (math_tools.rs:477: &input.data)
+    pre = cube * chain["w_tilt"]
+    pre, _, _ = ob.td_bandpass(pre, time, float(time[0]), float(time[-1]), 2.0)
+    st = ob.fft_stage(pre, time, 0, 1.0, 7.0)
+    poly = np.array([[1, 1], [5, 1], [6, 4], [3, 6], [1, 4]], np.uint64)
+    assert np.array_equal(roi, ob.average_polygon_roi(st["data"], poly, 1))

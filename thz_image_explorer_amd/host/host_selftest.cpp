@@ -1,0 +1,242 @@
+// host_selftest.cpp — the reference's on-path unit tests re-created against the
+// C++ host mirror (so they read like the originals), plus a default-chain run on
+// a cube handed over by the Python test for comparison with the oracle.
+//   usage: host_selftest <dir>     reads <dir>/cube.bin, writes <dir>/out.bin
+#include "thz_host.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+using namespace thzhost;
+
+static int g_fail = 0;
+#define CHECK(cond, name)                                             \
+    do {                                                              \
+        if (!(cond)) { std::printf("FAIL %s: %s\n", name, #cond); ++g_fail; } \
+    } while (0)
+
+static std::vector<float> linspace(float a, float b, size_t n)
+{
+    std::vector<float> v(n);
+    const float step = n > 1 ? (b - a) / (float)(n - 1) : 0.0f;
+    for (size_t i = 0; i < n; ++i) v[i] = a + step * (float)i;
+    return v;
+}
+
+static ScannedImageFilterData make_input(const std::vector<float> &data, size_t w, size_t h,
+                                         const std::vector<float> &time)
+{
+    ScannedImageFilterData in;
+    in.width = w; in.height = h;
+    in.time = time;
+    in.data.upload(data.data(), data.size());
+    in.has_plan = true;
+    in.frequency.resize(time.size() / 2 + 1);
+    for (size_t i = 0; i < in.frequency.size(); ++i) in.frequency[i] = (float)i / 50.0f;
+    in.phases.resize(w * h * in.nf()); in.phases.zero();
+    in.amplitudes.resize(w * h * in.nf()); in.amplitudes.zero();
+    in.fft.resize(w * h * in.nf() * 2); in.fft.zero();
+    in.img.resize(w * h); in.img.zero();
+    return in;
+}
+
+// math_tools.rs:843-897
+static void test_fft_roundtrip()
+{
+    const size_t n = 128;
+    std::vector<float> data(n);
+    const float pi = 3.14159274f;
+    for (size_t t = 0; t < n; ++t) {
+        const float tt = (float)t / (float)n;
+        data[t] = std::sin(2.0f * pi * 3.0f * tt) + 0.5f * std::cos(2.0f * pi * 7.0f * tt);
+    }
+    ScannedImageFilterData input = make_input(data, 1, 1, linspace(0.0f, 1.0f, n));
+    ConfigContainer config;
+    config.fft_window_type = FftWindowType::AdaptedBlackman;
+    config.fft_window = {0.0f, 0.0f};
+    config.avg_in_fourier_space = false;
+    const ScannedImageFilterData after_fft = math_tools::fft(input, config);
+    const std::vector<float> expected_time = after_fft.data.download();
+    const ScannedImageFilterData after_ifft = math_tools::ifft(after_fft, config);
+    const std::vector<float> got = after_ifft.data.download();
+    bool ok = true;
+    for (size_t t = 0; t < n; ++t) ok = ok && std::fabs(got[t] - expected_time[t]) <= 1e-4f;
+    CHECK(ok, "test_fft_roundtrip");
+    CHECK(after_ifft.avg_signal_fft.size() == n / 2 + 1, "test_fft_roundtrip(avg)");
+    std::printf("PASS? test_fft_roundtrip done\n");
+}
+
+// band_pass_fd.rs:475-567
+static void test_fd_bandpass()
+{
+    const size_t n = 256, k = 9;
+    std::vector<float> data(n);
+    const float pi = 3.14159274f;
+    for (size_t t = 0; t < n; ++t) data[t] = std::sin(2.0f * pi * (float)k * (float)t / (float)n);
+    ScannedImageFilterData input = make_input(data, 1, 1, linspace(0.0f, 1.0f, n));
+    ConfigContainer config;
+    config.fft_window = {0.0f, 0.0f};
+    const ScannedImageFilterData spec = math_tools::fft(input, config);
+    FrequencyDomainBandPass f;
+    f.low = spec.frequency[k - 2];
+    f.high = spec.frequency[k + 2];
+    f.window_width = 0.0;
+    GuiSettingsContainer gui;
+    ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    std::atomic<bool> abort{false};
+    const ScannedImageFilterData out = f.filter(spec, gui, pl, abort);
+    CHECK(out.fft.size() == spec.fft.size() && out.amplitudes.size() == spec.amplitudes.size(), "fd shapes");
+    const std::vector<float> amp = out.amplitudes.download();
+    bool zeros = true;
+    float inside = 0.0f;
+    for (size_t i = 0; i < amp.size(); ++i) {
+        if (i < k - 2 || i > k + 2) zeros = zeros && amp[i] == 0.0f;
+        else inside += amp[i];
+    }
+    CHECK(zeros, "fd exact zeros outside the band");
+    CHECK(inside > 0.0f, "fd energy inside the band");
+    std::printf("PASS? test_fd_bandpass done\n");
+}
+
+// band_pass_td_before_fft.rs:390-443
+static void test_td_bandpass()
+{
+    const size_t n = 256;
+    const std::vector<float> time = linspace(0.0f, 1.0f, n);
+    std::vector<float> data(n);
+    for (size_t t = 0; t < n; ++t) data[t] = std::sin(2.0f * 3.14159274f * 5.0f * time[t]);
+    ScannedImageFilterData input = make_input(data, 1, 1, time);
+    TimeDomainBandPassBeforeFFT f;
+    f.low = 0.25; f.high = 0.55; f.window_width = 0.0;
+    GuiSettingsContainer gui;
+    ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    std::atomic<bool> abort{false};
+    const ScannedImageFilterData out = f.filter(input, gui, pl, abort);
+    const std::vector<float> o = out.data.download();
+    size_t lower = 0, upper = n - 1;
+    for (size_t i = 0; i < n; ++i) if (time[i] >= 0.25f) { lower = i; break; }
+    for (size_t i = 0; i < n; ++i) if (time[i] >= 0.55f) { upper = i; break; }
+    bool zeros = true;
+    float inside = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        if (i < lower || i >= upper) zeros = zeros && o[i] == 0.0f;
+        else inside += std::fabs(o[i]);
+    }
+    CHECK(o.size() == n, "td shape");
+    CHECK(zeros, "td exact zeros outside the window");
+    CHECK(inside > 0.0f, "td energy inside the window");
+    std::printf("PASS? test_td_bandpass done\n");
+}
+
+// tilt_compensation.rs:303-389
+static void test_tilt()
+{
+    const size_t n = 64, impulse = 10;
+    const std::vector<float> time = linspace(0.0f, 0.05f * ((float)n - 1.0f), n);
+    std::vector<float> data(2 * 2 * n, 0.0f);
+    data[(1 * 2 + 1) * n + impulse] = 1.0f;
+    ScannedImageFilterData input = make_input(data, 2, 2, time);
+    input.dx = 1.0f; input.dy = 1.0f;
+    GuiSettingsContainer gui;
+    ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    std::atomic<bool> abort{false};
+    for (double tx : {10.0, 0.0}) {
+        TiltCompensation f;
+        f.tilt_x = tx;
+        const ScannedImageFilterData out = f.filter(input, gui, pl, abort);
+        const size_t steps = thz_host_tilt_plan(time.data(), n, 2, 2, tx, 0.0, 1.0f, 1.0f, nullptr, nullptr);
+        CHECK(out.time.size() == n + 2 * steps, "tilt extended length");
+        CHECK((tx != 0.0) == (steps > 0), "tilt extension only with tilt");
+        const std::vector<float> tr = out.data.download((1 * 2 + 1) * out.nt(), out.nt());
+        size_t peak = 0;
+        for (size_t i = 0; i < tr.size(); ++i) if (tr[i] > tr[peak]) peak = i;
+        CHECK(peak == impulse + steps, "tilt centre-pixel impulse index");
+    }
+    std::printf("PASS? test_tilt done\n");
+}
+
+// deconvolution.rs:1139-1177: 2x2 image -> guard -> shape preserved, data unchanged
+static void test_deconvolution_small()
+{
+    const size_t n = 64;
+    std::vector<float> data(2 * 2 * n, 0.0f);
+    data[5] = 1.0f;
+    ScannedImageFilterData input = make_input(data, 2, 2, linspace(0.0f, 3.15f, n));
+    input.dx = 1.0f; input.dy = 1.0f;
+    GuiSettingsContainer gui;  // empty PSF, like a fresh GuiSettingsContainer::new()
+    ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    std::atomic<bool> abort{false};
+    Deconvolution f;
+    const ScannedImageFilterData out = f.filter(input, gui, pl, abort);
+    CHECK(out.data.size() == input.data.size(), "deconvolution shape");
+    CHECK(out.data.download() == data, "deconvolution guard returns the input");
+    std::printf("PASS? test_deconvolution_small done\n");
+}
+
+static void run_default_chain(const std::string &dir)
+{
+    std::FILE *fi = std::fopen((dir + "/cube.bin").c_str(), "rb");
+    if (!fi) { std::printf("SKIP chain: no cube.bin\n"); return; }
+    int32_t dims[3];
+    float dxy[2];
+    if (std::fread(dims, 4, 3, fi) != 3 || std::fread(dxy, 4, 2, fi) != 2) { std::fclose(fi); ++g_fail; return; }
+    const size_t nx = dims[0], ny = dims[1], nt = dims[2];
+    std::vector<float> time(nt), cube(nx * ny * nt);
+    if (std::fread(time.data(), 4, nt, fi) != nt || std::fread(cube.data(), 4, cube.size(), fi) != cube.size()) {
+        std::fclose(fi); ++g_fail; return;
+    }
+    std::fclose(fi);
+    Pipeline pipe;
+    // order of main.rs:194-247
+    const char *expect[] = {"initial", "scaling", "Tilt Compensation", "Time Band Pass", "fft",
+                            "Frequency Band Pass", "ifft", "Time Band Pass", "Deconvolution"};
+    CHECK(pipe.filter_chain.size() == 9, "chain length");
+    for (size_t i = 0; i < pipe.filter_chain.size() && i < 9; ++i) {
+        const std::string &id = pipe.filter_chain[i];
+        std::string name = id;
+        for (auto &f : FilterRegistry::global().filters)
+            if (f.first == id) name = f.second->config().name;
+        CHECK(name == expect[i], "chain order");
+    }
+    pipe.open(ScannedImageFilterData::from_host_cube(cube.data(), nx, ny, time, dxy[0], dxy[1]));
+    pipe.filter_data[0].rois["roi-1"] = {"pentagon", Polygon{{1, 1}, {5, 1}, {6, 4}, {3, 6}, {1, 4}}};
+    pipe.update_filter(1);  // "Calculate All Filters"
+    const ScannedImageFilterData &spec = pipe.filter_data[pipe.filter_uuid_to_index["ifft"]];
+    const ScannedImageFilterData &last = pipe.filter_data.back();
+    std::FILE *fo = std::fopen((dir + "/out.bin").c_str(), "wb");
+    auto put = [&](const std::vector<float> &v) { std::fwrite(v.data(), 4, v.size(), fo); };
+    put(spec.fft.download());
+    put(spec.amplitudes.download());
+    put(spec.phases.download());
+    put(last.data.download());
+    put(last.img.download());
+    put(spec.avg_signal_fft);
+    put(spec.avg_phase_fft);
+    put(spec.roi_data.at("roi-1").second);
+    std::fclose(fo);
+    CHECK(last.nt() == nt && last.data.size() == cube.size(), "chain output shape");
+    // partial recompute from the fft stage (SetFFTWindow* -> Filter(fft_index), data_thread.rs:813-836)
+    pipe.config.fft_window = {0.5f, 3.0f};
+    pipe.update_filter(pipe.fft_index + 1);
+    CHECK(pipe.filter_data.back().data.size() == cube.size(), "partial recompute shape");
+    std::printf("PASS? default chain done (%zux%zux%zu)\n", nx, ny, nt);
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        test_fft_roundtrip();
+        test_fd_bandpass();
+        test_td_bandpass();
+        test_tilt();
+        test_deconvolution_small();
+        if (argc > 1) run_default_chain(argv[1]);
+    } catch (const std::exception &e) {
+        std::printf("FAIL exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf(g_fail ? "SELFTEST FAILED (%d)\n" : "SELFTEST OK (%d failures)\n", g_fail);
+    return g_fail ? 1 : 0;
+}

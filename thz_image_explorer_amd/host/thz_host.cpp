@@ -1,0 +1,626 @@
+// thz_host.cpp — see thz_host.hpp.  Every stage is a call into libthzgpu.so;
+// nothing here computes on the CPU beyond O(nt) vectors and ROI bookkeeping.
+#include "thz_host.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace thzhost {
+
+static void log_error(const std::string &m) { std::fprintf(stderr, "[thzhost][error] %s\n", m.c_str()); }
+static void log_warn(const std::string &m) { std::fprintf(stderr, "[thzhost][warn] %s\n", m.c_str()); }
+
+// ------------------------------------------------------------------ Engine
+Engine::Engine()
+{
+    const char *dev = std::getenv("THZ_DEVICE");
+    if (thz_create(dev ? std::atoi(dev) : 0, &ctx_) != THZ_OK)
+        throw std::runtime_error("thz_create failed: no HIP device (the engine has no CPU fallback)");
+}
+Engine::~Engine() { thz_destroy(ctx_); }
+Engine &Engine::instance()
+{
+    static Engine e;
+    return e;
+}
+bool Engine::ensure_axis(const std::vector<float> &time)
+{
+    if (time == axis_) return true;
+    if (thz_set_time_axis(ctx_, time.data(), time.size()) != THZ_OK) {
+        log_error(std::string("thz_set_time_axis: ") + thz_last_error(ctx_));
+        return false;
+    }
+    axis_ = time;
+    return true;
+}
+std::string Engine::last_error() const { return thz_last_error(ctx_); }
+
+// ------------------------------------------------------------------ DeviceArray
+DeviceArray::DeviceArray(const DeviceArray &o) { *this = o; }
+DeviceArray &DeviceArray::operator=(const DeviceArray &o)
+{
+    if (this == &o) return *this;
+    resize(o.n_);
+    if (n_) thz_memcpy_d2d(Engine::instance().ctx(), p_, o.p_, n_ * sizeof(float));
+    return *this;
+}
+DeviceArray::~DeviceArray()
+{
+    if (p_) thz_free(Engine::instance().ctx(), p_);
+}
+void DeviceArray::resize(size_t n)
+{
+    if (n == n_) return;
+    if (p_) thz_free(Engine::instance().ctx(), p_);
+    p_ = nullptr;
+    n_ = 0;
+    if (n) {
+        void *q = nullptr;
+        if (thz_malloc(Engine::instance().ctx(), &q, n * sizeof(float)) != THZ_OK)
+            throw std::runtime_error("thz_malloc failed: " + Engine::instance().last_error());
+        p_ = static_cast<float *>(q);
+        n_ = n;
+    }
+}
+void DeviceArray::zero()
+{
+    if (n_) thz_memset(Engine::instance().ctx(), p_, 0, n_ * sizeof(float));
+}
+void DeviceArray::upload(const float *src, size_t n)
+{
+    resize(n);
+    if (n) thz_memcpy_h2d(Engine::instance().ctx(), p_, src, n * sizeof(float));
+}
+std::vector<float> DeviceArray::download() const { return download(0, n_); }
+std::vector<float> DeviceArray::download(size_t offset, size_t n) const
+{
+    std::vector<float> out(n);
+    if (n) thz_memcpy_d2h(Engine::instance().ctx(), out.data(), p_ + offset, n * sizeof(float));
+    return out;
+}
+
+// ------------------------------------------------------------------ container
+ScannedImageFilterData ScannedImageFilterData::from_host_cube(const float *cube, size_t width, size_t height,
+                                                              const std::vector<float> &time, float dx_, float dy_)
+{
+    ScannedImageFilterData s;
+    Engine &e = Engine::instance();
+    s.width = width;
+    s.height = height;
+    s.dx = dx_;
+    s.dy = dy_;
+    s.time = time;
+    s.data.upload(cube, width * height * time.size());
+    s.img.resize(width * height);
+    e.ensure_axis(time);
+    // io.rs:578-596: per-trace bias subtraction, then sum of squares
+    thz_subtract_bias(e.ctx(), s.npix(), s.data.ptr(), s.img.ptr());
+    // io.rs:614-628
+    s.frequency.resize(time.size() / 2 + 1);
+    thz_host_frequency_axis(time.data(), time.size(), s.frequency.data());
+    s.has_plan = true;
+    s.phases.resize(s.npix() * s.nf()); s.phases.zero();
+    s.amplitudes.resize(s.npix() * s.nf()); s.amplitudes.zero();
+    s.fft.resize(s.npix() * s.nf() * 2); s.fft.zero();
+    return s;
+}
+
+// ------------------------------------------------------------------ math_tools
+namespace math_tools {
+
+// math_tools.rs:242-310
+ScannedImageFilterData scaling(const ScannedImageFilterData &input, const ConfigContainer &config)
+{
+    const size_t s = config.scale_factor;
+    if (s <= 1) return input;
+    const size_t nw = input.width / s, nh = input.height / s;
+    if (nw == 0 || nh == 0) return input;
+    ScannedImageFilterData out = input;
+    out.width = nw;
+    out.height = nh;
+    out.scaling = s;
+    if (out.dx) out.dx = *out.dx * (float)s;
+    if (out.dy) out.dy = *out.dy * (float)s;
+    out.pixel_selected[0] /= s;
+    out.pixel_selected[1] /= s;
+    thz_ctx *ctx = Engine::instance().ctx();
+    const size_t nt = input.nt(), nf = input.nf();
+    out.data.resize(nw * nh * nt);
+    out.amplitudes.resize(nw * nh * nf);
+    out.phases.resize(nw * nh * nf);
+    out.fft.resize(nw * nh * nf * 2);
+    thz_scale3d(ctx, input.data.ptr(), input.width, input.height, nt, 1, s, out.data.ptr());
+    thz_scale3d(ctx, input.amplitudes.ptr(), input.width, input.height, nf, 1, s, out.amplitudes.ptr());
+    thz_scale3d(ctx, input.phases.ptr(), input.width, input.height, nf, 1, s, out.phases.ptr());
+    thz_scale3d(ctx, input.fft.ptr(), input.width, input.height, nf, 2, s, out.fft.ptr());
+    return out;
+}
+
+// math_tools.rs:330-398
+ScannedImageFilterData fft(const ScannedImageFilterData &input, const ConfigContainer &config)
+{
+    ScannedImageFilterData output = input;
+    if (!output.has_plan) return output;  // `if let Some(r2c)`
+    Engine &e = Engine::instance();
+    if (!e.ensure_axis(input.time)) return input;
+    std::vector<float> w(input.nt());
+    thz_window_cfg cfg{(int32_t)config.fft_window_type, config.fft_window[0], config.fft_window[1]};
+    thz_host_fft_window(input.time.data(), input.nt(), &cfg, w.data());
+    DeviceArray d_w;
+    d_w.upload(w.data(), w.size());
+    const int rc = thz_fft(e.ctx(), input.npix(), input.data.ptr(), d_w.ptr(), nullptr, output.data.ptr(),
+                           output.fft.ptr(), output.amplitudes.ptr(), output.phases.ptr(), nullptr);
+    if (rc != THZ_OK) {
+        log_error("fft: " + e.last_error());
+        return input;
+    }
+    thz_sync(e.ctx());
+    return output;
+}
+
+static std::vector<float> roi_mean(const DeviceArray &arr, size_t shape0, size_t shape1, size_t len,
+                                   const Polygon &poly, size_t scaling)
+{
+    Engine &e = Engine::instance();
+    std::vector<uint64_t> xy;
+    for (auto &p : poly) { xy.push_back(p.first); xy.push_back(p.second); }
+    void *mask = nullptr;
+    thz_malloc(e.ctx(), &mask, shape0 * shape1);
+    DeviceArray out(len);
+    thz_roi_mask(e.ctx(), xy.data(), poly.size(), scaling, shape0, shape1, static_cast<uint8_t *>(mask));
+    thz_roi_mean(e.ctx(), arr.ptr(), shape0, shape1, len, static_cast<uint8_t *>(mask), out.ptr(), nullptr, 0);
+    thz_free(e.ctx(), mask);
+    return out.download();
+}
+
+// from_polar + C2R + /nt for one spectrum (math_tools.rs:446-468, 499-529)
+static std::vector<float> polar_irfft(const std::vector<float> &amp, const std::vector<float> &phase, size_t nt,
+                                      bool zero_dc_imag)
+{
+    Engine &e = Engine::instance();
+    const size_t nf = amp.size();
+    std::vector<float> spec(2 * nf);
+    for (size_t i = 0; i < nf; ++i) {
+        spec[2 * i] = amp[i] * std::cos(phase[i]);
+        spec[2 * i + 1] = amp[i] * std::sin(phase[i]);
+    }
+    if (zero_dc_imag && nf) spec[1] = 0.0f;
+    DeviceArray d_s, d_o(nt);
+    d_s.upload(spec.data(), spec.size());
+    thz_ifft(e.ctx(), 1, d_s.ptr(), nullptr, d_o.ptr(), nullptr);
+    return d_o.download();
+}
+
+// math_tools.rs:418-571
+ScannedImageFilterData ifft(const ScannedImageFilterData &input, const ConfigContainer &config)
+{
+    ScannedImageFilterData output = input;
+    Engine &e = Engine::instance();
+    if (!e.ensure_axis(input.time)) return input;
+    const size_t nf = input.nf(), nt = input.nt();
+    // :421-440 pixel means (mean over x, then over y)
+    {
+        DeviceArray m(2 * nf);
+        thz_pixel_mean(e.ctx(), input.width, input.height, nf, 2, output.fft.ptr(), m.ptr());
+        const std::vector<float> v = m.download();
+        output.avg_fft.resize(nf);
+        for (size_t i = 0; i < nf; ++i) output.avg_fft[i] = {v[2 * i], v[2 * i + 1]};
+        DeviceArray m1(nf);
+        thz_pixel_mean(e.ctx(), input.width, input.height, nf, 1, output.amplitudes.ptr(), m1.ptr());
+        output.avg_signal_fft = m1.download();
+        thz_pixel_mean(e.ctx(), input.width, input.height, nf, 1, output.phases.ptr(), m1.ptr());
+        output.avg_phase_fft = m1.download();
+    }
+    if (config.avg_in_fourier_space && output.has_plan)
+        output.avg_data = polar_irfft(output.avg_signal_fft, output.avg_phase_fft, nt, false);
+    // :473-543 ROIs
+    for (auto &kv : input.rois) {
+        const std::string &uuid = kv.first;
+        const std::string &name = kv.second.first;
+        if (!kv.second.second) continue;
+        const Polygon &poly = *kv.second.second;
+        if (!config.avg_in_fourier_space)
+            output.roi_data[uuid] = {name, roi_mean(input.data, input.width, input.height, nt, poly, input.scaling)};
+        auto sig = roi_mean(input.amplitudes, input.width, input.height, nf, poly, input.scaling);
+        auto ph = roi_mean(input.phases, input.width, input.height, nf, poly, input.scaling);
+        output.roi_signal_fft[uuid] = {name, sig};
+        output.roi_phase_fft[uuid] = {name, ph};
+        if (config.avg_in_fourier_space && output.has_plan)
+            output.roi_data[uuid] = {name, polar_irfft(sig, ph, nt, true)};
+    }
+    // :545-568 per-pixel C2R and 1/nt
+    if (output.has_plan) {
+        const int rc = thz_ifft(e.ctx(), input.npix(), output.fft.ptr(), nullptr, output.data.ptr(), nullptr);
+        if (rc != THZ_OK) {
+            log_error("ifft: " + e.last_error());
+            return input;
+        }
+        thz_sync(e.ctx());
+    }
+    return output;
+}
+
+}  // namespace math_tools
+
+// ------------------------------------------------------------------ registry
+FilterRegistry &FilterRegistry::global()
+{
+    static FilterRegistry r;
+    return r;
+}
+void FilterRegistry::add(std::unique_ptr<Filter> f)
+{
+    std::lock_guard<std::mutex> g(mu);
+    // the reference draws a random Uuid::new_v4() (filter.rs:319-338); any unique string serves
+    const std::string uuid = "filter-" + std::to_string(filters.size()) + "-" + f->config().name;
+    filters.emplace_back(uuid, std::move(f));
+}
+
+thz_psf PsfArrays::view() const
+{
+    auto sp = [&](int i) {
+        thz_spline s;
+        s.knots = k[i].data(); s.values = v[i].data();
+        s.coeff_a = a[i].data(); s.coeff_b = b[i].data(); s.coeff_c = c[i].data(); s.coeff_d = d[i].data();
+        s.n_knots = k[i].size();
+        return s;
+    };
+    thz_psf p;
+    p.wx_fit = thz_hybrid_fit{wx_a, wx_b, sp(0)};
+    p.wy_fit = thz_hybrid_fit{wy_a, wy_b, sp(1)};
+    p.x0_spline = sp(2);
+    p.y0_spline = sp(3);
+    return p;
+}
+
+static void clear_progress(ProgressLock &p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(p->first);
+    p->second.reset();
+}
+
+// ------------------------------------------------------------------ Tilt Compensation
+FilterConfig TiltCompensation::config() const
+{
+    return {"Tilt Compensation", "Compensate the tilt of the sample along the x and y axis.",
+            FilterDomain::TimeBeforeFFTPrioFirst};
+}
+ScannedImageFilterData TiltCompensation::filter(const ScannedImageFilterData &input, GuiSettingsContainer &,
+                                                ProgressLock &, const std::atomic<bool> &)
+{
+    ScannedImageFilterData output = input;
+    if (!(input.dx && input.dy)) return output;  // tilt_compensation.rs:111
+    if (input.time.empty()) {
+        log_warn("scan time is empty, cannot update voxel plot instances");
+        return output;
+    }
+    Engine &e = Engine::instance();
+    const size_t nt = input.nt(), nx = input.width, ny = input.height;
+    const size_t steps = thz_host_tilt_plan(input.time.data(), nt, nx, ny, tilt_x, tilt_y, *input.dx, *input.dy,
+                                            nullptr, nullptr);
+    const size_t nt2 = nt + 2 * steps;
+    std::vector<float> new_time(nt2), taper(nt);
+    std::vector<int32_t> ins(nx * ny);
+    thz_host_tilt_plan(input.time.data(), nt, nx, ny, tilt_x, tilt_y, *input.dx, *input.dy, new_time.data(), ins.data());
+    thz_host_adapted_blackman(input.time.data(), nt, 0.0f, 7.0f, taper.data());
+    DeviceArray d_taper, d_ins, out(nx * ny * nt2);
+    d_taper.upload(taper.data(), nt);
+    d_ins.upload(reinterpret_cast<const float *>(ins.data()), ins.size());
+    if (thz_tilt_apply(e.ctx(), nx * ny, input.data.ptr(), nt, d_taper.ptr(),
+                       reinterpret_cast<const int32_t *>(d_ins.ptr()), nt2, out.ptr()) != THZ_OK) {
+        log_error("tilt: " + e.last_error());
+        return input;
+    }
+    thz_sync(e.ctx());
+    output.time = new_time;
+    output.frequency.resize(nt2 / 2 + 1);
+    thz_host_frequency_axis(new_time.data(), nt2, output.frequency.data());  // :206-217
+    output.has_plan = true;
+    output.data.swap(out);
+    return output;
+}
+
+// ------------------------------------------------------------------ Time Band Pass
+void TimeDomainBandPassBeforeFFT::reset(const std::vector<float> &time, const std::array<size_t, 3> &)
+{
+    time_axis = time;
+    signal_axis.assign(time.size(), 0.0f);
+    input_signal_axis.assign(time.size(), 0.0f);
+    low = time.empty() ? 0.0 : (double)time.front();   // band_pass_td_before_fft.rs:66-72
+    high = time.empty() ? 0.0 : (double)time.back();
+}
+void TimeDomainBandPassBeforeFFT::show_data(const ScannedImageFilterData &data)
+{
+    if (data.width == 0 || data.height == 0 || data.nt() == 0) return;
+    time_axis = data.time;
+    const auto px = data.pixel_selected;
+    if (px[0] < data.width && px[1] < data.height)
+        signal_axis = data.data.download((px[0] * data.height + px[1]) * data.nt(), data.nt());
+    else
+        signal_axis.assign(data.nt(), 0.0f);
+    input_signal_axis = signal_axis;
+}
+FilterConfig TimeDomainBandPassBeforeFFT::config() const
+{
+    return {"Time Band Pass", "Band-Pass Filter in Time Domain before the FFT.", FilterDomain::TimeBeforeFFT};
+}
+FilterConfig TimeDomainBandPassAfterFFT::config() const
+{
+    return {"Time Band Pass", "Band-Pass Filter in Time Domain after the FFT.", FilterDomain::TimeAfterFFT};
+}
+ScannedImageFilterData TimeDomainBandPassBeforeFFT::filter(const ScannedImageFilterData &input,
+                                                           GuiSettingsContainer &, ProgressLock &progress,
+                                                           const std::atomic<bool> &)
+{
+    ScannedImageFilterData output = input;
+    Engine &e = Engine::instance();
+    std::vector<float> w(input.nt());
+    // clamps self.low / self.high like :137-138
+    thz_host_td_bandpass(input.time.data(), input.nt(), &low, &high, window_width, w.data(), nullptr, nullptr);
+    DeviceArray d_w;
+    d_w.upload(w.data(), w.size());
+    if (!e.ensure_axis(input.time) ||
+        thz_apply_td_window(e.ctx(), input.npix(), input.data.ptr(), d_w.ptr(), output.data.ptr()) != THZ_OK) {
+        log_error("time band pass: " + e.last_error());
+        return input;
+    }
+    thz_sync(e.ctx());
+    clear_progress(progress);
+    return output;
+}
+void TimeDomainBandPassBeforeFFT::copy_static_fields_from(const Filter &o)
+{
+    if (auto *p = dynamic_cast<const TimeDomainBandPassBeforeFFT *>(&o)) {
+        time_axis = p->time_axis;
+        signal_axis = p->signal_axis;
+        input_signal_axis = p->input_signal_axis;
+    }
+}
+
+// ------------------------------------------------------------------ Frequency Band Pass
+void FrequencyDomainBandPass::show_data(const ScannedImageFilterData &data)
+{
+    if (data.width == 0 || data.height == 0 || data.nf() == 0) return;
+    freq_axis = data.frequency;
+    const auto px = data.pixel_selected;
+    if (px[0] < data.width && px[1] < data.height) {
+        const auto s = data.fft.download((px[0] * data.height + px[1]) * data.nf() * 2, data.nf() * 2);
+        signal_axis.resize(data.nf());
+        for (size_t i = 0; i < data.nf(); ++i) signal_axis[i] = std::hypot(s[2 * i], s[2 * i + 1]);
+    } else {
+        signal_axis.assign(data.nf(), 0.0f);
+    }
+}
+FilterConfig FrequencyDomainBandPass::config() const
+{
+    return {"Frequency Band Pass", "Band Pass Filter in Frequency Domain.", FilterDomain::Frequency};
+}
+ScannedImageFilterData FrequencyDomainBandPass::filter(const ScannedImageFilterData &input, GuiSettingsContainer &,
+                                                       ProgressLock &progress, const std::atomic<bool> &)
+{
+    ScannedImageFilterData output = input;
+    Engine &e = Engine::instance();
+    std::vector<float> m(input.nf());
+    thz_host_fd_bandpass(input.frequency.data(), input.nf(), low, high, window_width, m.data(), nullptr, nullptr);
+    DeviceArray d_m;
+    d_m.upload(m.data(), m.size());
+    if (!e.ensure_axis(input.time) ||
+        thz_apply_fd_mask(e.ctx(), input.npix(), output.fft.ptr(), output.amplitudes.ptr(), d_m.ptr()) != THZ_OK) {
+        log_error("frequency band pass: " + e.last_error());
+        return input;
+    }
+    thz_sync(e.ctx());
+    clear_progress(progress);
+    return output;
+}
+void FrequencyDomainBandPass::copy_static_fields_from(const Filter &o)
+{
+    if (auto *p = dynamic_cast<const FrequencyDomainBandPass *>(&o)) {
+        freq_axis = p->freq_axis;
+        signal_axis = p->signal_axis;
+    }
+}
+
+// ------------------------------------------------------------------ Deconvolution
+FilterConfig Deconvolution::config() const
+{
+    return {"Deconvolution",
+            "Frequency-dependent deconvolution for enhanced THz-TDS scans, accounting for beam width variations "
+            "in time traces.",
+            FilterDomain::TimeAfterFFTPrioLast};
+}
+ScannedImageFilterData Deconvolution::filter(const ScannedImageFilterData &input, GuiSettingsContainer &gui,
+                                             ProgressLock &progress, const std::atomic<bool> &abort_flag)
+{
+    if (!input.dx || !input.dy) {  // deconvolution.rs:781
+        log_error("No data loaded, skipping deconvolution.");
+        clear_progress(progress);
+        return input;
+    }
+    Engine &e = Engine::instance();
+    if (!e.ensure_axis(input.time)) return input;
+    ScannedImageFilterData output = input;
+    const thz_psf psf = gui.psf.view();
+    const thz_deconv_cfg cfg{(uint32_t)n_iterations, (uint32_t)n_filters, start_freq, end_freq, win_width};
+    // abort: Arc<AtomicBool> -> plain int the engine polls between batches
+    volatile int abort_now = abort_flag.load() ? 1 : 0;
+    float prog = 0.0f;
+    const int rc = thz_deconvolve(e.ctx(), &psf, &cfg, input.width, input.height, *input.dx, *input.dy,
+                                  input.data.ptr(), output.data.ptr(), output.img.ptr(), nullptr, &abort_now, &prog);
+    clear_progress(progress);
+    if (rc == THZ_SKIPPED) {
+        log_warn("deconvolution skipped by a guard (PSF missing / image too small / PSF too large)");
+        return input;
+    }
+    if (rc != THZ_OK) {
+        log_error("deconvolution: " + e.last_error());
+        return input;
+    }
+    return output;
+}
+
+// ------------------------------------------------------------------ Pipeline
+static bool registered_defaults()
+{
+    static bool once = [] {
+        FilterRegistry::register_filter<TiltCompensation>();
+        FilterRegistry::register_filter<TimeDomainBandPassBeforeFFT>();
+        FilterRegistry::register_filter<FrequencyDomainBandPass>();
+        FilterRegistry::register_filter<TimeDomainBandPassAfterFFT>();
+        FilterRegistry::register_filter<Deconvolution>();
+        return true;
+    }();
+    return once;
+}
+
+Pipeline::Pipeline()
+{
+    registered_defaults();
+    FilterRegistry &reg = FilterRegistry::global();
+    std::lock_guard<std::mutex> g(reg.mu);
+    filter_chain = {"initial"};
+    filters_active["initial"] = true;
+    std::vector<std::string> ordered = {"scaling"};
+    auto collect = [&](FilterDomain d) {
+        for (auto &f : reg.filters)
+            if (f.second->config().domain == d) ordered.push_back(f.first);
+    };
+    collect(FilterDomain::TimeBeforeFFTPrioFirst);
+    collect(FilterDomain::TimeBeforeFFT);
+    fft_index = ordered.size();
+    ordered.push_back("fft");
+    collect(FilterDomain::Frequency);
+    ifft_index = ordered.size();
+    ordered.push_back("ifft");
+    collect(FilterDomain::TimeAfterFFT);
+    collect(FilterDomain::TimeAfterFFTPrioLast);
+    filter_uuid_to_index["initial"] = 0;
+    for (size_t i = 0; i < ordered.size(); ++i) {
+        filter_chain.push_back(ordered[i]);
+        filter_uuid_to_index[ordered[i]] = i + 1;
+    }
+    for (auto &f : reg.filters)  // main.rs:250-261: Deconvolution starts inactive
+        filters_active[f.first] = f.second->config().name.find("Deconvolution") == std::string::npos;
+    filter_data.resize(filter_chain.size());
+}
+
+std::string Pipeline::uuid_of(const std::string &name) const
+{
+    FilterRegistry &reg = FilterRegistry::global();
+    // the two Time Band Pass filters share a name; the description tells them apart
+    for (auto &f : reg.filters)
+        if (f.second->config().name == name || f.second->config().description == name) return f.first;
+    return "";
+}
+
+void Pipeline::open(ScannedImageFilterData scan)
+{
+    filter_data[0] = std::move(scan);
+    reset_filters = true;
+}
+
+// data_thread.rs:1023-1334
+void Pipeline::update_filter(size_t start_idx)
+{
+    FilterRegistry &reg = FilterRegistry::global();
+    if (start_idx < 1) start_idx = 1;
+    if (reset_filters) {  // :1027-1060
+        std::lock_guard<std::mutex> g(reg.mu);
+        for (size_t i = 0; i < filter_chain.size(); ++i) {
+            const size_t input_index = i == 0 ? 0 : filter_uuid_to_index[filter_chain[i - 1]];
+            for (auto &f : reg.filters)
+                if (f.first == filter_chain[i]) {
+                    const auto &d = filter_data[input_index];
+                    f.second->reset(d.time, {d.width, d.height, d.nt()});
+                }
+        }
+    }
+    reset_filters = false;
+    // :1064-1078 clone the filters out of the registry
+    std::vector<std::pair<std::string, std::unique_ptr<Filter>>> cloned;
+    {
+        std::lock_guard<std::mutex> g(reg.mu);
+        for (auto &f : reg.filters) cloned.emplace_back(f.first, f.second->clone_box());
+    }
+    bool run_deconvolution = true;
+    ProgressLock progress = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    for (size_t i = start_idx; i < filter_chain.size(); ++i) {
+        const std::string &id = filter_chain[i];
+        const size_t out_idx = filter_uuid_to_index[id];
+        const size_t in_idx = filter_uuid_to_index[filter_chain[i - 1]];
+        if (filter_data[in_idx].time.empty()) {  // :1099-1105
+            log_warn("Input data for filter " + id + " is empty, skipping filter application");
+            continue;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (id == "scaling") {
+            filter_data[out_idx] = math_tools::scaling(filter_data[in_idx], config);
+        } else if (id == "fft") {
+            filter_data[out_idx] = math_tools::fft(filter_data[in_idx], config);
+        } else if (id == "ifft") {
+            filter_data[out_idx] = math_tools::ifft(filter_data[in_idx], config);
+        } else {
+            for (auto &f : cloned) {
+                if (f.first != id) continue;
+                const bool active = filters_active.count(id) ? filters_active[id] : false;
+                const bool deconvolution = f.second->config().name.find("Deconvolution") != std::string::npos;
+                if (!deconvolution) run_deconvolution = false;  // :1144-1147
+                if (active && !(deconvolution && !run_deconvolution)) {
+                    filter_data[out_idx] = f.second->filter(filter_data[in_idx], gui_settings, progress, abort_flag);
+                    f.second->show_data(filter_data[out_idx]);
+                    filter_computation_time_ms[id] =
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                } else {
+                    filter_data[out_idx] = filter_data[in_idx];
+                }
+            }
+        }
+        // :1194-1227 re-plan when the time axis length changed
+        if (filter_data[in_idx].nt() != filter_data[out_idx].nt()) {
+            auto &o = filter_data[out_idx];
+            const size_t n = o.nt();
+            o.frequency.resize(n / 2 + 1);
+            thz_host_frequency_axis(o.time.data(), n, o.frequency.data());
+            o.has_plan = true;
+            o.phases.resize(o.npix() * o.nf()); o.phases.zero();
+            o.amplitudes.resize(o.npix() * o.nf()); o.amplitudes.zero();
+            o.fft.resize(o.npix() * o.nf() * 2); o.fft.zero();
+        }
+    }
+    // :1242-1308 intensity image of the last slot
+    ScannedImageFilterData &last = filter_data.back();
+    if (!last.time.empty()) {
+        Engine &e = Engine::instance();
+        e.ensure_axis(last.time);
+        if (last.scaling > 1) {
+            DeviceArray small(last.npix());
+            thz_intensity(e.ctx(), last.npix(), last.data.ptr(), small.ptr());
+            const std::vector<float> s = small.download();
+            const size_t W = last.width * last.scaling, H = last.height * last.scaling;
+            std::vector<float> big(W * H, 0.0f);
+            for (size_t x = 0; x < last.width; ++x)
+                for (size_t y = 0; y < last.height; ++y)
+                    for (size_t a = 0; a < last.scaling; ++a)
+                        for (size_t b = 0; b < last.scaling; ++b)
+                            big[(x * last.scaling + a) * H + (y * last.scaling + b)] = s[x * last.height + y];
+            last.img.upload(big.data(), big.size());
+        } else {
+            last.img.resize(last.npix());
+            thz_intensity(e.ctx(), last.npix(), last.data.ptr(), last.img.ptr());
+            thz_sync(e.ctx());
+        }
+    }
+    // :1322-1334 copy the static fields back into the registry
+    {
+        std::lock_guard<std::mutex> g(reg.mu);
+        for (auto &c : cloned)
+            for (auto &f : reg.filters)
+                if (f.first == c.first) f.second->copy_static_fields_from(*c.second);
+    }
+}
+
+}  // namespace thzhost
