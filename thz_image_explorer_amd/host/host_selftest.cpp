@@ -203,6 +203,15 @@ static void run_default_chain(const std::string &dir)
     pipe.open(ScannedImageFilterData::from_host_cube(cube.data(), nx, ny, time, dxy[0], dxy[1]));
     pipe.filter_data[0].rois["roi-1"] = {"pentagon", Polygon{{1, 1}, {5, 1}, {6, 4}, {3, 6}, {1, 4}}};
     pipe.update_filter(1);  // "Calculate All Filters"
+    if (std::getenv("THZ_SELFTEST_VERBOSE")) {
+        for (size_t i = 0; i < pipe.filter_data.size(); ++i) {
+            const auto &d = pipe.filter_data[i];
+            float mx = 0.0f, mf = 0.0f;
+            for (float v : d.data.download()) mx = std::fmax(mx, std::fabs(v));
+            for (float v : d.fft.download()) mf = std::fmax(mf, std::fabs(v));
+            std::printf("stage %zu %-40s nt=%zu max|data|=%g max|fft|=%g\n", i, pipe.filter_chain[i].c_str(), d.nt(), mx, mf);
+        }
+    }
     const ScannedImageFilterData &spec = pipe.filter_data[pipe.filter_uuid_to_index["ifft"]];
     const ScannedImageFilterData &last = pipe.filter_data.back();
     std::FILE *fo = std::fopen((dir + "/out.bin").c_str(), "wb");

@@ -520,6 +520,9 @@ std::string Pipeline::uuid_of(const std::string &name) const
 void Pipeline::open(ScannedImageFilterData scan)
 {
     filter_data[0] = std::move(scan);
+    // data_thread.rs:715-718: "Copy the first entry into all others" — the filters'
+    // reset() below therefore sees the loaded time axis in every slot
+    for (size_t i = 1; i < filter_data.size(); ++i) filter_data[i] = filter_data[0];
     reset_filters = true;
 }
 
