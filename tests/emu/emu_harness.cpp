@@ -69,3 +69,8 @@ int emu_roi_mask(const uint64_t *poly, int n, uint64_t x_min, uint64_t x_max, ui
     return 0;
 }
 }
+
+extern "C" void emu_fast_atan2(const float *y, const float *x, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = thz::fast_atan2f(y[i], x[i]);
+}

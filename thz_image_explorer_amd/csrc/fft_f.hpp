@@ -465,7 +465,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
         if constexpr (AMP_PHASE) {
             float a[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] = sqrtf(fmaf(X[c].re, X[c].re, X[c].im * X[c].im)) * m[c];
+            for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].re, X[c].re, X[c].im * X[c].im)) * m[c];
             store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
         }
         {
@@ -476,7 +476,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
         if constexpr (want_phase) {
             float ph[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ph[c] = atan2f(X[c].im, X[c].re);
+            for (int c = 0; c < 4; ++c) ph[c] = fast_atan2f(X[c].im, X[c].re);
             if (g == 0) first = wave_bcast<0>(ph[0]);
             float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;
@@ -485,8 +485,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float d = ph[c] - (c == 0 ? prev : ph[c - 1]);
-                if (d > kPi) d -= kTwoPi;
-                else if (d < -kPi) d += kTwoPi;
+                d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);  // numpy_unwrap's if / else if
                 if (g == 0 && c == 0 && lane == 0) d = 0.0f;
                 run += d;
                 s[c] = run;
@@ -513,10 +512,9 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
         A.fft_out[p * nf + N] = c32{xr * mN, 0.0f};
         if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = fabsf(xr) * mN;
         if constexpr (want_phase) {
-            const float phn = atan2f(0.0f, xr);
+            const float phn = fast_atan2f(0.0f, xr);
             float d = phn - last_raw;
-            if (d > kPi) d -= kTwoPi;
-            else if (d < -kPi) d += kTwoPi;
+            d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);
             A.ph_out[p * nf + N] = last_unwrapped + d;
         }
     }

@@ -104,6 +104,40 @@ __device__ __forceinline__ int launder_v(int x)
 
 #endif  // !THZ_EMU
 
+// ---- lean single-precision elementary functions for the spectrum epilogue.
+// OCML's atan2f/sqrtf are IEEE-careful (denormal scaling, inf/nan lattice:
+// ~60 and ~12 instructions); the epilogue evaluates one of each per bin, which
+// made it cost more VALU issue than the transform itself.
+#ifdef THZ_EMU
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // 1 ulp
+#endif
+
+// atan2f to ~2e-7 rad: octant reduction to a = min/max in [0,1], the Cephes atanf
+// second reduction t = (a-1)/(a+1) for a > tan(pi/8), degree-4 polynomial in t^2.
+// atan2(0, 0) = 0 (num_complex::arg's atan2 gives 0 or pi depending on the
+// sign of zero; bins that are exactly zero carry no phase information).
+__device__ __forceinline__ float fast_atan2f(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * fast_rcp(mx);
+    if (!(mx > 0.0f)) a = 0.0f;  // 0/0
+    const bool hi = a > 0.41421356237309503f;
+    const float t = hi ? (a - 1.0f) * fast_rcp(a + 1.0f) : a;
+    const float z = t * t;
+    float r = fmaf(fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z,
+                        -3.33329491539e-1f) * z,
+                   t, t);
+    r += hi ? 0.78539816339744831f : 0.0f;
+    r = (ay > ax) ? 1.57079632679489662f - r : r;
+    r = (x < 0.0f) ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+}
+
 struct alignas(8) c32 {
     float re, im;
 };
