@@ -112,6 +112,14 @@ __device__ __forceinline__ void dftR(c32 (&v)[R])
     else dft16(v);
 }
 
+// Natural-order layout of the spectrum / result in the wave's LDS slice: element
+// k sits at nat(k) = k ^ ((k >> 5) & 3).  The XOR only permutes elements inside
+// aligned groups of four, and makes every access pattern of the epilogues
+// (stride-4 and stride-2 element reads, ascending or mirrored) hit 32 distinct
+// 8-byte slots per 32 lanes; index N (the copy of Z[0] / the Nyquist bin) is a
+// fixed point.
+__device__ __forceinline__ int nat(int k) { return k ^ ((k >> 5) & 3); }
+
 // 16-byte LDS accesses (ds_read_b128 / ds_write_b128): index must be even
 __device__ __forceinline__ c32x2 ld2(const c32 *p) { return *reinterpret_cast<const c32x2 *>(p); }
 __device__ __forceinline__ void st2(c32 *p, c32 a, c32 b) { *reinterpret_cast<c32x2 *>(p) = c32x2{a, b}; }
@@ -285,12 +293,18 @@ __device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAd
         THZ_SCHED_FENCE();
     }
     wave_sync();
-    const int nb = launder_v(lane);
+    // k = lane + off, off = 64*c3 + R1*R2*k3 (a multiple of 64):
+    // (k >> 5) & 3 = ((lane >> 5) + (off >> 5)) & 3, and (off >> 5) & 3 is 0 or 2
+    const int nb0 = launder_v(lane ^ ((lane >> 5) & 3));
+    const int nb1 = launder_v(lane ^ (((lane >> 5) + 2) & 3));
 #pragma unroll
     for (int c3 = 0; c3 < C3; ++c3) {
         dftR<R3>(d[c3]);
 #pragma unroll
-        for (int k3 = 0; k3 < R3; ++k3) buf[nb + (kWave * c3 + R1 * R2 * k3)] = d[c3][k3];
+        for (int k3 = 0; k3 < R3; ++k3) {
+            const int off = kWave * c3 + R1 * R2 * k3;
+            buf[(((off >> 5) & 2) ? nb1 : nb0) + off] = d[c3][k3];  // = nat(lane + off)
+        }
         THZ_SCHED_FENCE();
     }
     if (lane == 0) buf[P::N] = d[0][0];  // Z[N] := Z[0], so that Z[N-k] needs no wrap at k = 0
@@ -421,14 +435,23 @@ __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane
     }
 }
 
-// Spectrum epilogue in the store layout: lane owns bins k = 256 g + 4 lane + c.
-// buf holds Z[0..N) in natural order.
+// Spectrum epilogue.  buf holds Z[0..N] in the nat() layout; on return it holds
+// the (unmasked) spectrum X[0..N] in the same layout.
+//   groups g <  NG/2: the lane owns bins k = 256 g + 4 lane + c AND their mirrors
+//                     N - k: one R2C split per pair gives X[k] and X[N-k], both
+//                     written back in place (each Z element is read exactly once);
+//                     the low bins are finished here (|X|, arg, mask, stores, scan)
+//   lane 0          : X[N/2] = conj(Z[N/2])
+//   groups g >= NG/2: bins k = 256 g + 4 lane + c are read back as X and finished
+//   bin N           : lane 0, after the last group
+// so the unwrap scan always runs over ascending bins.
 template <class P, bool AMP_PHASE>
-__device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *__restrict__ w2n,
+__device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restrict__ w2n,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane)
 {
     constexpr int N = P::N, NG = P::NG;
+    static_assert(NG % 2 == 0, "pair ownership splits the groups in halves");
     const int nf = N + 1;
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
     constexpr bool want_phase = AMP_PHASE;
@@ -439,23 +462,41 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
     float prev_tail = 0.0f;   // raw phase of the last bin of the previous group
     float first = 0.0f;       // raw phase of bin 0
     float last_unwrapped = 0.0f, last_raw = 0.0f;
-    c32 x_nyq = c32{0.0f, 0.0f};
-    const int kb = launder_v(4 * lane);           // first bin of this lane in group 0
-    const int rb = launder_v(N - 3 - 4 * lane);   // index of Z[N - (kb + 3)]
+    // nat(256 g + 4 lane + c) = 256 g + fb[c];  nat(N - 256 g - 4 lane - c) = mb[c] - 256 g
+    int fb[4], mb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        fb[c] = launder_v(nat(4 * lane + c));
+        mb[c] = launder_v(nat(N - 4 * lane - c));
+    }
+    const int kb = launder_v(4 * lane);
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         const int k0 = 256 * g + kb;
-        const c32 wg = w2n[256 * g];  // wave-uniform
-        const c32 *zf = buf + k0;            // Z[k0 + c]      = zf[c]
-        const c32 *zr = buf + (rb - 256 * g);  // Z[N - (k0 + c)] = zr[3 - c]
+        c32 *zf = buf + 256 * g;
         c32 X[4];
+        if (g < NG / 2) {
+            c32 *zm = buf - 256 * g;
+            const c32 wg = w2n[256 * g];  // wave-uniform
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const c32 a = zf[c], b = zr[3 - c];
-            c32 xk, xn;
-            r2c_pair(a, b, g == 0 ? wl[c] : cmul(wl[c], wg), xk, xn);
-            X[c] = xk;
-            if (g == 0 && c == 0) x_nyq = xn;  // lane 0: conj(X[N]) = X[N] (real)
+            for (int c = 0; c < 4; ++c) {
+                const c32 a = zf[fb[c]], b = zm[mb[c]];
+                c32 xk, xnc;
+                r2c_pair(a, b, g == 0 ? wl[c] : cmul(wl[c], wg), xk, xnc);
+                X[c] = xk;
+                zf[fb[c]] = xk;          // X[k]
+                zm[mb[c]] = cconj(xnc);  // X[N-k]  (k = 0: buf[N] = X[N], and X[0] over Z[0])
+            }
+            if (g == NG / 2 - 1) {
+                // the one bin without a partner: X[N/2] = conj(Z[N/2]); every lane has
+                // finished its reads of this group before lane 0 rewrites the slot
+                wave_sync();
+                if (lane == 0) buf[nat(N / 2)] = cconj(buf[nat(N / 2)]);
+                wave_sync();
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) X[c] = zf[fb[c]];
         }
         float m[4];
         {
@@ -480,7 +521,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
             if (g == 0) first = wave_bcast<0>(ph[0]);
             float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;
-            float s[4];
+            float s_[4];
             float run = 0.0f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -488,14 +529,14 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
                 d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);  // numpy_unwrap's if / else if
                 if (g == 0 && c == 0 && lane == 0) d = 0.0f;
                 run += d;
-                s[c] = run;
+                s_[c] = run;
             }
             const float incl = wave_scan_add(run);
             const float excl = wave_shr1(incl);
             const float base = carry + excl;
             float y[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = first + (base + s[c]);
+            for (int c = 0; c < 4; ++c) y[c] = first + (base + s_[c]);
             store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
             carry += wave_bcast<kWave - 1>(incl);
             prev_tail = wave_bcast<kWave - 1>(ph[3]);
@@ -508,7 +549,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
     // Nyquist bin k = N (real): lane 0
     if (lane == 0) {
         const float mN = mask[N];
-        const float xr = x_nyq.re;
+        const float xr = buf[N].re;
         A.fft_out[p * nf + N] = c32{xr * mN, 0.0f};
         if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = fabsf(xr) * mN;
         if constexpr (want_phase) {
@@ -520,26 +561,34 @@ __device__ __forceinline__ void f_spectrum_epilogue(const c32 *buf, const c32 *_
     }
 }
 
-// Builds the (swapped) input of the inverse core in the core layout
-// r[c][j1] <- swap(Z'[n]), n = M1 j1 + C1 lane + c.
-//   FROM_Z: buf holds the forward transform Z (fused pipeline); X is derived
-//           on the fly and masked.
-//   else  : buf holds the spectrum X[0..N) itself and x_n = X[N].re.
-template <class P, bool FROM_Z>
+// Builds the (swapped) input of the inverse core in the core layout,
+// r[c][j1] <- swap(Z'[n]), n = M1 j1 + C1 lane + c, from the spectrum X[0..N]
+// held in buf in the nat() layout (X[N] real at buf[N]).  MASKED: multiply by
+// the band-pass mask on the way (fused chain; the stored copy is unmasked so
+// that the phases of the whole spectrum could be taken).
+template <class P, bool MASKED>
 __device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__restrict__ w2n,
-                                                const float *__restrict__ mask, float x_n, int lane,
+                                                const float *__restrict__ mask, int lane,
                                                 c32 (&r)[P::C1][P::R1])
 {
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
     c32 wl[C1];
 #pragma unroll
     for (int c = 0; c < C1; ++c) wl[c] = w2n[C1 * lane + c];
-    // n = M1 j1 + C1 lane + c: forward index fb + (M1 j1 + c); the mirrored index
-    // N - n is written as rbase + (TOP - (M1 j1 + c)) so that it, too, is a base
-    // plus a non-negative immediate
+    // n = M1 j1 + C1 lane + c and its mirror N - n; M1 is a multiple of 32*4 only for
+    // C1 = 2 (M1 = 128), so (n >> 5) & 3 is lane-constant there; for C1 = 1 (M1 = 64)
+    // it alternates with j1 & 1 -> two base variants cover both plans.
+    int fbase[2][C1], mbase[2][C1];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
+            mbase[v][c] = launder_v(nat(N - M1 * v - C1 * lane - c) + M1 * v);
+        }
     constexpr int TOP = M1 * (R1 - 1) + C1 - 1;
-    const int fb = launder_v(C1 * lane);
-    const int rbase = launder_v(N - TOP - C1 * lane);
+    const int mk_f = launder_v(C1 * lane);                 // mask[n]     = mask[mk_f + M1 j1 + c]
+    const int mk_r = launder_v(N - TOP - C1 * lane);       // mask[N - n] = mask[mk_r + TOP - (M1 j1 + c)]
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
         const c32 wg = w2n[M1 * j1];  // wave-uniform
@@ -547,26 +596,20 @@ __device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__res
         for (int c = 0; c < C1; ++c) {
             const int off = M1 * j1 + c;
             const c32 w = j1 == 0 ? wl[c] : cmul(wl[c], wg);
-            c32 xk, xnc;  // X[n], conj(X[N-n])
-            if constexpr (FROM_Z) {
-                r2c_pair(buf[fb + off], buf[rbase + (TOP - off)], w, xk, xnc);
-                const float mk = mask[fb + off], mn = mask[rbase + (TOP - off)];
+            c32 xk = buf[fbase[j1 & 1][c] + M1 * j1];
+            c32 xnc = cconj(buf[mbase[j1 & 1][c] - M1 * j1]);
+            if (off == 0) {
+                // n == 0 only in lane 0: X[0] and X[N] are real (realfft ignores /
+                // rejects their imaginary parts, SURVEY a'-4)
+                if (lane == 0) {
+                    xk.im = 0.0f;
+                    xnc.im = 0.0f;
+                }
+            }
+            if constexpr (MASKED) {
+                const float mk = mask[mk_f + off], mn = mask[mk_r + (TOP - off)];
                 xk = c32{xk.re * mk, xk.im * mk};
                 xnc = c32{xnc.re * mn, xnc.im * mn};
-            } else {
-                xk = buf[fb + off];
-                if (off == 0) {
-                    // n == 0 only in lane 0; elsewhere X[N - n] is a regular bin
-                    const c32 mirror = buf[(rbase + TOP) & (N - 1)];
-                    if (lane == 0) {
-                        xk.im = 0.0f;  // realfft ignores / rejects these imaginary parts (a'-4)
-                        xnc = c32{x_n, 0.0f};
-                    } else {
-                        xnc = cconj(mirror);
-                    }
-                } else {
-                    xnc = cconj(buf[rbase + (TOP - off)]);
-                }
             }
             const c32 z = c2r_elem(xk, xnc, w);
             r[c][j1] = c32{z.im, z.re};
@@ -575,7 +618,6 @@ __device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__res
     }
 }
 
-// Final stage of the inverse: buf holds the swapped result R in natural order.
 // Window block bits: bit j set <=> samples [j*NT/R1, (j+1)*NT/R1) of a time
 // multiplier hold a value != 1.  Each block scans the (L2-resident) vector once
 // in its prologue.  The usual multipliers are edge tapers (the reference's
@@ -605,17 +647,24 @@ __device__ __forceinline__ void f_time_epilogue(const c32 *buf, size_t p, const 
     constexpr int NT = P::NT, R1 = P::R1, C1 = P::C1;
     const float fnt = (float)NT;
     const float *post_w = launder_uniform(A.post_win);
-    const int ob = launder_v(C1 * lane);
+    // n = C1*(64 j + lane) + c: for C1 = 2 the pair (2u, 2u+1), u = 64 j + lane, is one
+    // 16-byte unit also under nat(): unit (2u ^ (s & 2)), elements swapped when s & 1,
+    // s = (lane >> 4) & 3.  For C1 = 1 s = ((lane >> 5) + 2 j) & 3: two variants.
+    const int s2 = (lane >> 4) & 3;
+    const int ob2 = launder_v((2 * lane) ^ (s2 & 2));
+    const bool swap2 = (s2 & 1) != 0;
+    const int ob1a = launder_v(nat(lane)), ob1b = launder_v(nat(kWave + lane) - kWave);
     float acc = 0.0f;
 #pragma unroll
     for (int j = 0; j < R1; ++j) {
         float v[2 * C1];
         if constexpr (C1 == 2) {
-            const c32x2 rr = ld2(buf + ob + 2 * kWave * j);
-            v[0] = rr.a.im / fnt; v[1] = rr.a.re / fnt;
-            v[2] = rr.b.im / fnt; v[3] = rr.b.re / fnt;
+            const c32x2 rr = ld2(buf + ob2 + 2 * kWave * j);
+            const c32 e0 = swap2 ? rr.b : rr.a, e1 = swap2 ? rr.a : rr.b;
+            v[0] = e0.im / fnt; v[1] = e0.re / fnt;
+            v[2] = e1.im / fnt; v[3] = e1.re / fnt;
         } else {
-            const c32 rr = buf[ob + kWave * j];
+            const c32 rr = buf[((j & 1) ? ob1b : ob1a) + kWave * j];
             v[0] = rr.im / fnt;
             v[1] = rr.re / fnt;
         }
@@ -733,7 +782,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             f_core_pass23<P>(buf, t2, ad, lane);
             f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform(T.w2n), mask_l, p, A, lane);
             if constexpr (MODE == kPipe) {
-                f_inverse_input<P, true>(buf, launder_uniform(T.w2n), mask_l, 0.0f, lane, r);
+                f_inverse_input<P, true>(buf, launder_uniform(T.w2n), mask_l, lane, r);
                 wave_sync();  // every lane has read Z before the core overwrites buf
                 f_core_pass1<P>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
@@ -745,20 +794,25 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 wave_sync();
             }
         } else {
-            // prefetched spectrum -> LDS in natural order (X[N] is real and travels in a register)
-            const float x_n = x_nyq_next;
+            // prefetched spectrum -> LDS in the nat() layout, X[N] at buf[N]
             {
-                const int sb = launder_v(C1 * lane);
+                const int s2 = (lane >> 4) & 3;
+                const int sb2 = launder_v((2 * lane) ^ (s2 & 2));
+                const bool swap2 = (s2 & 1) != 0;
+                const int sb1a = launder_v(nat(lane)), sb1b = launder_v(nat(kWave + lane) - kWave);
 #pragma unroll
                 for (int j = 0; j < R1; ++j) {
-                    if constexpr (C1 == 2)
-                        st2(buf + sb + 2 * kWave * j, c32{raw[j][0], raw[j][1]}, c32{raw[j][2], raw[j][3]});
-                    else
-                        buf[sb + kWave * j] = c32{raw[j][0], raw[j][1]};
+                    if constexpr (C1 == 2) {
+                        const c32 e0 = c32{raw[j][0], raw[j][1]}, e1 = c32{raw[j][2], raw[j][3]};
+                        st2(buf + sb2 + 2 * kWave * j, swap2 ? e1 : e0, swap2 ? e0 : e1);
+                    } else {
+                        buf[((j & 1) ? sb1b : sb1a) + kWave * j] = c32{raw[j][0], raw[j][1]};
+                    }
                 }
+                if (lane == 0) buf[N] = c32{x_nyq_next, 0.0f};
             }
             wave_sync();
-            f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, x_n, lane, r);
+            f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, lane, r);
             wave_sync();
             f_core_pass1<P>(r, buf, t1, ad, lane);
             if (p + stride < A.npix) {
