@@ -393,11 +393,23 @@ int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float 
     }
     // two-level: row groups x column tiles with 4 rows of loads in flight per
     // thread, then one small pass over the partial rows
-    const size_t max_groups = 1024;
-    if (int rc = ensure_ws(ctx, max_groups * L * sizeof(float))) return rc;
+    const size_t max_groups = 2048, mid_groups = 32;
+    if (int rc = ensure_ws(ctx, (max_groups + mid_groups) * L * sizeof(float))) return rc;
     float *part = reinterpret_cast<float *>(ctx->ws);
-    const size_t groups = launch_colsum_partial(ctx->stream, d_arr, npix, L, part, max_groups);
-    launch_sum_axis0(ctx->stream, part, groups, L, 0.0f, d_out);
+    float *part2 = part + max_groups * L;
+    size_t groups = launch_colsum_partial(ctx->stream, d_arr, npix, L, part, max_groups);
+    if (groups == 0) {  // very long rows: plain strided sum
+        launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
+        return check_launch(ctx);
+    }
+    // the last level is one thread per column walking the partial rows one by one:
+    // keep it short (a 2048-row walk is 2048 dependent loads)
+    const float *src = part;
+    if (groups > 4 * mid_groups) {
+        groups = launch_colsum_partial(ctx->stream, part, groups, L, part2, mid_groups);
+        src = part2;
+    }
+    launch_sum_axis0(ctx->stream, src, groups, L, 0.0f, d_out);
     return check_launch(ctx);
 }
 

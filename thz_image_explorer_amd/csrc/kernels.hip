@@ -502,47 +502,73 @@ __global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr
 }
 
 // Column sums with memory-level parallelism (pixel-mean partials of big cubes):
-// block = (column tile of 1024 floats) x (row group); every thread keeps 4 rows of
-// 16-byte loads in flight.  Rows are only 4-byte aligned (L = 2*nf or nf).
+// one block per row group; thread t owns the 16-byte column chunks t, t+256, ...
+// of every row (a full row is read by consecutive chunk-iterations, 4 KiB each)
+// and keeps U rows x KC chunks of loads in flight.  Rows are only 4-byte aligned
+// (L = 2*nf or nf); the ragged last chunk (L % 4 floats) is summed by thread 0.
+template <int KC>
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ arr,
-                                                        size_t nrows, size_t L, size_t ntiles,
+                                                        size_t nrows, size_t L,
                                                         size_t rows_per_group,
                                                         float *__restrict__ partial)
 {
-    const size_t tile = blockIdx.x % ntiles, rg = blockIdx.x / ntiles;
-    const size_t col0 = tile * 1024 + (size_t)threadIdx.x * 4;
-    const size_t r0 = rg * rows_per_group;
-    size_t r1 = r0 + rows_per_group;
-    if (r1 > nrows) r1 = nrows;
-    float acc[4][4];
+    constexpr int U = 2;
+    // rows are dealt round-robin to the blocks (row = rg + G*i): at any moment the
+    // chip streams one contiguous band of the array, like a linear copy does
+    const size_t rg = blockIdx.x, G = gridDim.x;
+    (void)rows_per_group;
+    const size_t nfull = L / 4;  // complete 16-byte chunks per row
+    const size_t t = threadIdx.x;
+    float acc[KC][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int k = 0; k < KC; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[u][i] = 0.0f;
-    if (col0 + 3 < L) {
-        size_t r = r0;
-        for (; r + 4 <= r1; r += 4) {
+        for (int i = 0; i < 4; ++i) acc[k][i] = 0.0f;
+    size_t r = rg;
+    for (; r + (U - 1) * G < nrows; r += U * G) {
+        float v[U][KC][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const size_t ch = t + 256 * (size_t)k;
+                if (ch < nfull) load_f4(arr + (r + u * G) * L + 4 * ch, v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3]);
+                else v[u][k][0] = v[u][k][1] = v[u][k][2] = v[u][k][3] = 0.0f;
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[k][i] += v[u][k][i];
+    }
+    for (; r < nrows; r += G)
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const size_t ch = t + 256 * (size_t)k;
+            if (ch < nfull) {
                 float a, b, c, d;
-                load_f4(arr + (r + u) * L + col0, a, b, c, d);
-                acc[u][0] += a; acc[u][1] += b; acc[u][2] += c; acc[u][3] += d;
+                load_f4(arr + r * L + 4 * ch, a, b, c, d);
+                acc[k][0] += a; acc[k][1] += b; acc[k][2] += c; acc[k][3] += d;
             }
         }
-        for (; r < r1; ++r) {
-            float a, b, c, d;
-            load_f4(arr + r * L + col0, a, b, c, d);
-            acc[0][0] += a; acc[0][1] += b; acc[0][2] += c; acc[0][3] += d;
-        }
-    } else {
-        for (size_t r = r0; r < r1; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (col0 + i < L) acc[0][i] += arr[r * L + col0 + i];
+    for (int k = 0; k < KC; ++k) {
+        const size_t ch = t + 256 * (size_t)k;
+        if (ch < nfull)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) partial[rg * L + 4 * ch + i] = acc[k][i];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (col0 + i < L) partial[rg * L + col0 + i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+    // ragged tail columns: lanes of wave 0 split the rows, then a wave reduction
+    const size_t tail0 = nfull * 4;
+    if (tail0 < L && t < kWave) {
+        for (size_t c = tail0; c < L; ++c) {
+            float s = 0.0f;
+            for (size_t rr = rg + G * t; rr < nrows; rr += G * kWave) s += arr[rr * L + c];
+            s = wave_reduce_add(s);
+            if (t == 0) partial[rg * L + c] = s;
+        }
+    }
 }
 
 // ROI mask, bit-exact u64 restatement of math_tools.rs:574-591, 604-652
@@ -1120,19 +1146,24 @@ void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner,
     THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out);
 }
 
-// returns the number of partial rows written to `partial` (each L floats)
+// returns the number of partial rows written to `partial` (each L floats); 0 if L is
+// too wide for the kernel (caller falls back)
 size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,
                              float *partial, size_t max_groups)
 {
-    const size_t ntiles = (L + 1023) / 1024;
-    size_t groups = ((size_t)kNumCU * 8 + ntiles - 1) / ntiles;
+    const size_t chunks = (L / 4 + 255) / 256;  // 16-byte chunks per thread
+    if (chunks > 8) return 0;
+    size_t groups = (size_t)kNumCU * 8;
     if (groups > max_groups) groups = max_groups;
     if (groups > nrows) groups = nrows;
     if (groups < 1) groups = 1;
     const size_t rows_per_group = (nrows + groups - 1) / groups;
     groups = (nrows + rows_per_group - 1) / rows_per_group;
-    THZ_LAUNCH(k_colsum_partial, (unsigned)(ntiles * groups), 256, 0, st, arr, nrows, L, ntiles,
-               rows_per_group, partial);
+    if (chunks <= 1) THZ_LAUNCH((k_colsum_partial<1>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
+    else if (chunks <= 2) THZ_LAUNCH((k_colsum_partial<2>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
+    else if (chunks <= 3) THZ_LAUNCH((k_colsum_partial<3>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
+    else if (chunks <= 5) THZ_LAUNCH((k_colsum_partial<5>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
+    else THZ_LAUNCH((k_colsum_partial<8>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
     return groups;
 }
 
