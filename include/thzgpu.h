@@ -292,6 +292,11 @@ typedef struct thz_deconv_cfg {
     uint32_t n_iterations;
     uint32_t n_filters;
     float start_freq, end_freq, win_width;
+    /* Band-parallel execution across GPUs: this call only sums
+     * bands [band_begin, band_end) of the n_filters-band bank; 0, 0 = all bands.
+     * The per-rank outputs add up to the full result (all-reduce them); the
+     * iteration schedule still uses the beam widths of the whole bank. */
+    uint32_t band_begin, band_end;
 } thz_deconv_cfg;
 
 /* host pieces, exported for tests and for hosts that want to show them:

@@ -103,3 +103,27 @@ def test_unit_gain_bank_reconstructs_input(engine):
         outs.append(d_out.download((nx, ny, nt), np.float32))
         d_in.free(); d_out.free()
     assert np.abs(outs[1] - 4.0 * outs[0]).max() / np.abs(outs[1]).max() < 1e-5
+
+
+def test_band_parallel_partials_add_up(engine):
+    """config 4 / SURVEY §8e: bands split over ranks, outputs all-reduced.  Two
+    band subsets computed one after the other must add up to the full result."""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nx = ny = 32
+    nt = 256
+    time, cube = _bar_target_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    d_in = engine.to_device(cube)
+    outs = {}
+    for name, (b0, b1) in {"all": (0, 0), "lo": (0, 3), "hi": (3, 6)}.items():
+        cfg = pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5, b0, b1)
+        d_out = engine.empty((nx * ny, nt))
+        assert engine.deconvolve(psf, cfg, nx, ny, 0.5, 0.5, d_in, d_out) == 0
+        outs[name] = d_out.download((nx, ny, nt), np.float32)
+        d_out.free()
+    d_in.free()
+    s = outs["lo"] + outs["hi"]
+    assert np.abs(s - outs["all"]).max() / np.abs(outs["all"]).max() < 1e-5
+    with pytest.raises(pkg.ThzError):
+        engine.deconvolve(psf, pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5, 4, 2), nx, ny, 0.5, 0.5, 0, 0)

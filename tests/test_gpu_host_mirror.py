@@ -34,6 +34,7 @@ def test_host_mirror_selftest_and_default_chain():
         assert r.returncode == 0, r.stdout
         assert "SELFTEST OK" in r.stdout and "FAIL" not in r.stdout
         out = np.fromfile(os.path.join(d, "out.bin"), np.float32)
+        out2 = np.fromfile(os.path.join(d, "out2.bin"), np.float32)
     nf = nt // 2 + 1
     npix = nx * ny
     sizes = [npix * nf * 2, npix * nf, npix * nf, npix * nt, npix, nf, nf, nt]
@@ -60,3 +61,20 @@ def test_host_mirror_selftest_and_default_chain():
     st = ob.fft_stage(pre, time, 0, 1.0, 7.0)
     poly = np.array([[1, 1], [5, 1], [6, 4], [3, 6], [1, 4]], np.uint64)
     assert np.array_equal(roi, ob.average_polygon_roi(st["data"], poly, 1))
+
+    # ---- second run of the self-test: scale_factor = 2, avg_in_fourier_space = true
+    sx, sy = nx // 2, ny // 2
+    sizes2 = [sx * sy * nt, nx * ny, nt, nf, nt]
+    assert out2.size == sum(sizes2)
+    data2, img2, avg_data2, avg_sig2, roi2 = np.split(out2, np.cumsum(sizes2)[:-1])
+    small = ob.scale3d(cube, 2)  # math_tools::scaling (block mean, :273-301)
+    ref2 = ob.run_pipeline(small, time, chain)
+    assert np.abs(data2.reshape(ref2["data"].shape) - ref2["data"]).max() / np.abs(ref2["data"]).max() < 1e-5
+    # data_thread.rs:1243-1285: image of the scaled data, replicated s x s
+    big = np.repeat(np.repeat(ref2["img"], 2, axis=0), 2, axis=1)
+    assert np.abs(img2.reshape(nx, ny) - big).max() / big.max() < 1e-5
+    # math_tools.rs:442-470: avg_data = C2R(from_polar(mean |X|, mean phase)) / nt
+    m_amp = ob.pixel_mean(ref2["amplitudes"], 1)
+    assert np.abs(avg_sig2 - m_amp).max() / np.abs(ref2["fft"]).max() < 1e-5
+    assert np.isfinite(avg_data2).all() and np.abs(avg_data2).max() > 0
+    assert np.isfinite(roi2).all() and roi2.size == nt

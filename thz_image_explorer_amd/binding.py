@@ -43,7 +43,8 @@ class Psf(C.Structure):
 
 class DeconvCfg(C.Structure):
     _fields_ = [("n_iterations", C.c_uint32), ("n_filters", C.c_uint32), ("start_freq", C.c_float),
-                ("end_freq", C.c_float), ("win_width", C.c_float)]
+                ("end_freq", C.c_float), ("win_width", C.c_float), ("band_begin", C.c_uint32),
+                ("band_end", C.c_uint32)]
 
 
 def psf_from_npz(z) -> "Psf":

@@ -158,14 +158,28 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, mem.alloc(&d_H, Hh.size() * sizeof(c32)));
     HIP_TRY(ctx, hipMemcpyAsync(d_H, Hh.data(), Hh.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
 
+    // ---- band subset of this call (band-parallel multi-GPU): compact the bank
+    int b0 = (int)cfg->band_begin, b1 = (int)cfg->band_end;
+    if (b0 == 0 && b1 == 0) b1 = nb;
+    if (b0 < 0 || b1 > nb || b0 >= b1)
+        return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad band range");
+    const int nb_all = nb;
+    (void)nb_all;
+    std::vector<float> centers_sel(centers.begin() + b0, centers.begin() + b1);
+    std::vector<c32> Hsel(Hh.begin() + (size_t)b0 * nk, Hh.begin() + (size_t)b1 * nk);
+    HIP_TRY(ctx, hipMemcpyAsync(d_H, Hsel.data(), Hsel.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    centers = centers_sel;
+    const int nbs = b1 - b0;
+
     // ---- per-band PSFs, iteration counts, workspace layout
-    std::vector<RlBand> bands((size_t)nb);
+    std::vector<RlBand> bands((size_t)nbs);
     std::vector<float> psf_pack;
     size_t ws_floats = 0;
     unsigned blk = 0;
     int max_iter = 0;
-    std::vector<BandPsf> psfs((size_t)nb);
-    for (int b = 0; b < nb; ++b) {
+    std::vector<BandPsf> psfs((size_t)nbs);
+    for (int b = 0; b < nbs; ++b) {
         psfs[(size_t)b] = band_psf(*psf, centers[(size_t)b], dx, dy, (int)nx, (int)ny);
         const BandPsf &bp = psfs[(size_t)b];
         RlBand &B = bands[(size_t)b];
@@ -185,7 +199,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.off_u = (unsigned)ws_floats; ws_floats += img;
         B.off_t = (unsigned)ws_floats; ws_floats += img;
     }
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < nbs; ++b) {
         const BandPsf &bp = psfs[(size_t)b];
         RlBand &B = bands[(size_t)b];
         B.off_psf = (unsigned)(ws_floats + psf_pack.size());
@@ -199,14 +213,14 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, mem.alloc(&d_bands, bands.size() * sizeof(RlBand)));
     HIP_TRY(ctx, hipMemcpyAsync(d_bands, bands.data(), bands.size() * sizeof(RlBand), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, mem.alloc(&d_spec, npix * nk * sizeof(c32)));
-    HIP_TRY(ctx, mem.alloc(&d_energy, (size_t)nb * npix * sizeof(float)));
-    HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nb * npix * sizeof(float)));
+    HIP_TRY(ctx, mem.alloc(&d_energy, (size_t)nbs * npix * sizeof(float)));
+    HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nbs * npix * sizeof(float)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope below
 
     const int shift = (kDeconvTaps - 1) / 2;
     launch_dc_fft(ctx->stream, P, npix, (int)nt, d_in, d_spec);
-    launch_dc_energy(ctx->stream, P, npix, (int)nt, nb, shift, d_spec, d_H, d_energy);
-    launch_rl_init(ctx->stream, d_bands, nb, blk, npix, d_energy, d_ws);
+    launch_dc_energy(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_energy);
+    launch_rl_init(ctx->stream, d_bands, nbs, blk, npix, d_energy, d_ws);
     if (int rc = check_launch(ctx)) return rc;
     for (int it = 0; it < max_iter; ++it) {
         if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
@@ -215,18 +229,18 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
         }
-        launch_rl_step(ctx->stream, d_bands, nb, blk, it, 0, d_ws);
-        launch_rl_step(ctx->stream, d_bands, nb, blk, it, 1, d_ws);
+        launch_rl_step(ctx->stream, d_bands, nbs, blk, it, 0, d_ws);
+        launch_rl_step(ctx->stream, d_bands, nbs, blk, it, 1, d_ws);
         if ((it & 31) == 31) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
             if (progress) *progress = (float)(it + 1) / (float)max_iter;
         }
     }
-    launch_dc_gain(ctx->stream, d_bands, nb, npix, d_energy, d_ws, d_gain);
-    launch_dc_combine(ctx->stream, P, npix, (int)nt, nb, shift, d_spec, d_H, d_gain, d_out, d_img);
+    launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);
+    launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
     if (int rc = check_launch(ctx)) return rc;
     if (d_gains_out)
-        HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nb * npix * sizeof(float),
+        HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nbs * npix * sizeof(float),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // temporaries are freed on return
     if (progress) *progress = 1.0f;

@@ -230,6 +230,26 @@ static void run_default_chain(const std::string &dir)
     pipe.config.fft_window = {0.5f, 3.0f};
     pipe.update_filter(pipe.fft_index + 1);
     CHECK(pipe.filter_data.back().data.size() == cube.size(), "partial recompute shape");
+    // second run: down-scaling by 2 and averaging in Fourier space
+    // (SetDownScaling -> Filter(1), SetAvgInFourierSpace -> Filter(fft_index))
+    pipe.config = ConfigContainer();
+    pipe.config.scale_factor = 2;
+    pipe.config.avg_in_fourier_space = true;
+    pipe.update_filter(1);
+    {
+        const ScannedImageFilterData &sp = pipe.filter_data[pipe.filter_uuid_to_index["ifft"]];
+        const ScannedImageFilterData &la = pipe.filter_data.back();
+        CHECK(sp.width == nx / 2 && sp.height == ny / 2 && sp.scaling == 2, "scaled container shape");
+        CHECK(la.img.size() == nx * ny, "scaled image is expanded back to the original size");
+        std::FILE *f2 = std::fopen((dir + "/out2.bin").c_str(), "wb");
+        auto put2 = [&](const std::vector<float> &v) { std::fwrite(v.data(), 4, v.size(), f2); };
+        put2(la.data.download());
+        put2(la.img.download());
+        put2(sp.avg_data);
+        put2(sp.avg_signal_fft);
+        put2(sp.roi_data.at("roi-1").second);
+        std::fclose(f2);
+    }
     std::printf("PASS? default chain done (%zux%zux%zu)\n", nx, ny, nt);
 }
 

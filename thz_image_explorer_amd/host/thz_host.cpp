@@ -445,7 +445,7 @@ ScannedImageFilterData Deconvolution::filter(const ScannedImageFilterData &input
     if (!e.ensure_axis(input.time)) return input;
     ScannedImageFilterData output = input;
     const thz_psf psf = gui.psf.view();
-    const thz_deconv_cfg cfg{(uint32_t)n_iterations, (uint32_t)n_filters, start_freq, end_freq, win_width};
+    const thz_deconv_cfg cfg{(uint32_t)n_iterations, (uint32_t)n_filters, start_freq, end_freq, win_width, 0u, 0u};
     // abort: Arc<AtomicBool> -> plain int the engine polls between batches
     volatile int abort_now = abort_flag.load() ? 1 : 0;
     float prog = 0.0f;

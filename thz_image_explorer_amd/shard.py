@@ -51,3 +51,17 @@ def gather_image(t_img, nx: int, dist=None, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat([b[:n] for b, n in zip(bufs, rows)], dim=0)
+
+
+def band_range(n_filters: int, world: int, rank: int) -> Tuple[int, int]:
+    """Deconvolution is band-parallel across GPUs (Richardson-Lucy is spatially
+    global per band): bands [b0, b1) of this rank; every rank
+    needs the whole cube; the per-rank outputs are all-reduced (sum)."""
+    b0, n = slab(n_filters, world, rank)
+    return b0, b0 + n
+
+
+def all_reduce_cube(t_out, dist=None):
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t_out)
+    return t_out
