@@ -11,7 +11,7 @@
 //   pass 2  radix-R2 over j2, twiddle W_(R2 R3)^(j3 k2)
 //   LDS exchange E2 (XOR-swizzled)
 //   pass 3  radix-R3 over j3 -> natural order in LDS
-// Each wave owns N c32 of LDS (16 KiB at nt = 4096) and never meets a
+// Each wave owns N cx of LDS (16 KiB at nt = 4096) and never meets a
 // workgroup barrier inside its trace loop; the block shares the twiddle
 // tables, staged once.  The inverse transform runs through the same passes
 // on re<->im swapped data.
@@ -21,63 +21,76 @@
 
 namespace thz {
 
+// Complex values of the F family are 2-element vectors (x = re, y = im): hipcc then
+// selects v_pk_add/mul/fma_f32 and folds the re<->im swizzles and sign flips of the
+// butterflies into the instructions' op_sel / neg modifiers instead of emitting
+// v_mov shuffles (a struct {re, im} costs ~40 % more VALU for a 16-point DFT).
+// Layout-compatible with c32.
+typedef float cx __attribute__((ext_vector_type(2)));
+static_assert(sizeof(cx) == 8, "cx must alias c32");
+struct alignas(16) cx2 {
+    cx a, b;
+};
+__device__ __forceinline__ cx cx_mul(cx a, cx b)
+{
+    const cx bs = {-b.y, b.x};
+    return a.xx * b + a.yy * bs;
+}
+__device__ __forceinline__ cx cx_conj(cx a) { return cx{a.x, -a.y}; }
+__device__ __forceinline__ cx cx_mnegi(cx a) { return cx{a.y, -a.x}; }  // a * (-i)
+__device__ __forceinline__ cx cx_swap(cx a) { return cx{a.y, a.x}; }
+
 // ---------------------------------------------------------------- butterflies
 // forward (exp(-i...)) DFTs of 4 / 8 / 16 points, natural order in and out
 
-__device__ __forceinline__ void bfly4(c32 &a0, c32 &a1, c32 &a2, c32 &a3)
+__device__ __forceinline__ void bfly4(cx &a0, cx &a1, cx &a2, cx &a3)
 {
-    const c32 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    const c32 s13 = cadd(a1, a3), d13 = csub(a1, a3);
-    a0 = cadd(s02, s13);
-    a1 = c32{d02.re + d13.im, d02.im - d13.re};
-    a2 = csub(s02, s13);
-    a3 = c32{d02.re - d13.im, d02.im + d13.re};
+    const cx s02 = a0 + a2, d02 = a0 - a2;
+    const cx s13 = a1 + a3, d13 = a1 - a3;
+    const cx t = cx_mnegi(d13);
+    a0 = s02 + s13;
+    a1 = d02 + t;
+    a2 = s02 - s13;
+    a3 = d02 - t;
 }
 
 // multiply by exp(-2*pi*i*e/16), e compile-time
 template <int E>
-__device__ __forceinline__ c32 mul_w16(c32 v)
+__device__ __forceinline__ cx mul_w16(cx v)
 {
     constexpr float C1 = 0.92387953251128673848f;  // cos(pi/8)
     constexpr float S1 = 0.38268343236508978178f;  // sin(pi/8)
     constexpr float H = 0.70710678118654752440f;   // cos(pi/4)
     constexpr int e = ((E % 16) + 16) % 16;
     if constexpr (e == 0) return v;
-    else if constexpr (e == 1) return c32{v.re * C1 + v.im * S1, v.im * C1 - v.re * S1};
-    else if constexpr (e == 2) return c32{(v.re + v.im) * H, (v.im - v.re) * H};
-    else if constexpr (e == 3) return c32{v.re * S1 + v.im * C1, v.im * S1 - v.re * C1};
-    else if constexpr (e == 4) return c32{v.im, -v.re};
-    else if constexpr (e == 5) return c32{-v.re * S1 + v.im * C1, -v.im * S1 - v.re * C1};
-    else if constexpr (e == 6) return c32{(v.im - v.re) * H, -(v.re + v.im) * H};
-    else if constexpr (e == 7) return c32{-v.re * C1 + v.im * S1, -v.im * C1 - v.re * S1};
-    else if constexpr (e == 8) return c32{-v.re, -v.im};
-    else if constexpr (e == 9) return c32{-v.re * C1 - v.im * S1, -v.im * C1 + v.re * S1};
-    else if constexpr (e == 10) return c32{-(v.re + v.im) * H, (v.re - v.im) * H};
-    else if constexpr (e == 11) return c32{-v.re * S1 - v.im * C1, -v.im * S1 + v.re * C1};
-    else if constexpr (e == 12) return c32{-v.im, v.re};
-    else if constexpr (e == 13) return c32{v.re * S1 - v.im * C1, v.im * S1 + v.re * C1};
-    else if constexpr (e == 14) return c32{(v.re - v.im) * H, (v.re + v.im) * H};
-    else return c32{v.re * C1 - v.im * S1, v.im * C1 + v.re * S1};
+    else if constexpr (e == 4) return cx_mnegi(v);
+    else if constexpr (e == 8) return -v;
+    else if constexpr (e == 12) return cx{-v.y, v.x};
+    else {
+        constexpr float cs[16] = {1.0f, C1, H, S1, 0.0f, -S1, -H, -C1, -1.0f, -C1, -H, -S1, 0.0f, S1, H, C1};
+        constexpr float sn[16] = {0.0f, S1, H, C1, 1.0f, C1, H, S1, 0.0f, -S1, -H, -C1, -1.0f, -C1, -H, -S1};
+        return cx_mul(v, cx{cs[e], -sn[e]});  // exp(-i theta) = (cos, -sin)
+    }
 }
 
-__device__ __forceinline__ void dft4(c32 (&v)[4]) { bfly4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void dft4(cx (&v)[4]) { bfly4(v[0], v[1], v[2], v[3]); }
 
-__device__ __forceinline__ void dft8(c32 (&v)[8])
+__device__ __forceinline__ void dft8(cx (&v)[8])
 {
-    c32 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    c32 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    cx e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cx o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     bfly4(e0, e1, e2, e3);
     bfly4(o0, o1, o2, o3);
     o1 = mul_w16<2>(o1);
     o2 = mul_w16<4>(o2);
     o3 = mul_w16<6>(o3);
-    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
-    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+    v[0] = (e0 + o0); v[4] = (e0 - o0);
+    v[1] = (e1 + o1); v[5] = (e1 - o1);
+    v[2] = (e2 + o2); v[6] = (e2 - o2);
+    v[3] = (e3 + o3); v[7] = (e3 - o3);
 }
 
-__device__ __forceinline__ void dft16(c32 (&v)[16])
+__device__ __forceinline__ void dft16(cx (&v)[16])
 {
     // A_r[q] = sum_j x[r + 4j] W4^(jq)
     bfly4(v[0], v[4], v[8], v[12]);
@@ -94,7 +107,7 @@ __device__ __forceinline__ void dft16(c32 (&v)[16])
     bfly4(v[8], v[9], v[10], v[11]);
     bfly4(v[12], v[13], v[14], v[15]);
     // v[4q + p] = y[q + 4p]  -> transpose to natural order
-    c32 t;
+    cx t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[2]; v[2] = v[8]; v[8] = t;
     t = v[3]; v[3] = v[12]; v[12] = t;
@@ -104,7 +117,7 @@ __device__ __forceinline__ void dft16(c32 (&v)[16])
 }
 
 template <int R>
-__device__ __forceinline__ void dftR(c32 (&v)[R])
+__device__ __forceinline__ void dftR(cx (&v)[R])
 {
     static_assert(R == 4 || R == 8 || R == 16, "radix");
     if constexpr (R == 4) dft4(v);
@@ -121,8 +134,8 @@ __device__ __forceinline__ void dftR(c32 (&v)[R])
 __device__ __forceinline__ int nat(int k) { return k ^ ((k >> 5) & 3); }
 
 // 16-byte LDS accesses (ds_read_b128 / ds_write_b128): index must be even
-__device__ __forceinline__ c32x2 ld2(const c32 *p) { return *reinterpret_cast<const c32x2 *>(p); }
-__device__ __forceinline__ void st2(c32 *p, c32 a, c32 b) { *reinterpret_cast<c32x2 *>(p) = c32x2{a, b}; }
+__device__ __forceinline__ cx2 ld2(const cx *p) { return *reinterpret_cast<const cx2 *>(p); }
+__device__ __forceinline__ void st2(cx *p, cx a, cx b) { *reinterpret_cast<cx2 *>(p) = cx2{a, b}; }
 
 // ------------------------------------------------------------------- the plan
 template <int R1_, int R2_, int R3_>
@@ -138,14 +151,14 @@ struct FPlan {
     static_assert(R3 == 8, "pass-2 lane map assumes R3 = 8");
     static_assert(C1 == 1 || C1 == 2, "C1");
     static_assert(C2 >= 1 && C3 >= 1, "lanes must all own a butterfly");
-    // LDS per block, in c32: [T1: R1*M1][T2: R2*R3][mask: nf floats][per wave: N + 2]
+    // LDS per block, in cx: [T1: R1*M1][T2: R2*R3][mask: nf floats][per wave: N + 2]
     static constexpr int T1_ENTRIES = R1 * M1;
     static constexpr int T2_ENTRIES = R2 * R3;
     static constexpr int MASK_ENTRIES = (N + 4) / 2;  // N + 1 floats, padded to 16 bytes
     static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
     static constexpr size_t lds_bytes(int waves)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + waves * WAVE_ENTRIES) * sizeof(c32);
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -161,18 +174,18 @@ using FPlan4096 = FPlan<16, 16, 8>;
 using FPlan2048 = FPlan<8, 16, 8>;
 using FPlan1024 = FPlan<8, 8, 8>;
 
-// Host-built tables for one plan (c32 arrays in global memory):
+// Host-built tables for one plan (cx arrays in global memory):
 //   t1[k1*M1 + C1*l + b ... ] laid out [k1][m]      : W_N^(m k1)
 //   t2[k2*8 + j3]                                   : W_(R2*8)^(j3 k2)
 //   tl[]  lane constants, see FTables
 struct FTables {
-    const c32 *t1;
-    const c32 *t2;
-    const c32 *w2n;  // exp(-i*pi*k/N), k in [0, N): R2C / C2R split twiddles
+    const cx *t1;
+    const cx *t2;
+    const cx *w2n;  // exp(-i*pi*k/N), k in [0, N): R2C / C2R split twiddles
 };
 
 // ------------------------------------------------------------------ the core
-// Lane-dependent LDS base indices (c32 units), computed once per kernel.  Every
+// Lane-dependent LDS base indices (cx units), computed once per kernel.  Every
 // LDS access of the core is base[...] + compile-time constant, so that it
 // becomes one ds_read/ds_write with an immediate offset and no per-access
 // address VGPR (without this the ~160 distinct addresses get hoisted out of the
@@ -217,7 +230,7 @@ struct FAddr {
 //      the inverse).  Out: natural-order spectrum Z[0..N] in `buf` (Z[N] = Z[0]).
 // t1/t2 point to the block's LDS copies of the tables.  Ends with wave_sync().
 template <class P>
-__device__ __forceinline__ void f_core_pass1(c32 (&r)[P::C1][P::R1], c32 *buf, const c32 *t1,
+__device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, const cx *t1,
                                              const FAddr<P> &ad, int lane)
 {
     constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
@@ -227,20 +240,20 @@ __device__ __forceinline__ void f_core_pass1(c32 (&r)[P::C1][P::R1], c32 *buf, c
         dftR<R1>(r[c]);
         THZ_SCHED_FENCE();
     }
-    const c32 *t1l = t1 + launder_v(C1 * lane);
+    const cx *t1l = t1 + launder_v(C1 * lane);
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
         if constexpr (C1 == 2) {
-            c32 v0 = r[0][k1], v1 = r[1][k1];
+            cx v0 = r[0][k1], v1 = r[1][k1];
             if (k1 > 0) {
-                const c32x2 w = ld2(t1l + k1 * M1);
-                v0 = cmul(v0, w.a);
-                v1 = cmul(v1, w.b);
+                const cx2 w = ld2(t1l + k1 * M1);
+                v0 = cx_mul(v0, w.a);
+                v1 = cx_mul(v1, w.b);
             }
             st2(buf + ad.w1[k1 & 3] + k1 * M1, v0, v1);  // = e1(k1, 2*lane + {0,1})
         } else {
-            c32 v = r[0][k1];
-            if (k1 > 0) v = cmul(v, t1l[k1 * M1]);
+            cx v = r[0][k1];
+            if (k1 > 0) v = cx_mul(v, t1l[k1 * M1]);
             buf[ad.w1[k1 & 3] + k1 * M1] = v;  // = e1(k1, lane)
         }
         if ((k1 & 3) == 3) THZ_SCHED_FENCE();
@@ -249,12 +262,12 @@ __device__ __forceinline__ void f_core_pass1(c32 (&r)[P::C1][P::R1], c32 *buf, c
 }
 
 template <class P>
-__device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAddr<P> &ad, int lane)
+__device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr<P> &ad, int lane)
 {
     constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, C2 = P::C2, C3 = P::C3;
     constexpr int M1 = P::M1;
     // ---- pass 2: lane owns (k1, j3) = ((lane>>3) + 8*c2, lane&7)
-    c32 b[C2][R2];
+    cx b[C2][R2];
 #pragma unroll
     for (int c2 = 0; c2 < C2; ++c2) {
 #pragma unroll
@@ -263,15 +276,15 @@ __device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAd
         THZ_SCHED_FENCE();
     }
     wave_sync();
-    const c32 *t2l = t2 + launder_v(lane & 7);
+    const cx *t2l = t2 + launder_v(lane & 7);
 #pragma unroll
     for (int c2 = 0; c2 < C2; ++c2) {
         dftR<R2>(b[c2]);
         THZ_SCHED_FENCE();
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) {
-            c32 v = b[c2][k2];
-            if (k2 > 0) v = cmul(v, t2l[k2 * 8]);
+            cx v = b[c2][k2];
+            if (k2 > 0) v = cx_mul(v, t2l[k2 * 8]);
             // row = k2*R1 + k1, k1 = (lane>>3) + 8*c2
             constexpr int kq = R1 / 4;
             const int variant = (((k2 * kq) & 3) >> 1) ^ c2;  // ((k2*R1/4) + 2*c2) & 3 is 0 or 2
@@ -281,12 +294,12 @@ __device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAd
     }
     wave_sync();
     // ---- pass 3: lane owns row r3 = lane + 64*c3  (k1 = r3 % R1, k2 = r3 / R1)
-    c32 d[C3][R3];
+    cx d[C3][R3];
 #pragma unroll
     for (int c3 = 0; c3 < C3; ++c3) {
 #pragma unroll
         for (int u = 0; u < R3 / 2; ++u) {
-            const c32x2 v = ld2(buf + ad.r3[u] + 512 * c3);  // = e2(row, 2u), e2(row, 2u + 1)
+            const cx2 v = ld2(buf + ad.r3[u] + 512 * c3);  // = e2(row, 2u), e2(row, 2u + 1)
             d[c3][2 * u] = v.a;
             d[c3][2 * u + 1] = v.b;
         }
@@ -313,22 +326,22 @@ __device__ __forceinline__ void f_core_pass23(c32 *buf, const c32 *t2, const FAd
 
 // --------------------------------------------------------- R2C / C2R algebra
 // X[k] and conj(X[N-k]) from Z[k], Z[N-k]  (w = exp(-i*pi*k/N))
-__device__ __forceinline__ void r2c_pair(c32 a, c32 b, c32 w, c32 &xk, c32 &xnk_conj)
+__device__ __forceinline__ void r2c_pair(cx a, cx b, cx w, cx &xk, cx &xnk_conj)
 {
-    const c32 E = c32{0.5f * (a.re + b.re), 0.5f * (a.im - b.im)};
-    const c32 O = c32{0.5f * (a.im + b.im), -0.5f * (a.re - b.re)};
-    const c32 t = cmul(O, w);
-    xk = cadd(E, t);
-    xnk_conj = csub(E, t);
+    const cx E = cx{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
+    const cx O = cx{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
+    const cx t = cx_mul(O, w);
+    xk = (E + t);
+    xnk_conj = (E - t);
 }
 
 // Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k])
-__device__ __forceinline__ c32 c2r_elem(c32 xk, c32 xnk_conj, c32 w)
+__device__ __forceinline__ cx c2r_elem(cx xk, cx xnk_conj, cx w)
 {
-    const c32 E = cadd(xk, xnk_conj);
-    const c32 D = csub(xk, xnk_conj);
-    const c32 O = c32{D.re * w.re + D.im * w.im, D.im * w.re - D.re * w.im};  // D * conj(w)
-    return c32{E.re - O.im, E.im + O.re};
+    const cx E = (xk + xnk_conj);
+    const cx D = (xk - xnk_conj);
+    const cx O = cx{D.x * w.x + D.y * w.y, D.y * w.x - D.x * w.y};  // D * conj(w)
+    return cx{E.x - O.y, E.y + O.x};
 }
 
 }  // namespace thz
@@ -368,11 +381,11 @@ struct FArgs {
     size_t npix;
     const float *in;        // (npix, nt) raw traces            [fwd, pipeline]
     const float *pre_win;   // (nt); may be null only when pre_blocks == 0
-    c32 *fft_out;           // (npix, nf), required
+    cx *fft_out;           // (npix, nf), required
     float *amp_out;         // (npix, nf), required when the kernel is built with AMP_PHASE
     float *ph_out;          // (npix, nf), required when the kernel is built with AMP_PHASE
     const float *mask;      // (nf), required (a vector of ones when no band-pass is wanted)
-    const c32 *fft_in;      // (npix, nf)                        [inv only]
+    const cx *fft_in;      // (npix, nf)                        [inv only]
     const float *post_win;  // (nt); may be null only when post_blocks == 0
     float *data_out;        // (npix, nt) final trace            [inv, pipeline]
     float *img;             // (npix) or null
@@ -407,7 +420,7 @@ __device__ __forceinline__ void f_load_raw(const float *__restrict__ x, int lane
 // Same register layout for a spectrum row (inverse kernel): raw[j][..] = X[C1*(64 j + lane) + c]
 // as {re, im} pairs.  Rows are only 8-byte aligned (nf is odd).
 template <class P>
-__device__ __forceinline__ void f_load_spec(const c32 *__restrict__ X, int lane,
+__device__ __forceinline__ void f_load_spec(const cx *__restrict__ X, int lane,
                                             float (&raw)[P::R1][2 * P::C1])
 {
 #pragma unroll
@@ -446,7 +459,7 @@ __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane
 //   bin N           : lane 0, after the last group
 // so the unwrap scan always runs over ascending bins.
 template <class P, bool AMP_PHASE>
-__device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restrict__ w2n,
+__device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *__restrict__ w2n,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane)
 {
@@ -455,7 +468,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restr
     const int nf = N + 1;
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
     constexpr bool want_phase = AMP_PHASE;
-    c32 wl[4];
+    cx wl[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) wl[c] = w2n[4 * lane + c];
     float carry = 0.0f;       // sum of adjusted differences of all previous groups
@@ -473,25 +486,25 @@ __device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restr
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         const int k0 = 256 * g + kb;
-        c32 *zf = buf + 256 * g;
-        c32 X[4];
+        cx *zf = buf + 256 * g;
+        cx X[4];
         if (g < NG / 2) {
-            c32 *zm = buf - 256 * g;
-            const c32 wg = w2n[256 * g];  // wave-uniform
+            cx *zm = buf - 256 * g;
+            const cx wg = w2n[256 * g];  // wave-uniform
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const c32 a = zf[fb[c]], b = zm[mb[c]];
-                c32 xk, xnc;
-                r2c_pair(a, b, g == 0 ? wl[c] : cmul(wl[c], wg), xk, xnc);
+                const cx a = zf[fb[c]], b = zm[mb[c]];
+                cx xk, xnc;
+                r2c_pair(a, b, g == 0 ? wl[c] : cx_mul(wl[c], wg), xk, xnc);
                 X[c] = xk;
                 zf[fb[c]] = xk;          // X[k]
-                zm[mb[c]] = cconj(xnc);  // X[N-k]  (k = 0: buf[N] = X[N], and X[0] over Z[0])
+                zm[mb[c]] = cx_conj(xnc);  // X[N-k]  (k = 0: buf[N] = X[N], and X[0] over Z[0])
             }
             if (g == NG / 2 - 1) {
                 // the one bin without a partner: X[N/2] = conj(Z[N/2]); every lane has
                 // finished its reads of this group before lane 0 rewrites the slot
                 wave_sync();
-                if (lane == 0) buf[nat(N / 2)] = cconj(buf[nat(N / 2)]);
+                if (lane == 0) buf[nat(N / 2)] = cx_conj(buf[nat(N / 2)]);
                 wave_sync();
             }
         } else {
@@ -506,18 +519,18 @@ __device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restr
         if constexpr (AMP_PHASE) {
             float a[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].re, X[c].re, X[c].im * X[c].im)) * m[c];
+            for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
             store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
         }
         {
             float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
-            store_f4(f, X[0].re * m[0], X[0].im * m[0], X[1].re * m[1], X[1].im * m[1]);
-            store_f4(f + 4, X[2].re * m[2], X[2].im * m[2], X[3].re * m[3], X[3].im * m[3]);
+            store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
+            store_f4(f + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
         }
         if constexpr (want_phase) {
             float ph[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ph[c] = fast_atan2f(X[c].im, X[c].re);
+            for (int c = 0; c < 4; ++c) ph[c] = fast_atan2f(X[c].y, X[c].x);
             if (g == 0) first = wave_bcast<0>(ph[0]);
             float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;
@@ -549,8 +562,8 @@ __device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restr
     // Nyquist bin k = N (real): lane 0
     if (lane == 0) {
         const float mN = mask[N];
-        const float xr = buf[N].re;
-        A.fft_out[p * nf + N] = c32{xr * mN, 0.0f};
+        const float xr = buf[N].x;
+        A.fft_out[p * nf + N] = cx{xr * mN, 0.0f};
         if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = fabsf(xr) * mN;
         if constexpr (want_phase) {
             const float phn = fast_atan2f(0.0f, xr);
@@ -567,12 +580,12 @@ __device__ __forceinline__ void f_spectrum_epilogue(c32 *buf, const c32 *__restr
 // the band-pass mask on the way (fused chain; the stored copy is unmasked so
 // that the phases of the whole spectrum could be taken).
 template <class P, bool MASKED>
-__device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__restrict__ w2n,
+__device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *__restrict__ w2n,
                                                 const float *__restrict__ mask, int lane,
-                                                c32 (&r)[P::C1][P::R1])
+                                                cx (&r)[P::C1][P::R1])
 {
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    c32 wl[C1];
+    cx wl[C1];
 #pragma unroll
     for (int c = 0; c < C1; ++c) wl[c] = w2n[C1 * lane + c];
     // n = M1 j1 + C1 lane + c and its mirror N - n; M1 is a multiple of 32*4 only for
@@ -591,28 +604,28 @@ __device__ __forceinline__ void f_inverse_input(const c32 *buf, const c32 *__res
     const int mk_r = launder_v(N - TOP - C1 * lane);       // mask[N - n] = mask[mk_r + TOP - (M1 j1 + c)]
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
-        const c32 wg = w2n[M1 * j1];  // wave-uniform
+        const cx wg = w2n[M1 * j1];  // wave-uniform
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
             const int off = M1 * j1 + c;
-            const c32 w = j1 == 0 ? wl[c] : cmul(wl[c], wg);
-            c32 xk = buf[fbase[j1 & 1][c] + M1 * j1];
-            c32 xnc = cconj(buf[mbase[j1 & 1][c] - M1 * j1]);
+            const cx w = j1 == 0 ? wl[c] : cx_mul(wl[c], wg);
+            cx xk = buf[fbase[j1 & 1][c] + M1 * j1];
+            cx xnc = cx_conj(buf[mbase[j1 & 1][c] - M1 * j1]);
             if (off == 0) {
                 // n == 0 only in lane 0: X[0] and X[N] are real (realfft ignores /
                 // rejects their imaginary parts, SURVEY a'-4)
                 if (lane == 0) {
-                    xk.im = 0.0f;
-                    xnc.im = 0.0f;
+                    xk.y = 0.0f;
+                    xnc.y = 0.0f;
                 }
             }
             if constexpr (MASKED) {
                 const float mk = mask[mk_f + off], mn = mask[mk_r + (TOP - off)];
-                xk = c32{xk.re * mk, xk.im * mk};
-                xnc = c32{xnc.re * mn, xnc.im * mn};
+                xk = cx{xk.x * mk, xk.y * mk};
+                xnc = cx{xnc.x * mn, xnc.y * mn};
             }
-            const c32 z = c2r_elem(xk, xnc, w);
-            r[c][j1] = c32{z.im, z.re};
+            const cx z = c2r_elem(xk, xnc, w);
+            r[c][j1] = cx{z.y, z.x};
         }
         if ((j1 & 1) == 1) THZ_SCHED_FENCE();
     }
@@ -641,7 +654,7 @@ __device__ __forceinline__ bool f_block_on(uint32_t blocks, int j)
 }
 
 template <class P, bool WIN_FULL>
-__device__ __forceinline__ void f_time_epilogue(const c32 *buf, size_t p, const FArgs &A,
+__device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const FArgs &A,
                                                 uint32_t post_blocks, int lane)
 {
     constexpr int NT = P::NT, R1 = P::R1, C1 = P::C1;
@@ -659,14 +672,14 @@ __device__ __forceinline__ void f_time_epilogue(const c32 *buf, size_t p, const 
     for (int j = 0; j < R1; ++j) {
         float v[2 * C1];
         if constexpr (C1 == 2) {
-            const c32x2 rr = ld2(buf + ob2 + 2 * kWave * j);
-            const c32 e0 = swap2 ? rr.b : rr.a, e1 = swap2 ? rr.a : rr.b;
-            v[0] = e0.im / fnt; v[1] = e0.re / fnt;
-            v[2] = e1.im / fnt; v[3] = e1.re / fnt;
+            const cx2 rr = ld2(buf + ob2 + 2 * kWave * j);
+            const cx e0 = swap2 ? rr.b : rr.a, e1 = swap2 ? rr.a : rr.b;
+            v[0] = e0.y / fnt; v[1] = e0.x / fnt;
+            v[2] = e1.y / fnt; v[3] = e1.x / fnt;
         } else {
-            const c32 rr = buf[((j & 1) ? ob1b : ob1a) + kWave * j];
-            v[0] = rr.im / fnt;
-            v[1] = rr.re / fnt;
+            const cx rr = buf[((j & 1) ? ob1b : ob1a) + kWave * j];
+            v[0] = rr.y / fnt;
+            v[1] = rr.x / fnt;
         }
         if (f_block_on<P, WIN_FULL>(post_blocks, j)) {
             float w[2 * C1];
@@ -699,10 +712,10 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     const int lane = lane_id();
     const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
-    c32 *t1 = reinterpret_cast<c32 *>(lds);
-    c32 *t2 = t1 + P::T1_ENTRIES;
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + P::T1_ENTRIES;
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES);
-    c32 *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    cx *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
     if (MODE != kInv)
@@ -738,12 +751,12 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             f_load_raw<P>(A.in + p * NT, lane, raw);
         } else {
             f_load_spec<P>(A.fft_in + p * nf, lane, raw);
-            x_nyq_next = A.fft_in[p * nf + N].re;
+            x_nyq_next = A.fft_in[p * nf + N].x;
         }
     }
 
     for (; p < A.npix; p += stride) {
-        c32 r[C1][R1];
+        cx r[C1][R1];
         ad.refresh();
         if constexpr (MODE != kInv) {
             const float *pre_w = launder_uniform(A.pre_win);
@@ -772,7 +785,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
 #pragma unroll
             for (int j1 = 0; j1 < R1; ++j1) {
 #pragma unroll
-                for (int c = 0; c < C1; ++c) r[c][j1] = c32{raw[j1][2 * c], raw[j1][2 * c + 1]};
+                for (int c = 0; c < C1; ++c) r[c][j1] = cx{raw[j1][2 * c], raw[j1][2 * c + 1]};
             }
             // The next trace of this wave is prefetched into registers right
             // after pass 1 (of the inverse transform in the fused chain): `r` is dead
@@ -803,13 +816,13 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
 #pragma unroll
                 for (int j = 0; j < R1; ++j) {
                     if constexpr (C1 == 2) {
-                        const c32 e0 = c32{raw[j][0], raw[j][1]}, e1 = c32{raw[j][2], raw[j][3]};
+                        const cx e0 = cx{raw[j][0], raw[j][1]}, e1 = cx{raw[j][2], raw[j][3]};
                         st2(buf + sb2 + 2 * kWave * j, swap2 ? e1 : e0, swap2 ? e0 : e1);
                     } else {
-                        buf[((j & 1) ? sb1b : sb1a) + kWave * j] = c32{raw[j][0], raw[j][1]};
+                        buf[((j & 1) ? sb1b : sb1a) + kWave * j] = cx{raw[j][0], raw[j][1]};
                     }
                 }
-                if (lane == 0) buf[N] = c32{x_nyq_next, 0.0f};
+                if (lane == 0) buf[N] = cx{x_nyq_next, 0.0f};
             }
             wave_sync();
             f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, lane, r);
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             f_core_pass1<P>(r, buf, t1, ad, lane);
             if (p + stride < A.npix) {
                 f_load_spec<P>(A.fft_in + (p + stride) * nf, lane, raw);
-                x_nyq_next = A.fft_in[(p + stride) * nf + N].re;
+                x_nyq_next = A.fft_in[(p + stride) * nf + N].x;
             }
             f_core_pass23<P>(buf, t2, ad, lane);
             if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);

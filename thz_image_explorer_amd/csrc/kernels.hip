@@ -1026,7 +1026,8 @@ static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
     size_t g = (A.npix + kWpb - 1) / kWpb;
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
     if (g < 1) g = 1;
-    FTables T{P.f_t1, P.f_t2, P.f_w2n};
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
+              reinterpret_cast<const cx *>(P.f_w2n)};
     allow_dynamic_lds(k_f<PL, MODE, CFG>, lds);
     THZ_LAUNCH((k_f<PL, MODE, CFG>), (unsigned)g, kBlock, lds, st, A, T);
 }
@@ -1064,7 +1065,7 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
     }
     if (P.family == kFamilyF && !wb && !data_out && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
         FArgs A{};
-        A.npix = npix; A.in = in; A.pre_win = wa; A.fft_out = fft_out; A.amp_out = amp_out;
+        A.npix = npix; A.in = in; A.pre_win = wa; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
         A.ph_out = ph_out; A.mask = mask ? mask : P.ones;
         dispatch_f<kFwd>(st, P, A, amp_out != nullptr);
         return;
@@ -1082,7 +1083,7 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 {
     if (P.family == kFamilyF) {
         FArgs A{};
-        A.npix = npix; A.fft_in = fft_in; A.post_win = win; A.data_out = out; A.img = img;
+        A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.post_win = win; A.data_out = out; A.img = img;
         dispatch_f<kInv>(st, P, A, false);
         return;
     }
@@ -1099,7 +1100,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
 {
     if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
         FArgs A{};
-        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = fft_out; A.amp_out = amp_out;
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
         A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.post_win = post_win;
         A.data_out = data_out; A.img = img;
         dispatch_f<kPipe>(st, P, A, true);
