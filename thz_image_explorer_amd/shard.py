@@ -25,7 +25,7 @@ def slab(nx: int, world: int, rank: int) -> Tuple[int, int]:
 
 def all_reduce_sums(t_sums, dist=None):
     """C2: in-place sum of the partial-sum vector over ranks."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t_sums)
     return t_sums
 
@@ -35,7 +35,7 @@ def gather_image(t_img, nx: int, dist=None, dst: int = 0):
     Slabs may differ by one row (nx % world != 0), so this is a padded gather."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return t_img
     world, rank = dist.get_world_size(), dist.get_rank()
     ny = t_img.shape[1]
