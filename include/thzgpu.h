@@ -333,6 +333,76 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
 int thz_synth_cube(thz_ctx *ctx, float *d_out, size_t ntraces, uint64_t first_trace,
                    const float *d_time, uint32_t seed, int subtract_bias);
 
+/* ------------------------------------------------------------------ */
+/* Resident cube + whole-chain recompute ("session")                    */
+/* ------------------------------------------------------------------ */
+/* What the data thread keeps per open file, on the device: the raw cube
+ * (after the load-time bias subtraction) and ONE set of outputs — spectrum,
+ * amplitudes, phases, final trace cube, image, pixel means — instead of the
+ * reference's nine full containers (config.rs:270, main.rs:178-268).  Because
+ * the whole default chain is one HBM pass (thz_pipeline), every
+ * UpdateType::Filter(idx) (data_thread.rs:1023) is served by re-running it from
+ * the raw cube: that is the partial-recompute policy — nothing but the raw cube
+ * is cached.  A non-zero tilt changes the trace length and takes the staged
+ * path (tilt kernel, re-plan, transforms of the new length). */
+typedef struct thz_session thz_session;
+
+typedef struct thz_chain_cfg {
+    /* TiltCompensation (tilt_compensation.rs:27-32); active by default with 0/0 */
+    int32_t tilt_active;
+    double tilt_x_deg, tilt_y_deg;
+    /* Time Band Pass before the FFT (band_pass_td_before_fft.rs:28-33, reset :66-72) */
+    int32_t td_before_active;
+    double td_before_low, td_before_high, td_before_width;
+    /* ConfigContainer.fft_window(_type), config.rs:171-213 */
+    thz_window_cfg fft_window;
+    /* Frequency Band Pass (band_pass_fd.rs:30-37) */
+    int32_t fd_active;
+    double fd_low, fd_high, fd_width;
+    /* Time Band Pass after the inverse FFT (band_pass_td_after_fft.rs) */
+    int32_t td_after_active;
+    double td_after_low, td_after_high, td_after_width;
+    /* pixel means of the ifft stage (math_tools.rs:421-440) */
+    int32_t want_means;
+} thz_chain_cfg;
+
+/* Defaults of the reference after OpenFile + reset(): every filter active, bounds
+ * = ends of the time axis, widths 2.0 / 0.1 ps, 0.2-5 THz / 0.1 THz, window
+ * AdaptedBlackman [1, 7] ps, no tilt. */
+int thz_chain_cfg_default(const float *time, size_t nt, thz_chain_cfg *out);
+
+enum {
+    THZ_BUF_RAW = 0,        /* (nx, ny, nt) f32 */
+    THZ_BUF_FFT = 1,        /* (nx, ny, nf) complex */
+    THZ_BUF_AMPLITUDES = 2, /* (nx, ny, nf) */
+    THZ_BUF_PHASES = 3,     /* (nx, ny, nf) */
+    THZ_BUF_DATA = 4,       /* (nx, ny, nt_out) final trace cube */
+    THZ_BUF_IMG = 5,        /* (nx, ny) */
+    THZ_BUF_AVG_FFT = 6,    /* (nf) complex   — needs want_means */
+    THZ_BUF_AVG_AMPLITUDES = 7, /* (nf) */
+    THZ_BUF_AVG_PHASES = 8  /* (nf) */
+};
+
+int thz_session_create(thz_ctx *ctx, size_t nx, size_t ny, size_t nt, const float *time, float dx,
+                       float dy, thz_session **out);
+void thz_session_destroy(thz_session *s);
+/* open_scan_from_thz's in-memory part (io.rs:576-628): H2D, per-trace bias
+ * subtraction when asked, intensity image of the raw cube.  `cube` is host
+ * memory (nx, ny, nt) C-order, or NULL when the caller fills the raw buffer
+ * itself through thz_session_buffer(). */
+int thz_session_upload(thz_session *s, const float *cube, int subtract_bias);
+/* UpdateType::Filter(start_idx) for any start_idx: recomputes every output. */
+int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg);
+/* trace length of the final cube (nt, or nt + 2*steps after a tilt) and its axis */
+size_t thz_session_nt_out(const thz_session *s);
+int thz_session_time_out(const thz_session *s, float *time /* nt_out */);
+/* device pointer of a resident buffer (NULL if absent) */
+void *thz_session_buffer(thz_session *s, int which);
+/* copies pixels [pix0, pix0+npix) of a per-pixel buffer (or the whole vector for
+ * the AVG_* ones, pix0 = 0, npix = 1) to the host: the selected-pixel trace, a
+ * tile, or everything */
+int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst);
+
 /* Per-stage device time of the most recent call of each kind, the value the
  * reference shows next to each filter (filter.rs:607-621).  `stage` is one
  * of the THZ_STAGE_* ids. */

@@ -1,0 +1,120 @@
+"""thz_session (resident cube + whole-chain recompute, include/thzgpu.h) against the
+oracle chain: what the data thread does for OpenFile + UpdateType::Filter(idx)
+(data_thread.rs:1023-1334), with defaults, changed sliders and a tilted scan."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+import thz_image_explorer_amd as pkg
+from test_gpu_parity import TOL, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chain(cube, time, cfg, dx=1.0, dy=1.0):
+    """stage-by-stage oracle with the parameters of a thz_chain_cfg"""
+    d, t = cube, time
+    if cfg.tilt_active:
+        _, t, d = ob.tilt(d, t, cfg.tilt_x_deg, cfg.tilt_y_deg, dx, dy)
+    if cfg.td_before_active:
+        d, _, _ = ob.td_bandpass(d, t, cfg.td_before_low, cfg.td_before_high, cfg.td_before_width)
+    st = ob.fft_stage(d, t, cfg.fft_window.type, cfg.fft_window.lower, cfg.fft_window.upper)
+    fft, amp = st["fft"], st["amplitudes"]
+    freq = ob.frequency_axis(t)
+    if cfg.fd_active:
+        fft, amp = ob.fd_bandpass(fft, amp, freq, cfg.fd_low, cfg.fd_high, cfg.fd_width)
+    avg = dict(fft=ob.pixel_mean(fft, 2), amp=ob.pixel_mean(amp), ph=ob.pixel_mean(st["phases"]))
+    out, nerr = ob.ifft_stage(fft, t.size)
+    assert nerr == 0
+    if cfg.td_after_active:
+        out, _, _ = ob.td_bandpass(out, t, cfg.td_after_low, cfg.td_after_high, cfg.td_after_width)
+    return dict(time=t, fft=fft, amp=amp, ph=st["phases"], amp_unmasked=st["amplitudes"], data=out,
+                img=ob.intensity(out), avg=avg)
+
+
+def check(sess, ref, nx, ny):
+    nto = sess.nt_out
+    assert nto == ref["time"].size
+    assert np.array_equal(sess.time_out(), ref["time"])
+    nf = nto // 2 + 1
+    scale = np.abs(ref["fft"]).max()
+    assert rel(sess.download(pkg.BUF_FFT).reshape(nx, ny, nf, 2), ref["fft"], scale) < TOL
+    assert rel(sess.download(pkg.BUF_AMPLITUDES).reshape(nx, ny, nf), ref["amp"], scale) < TOL
+    assert rel(sess.download(pkg.BUF_DATA).reshape(nx, ny, nto), ref["data"]) < TOL
+    assert rel(sess.download(pkg.BUF_IMG).reshape(nx, ny), ref["img"]) < TOL
+    assert rel(sess.download(pkg.BUF_AVG_FFT), ref["avg"]["fft"], np.abs(ref["avg"]["fft"]).max()) < TOL
+    assert rel(sess.download(pkg.BUF_AVG_AMPLITUDES), ref["avg"]["amp"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 1024), (3, 4, 256), (4, 4, 1001)])
+def test_session_default_chain_and_slider_changes(engine, shape):
+    nx, ny, nt = shape
+    time, _ = synth.make_cube(1, 1, nt)
+    ids = np.arange(nx * ny, dtype=np.uint64)
+    raw = synth.make_traces(ids, nt, subtract_bias=False).reshape(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time)
+    try:
+        sess.upload(raw, subtract_bias=True)
+        cube = ob.subtract_bias(raw)
+        assert np.array_equal(sess.download(pkg.BUF_RAW).reshape(nx, ny, nt), cube)
+        assert rel(sess.download(pkg.BUF_IMG).reshape(nx, ny), ob.intensity(cube)) < TOL
+        cfg = pkg.chain_cfg_default(time)
+        assert cfg.td_before_low == float(time[0]) and cfg.td_after_high == float(time[-1])
+        sess.recompute(cfg)
+        check(sess, oracle_chain(cube, time, cfg), nx, ny)
+        # selected-pixel download == slice of the full download
+        full = sess.download(pkg.BUF_DATA)
+        assert np.array_equal(sess.download(pkg.BUF_DATA, 5, 2), full[5:7])
+        # slider changes: UpdateType::Filter(idx) with new parameters
+        cfg.fd_low, cfg.fd_high = 0.4, 2.5
+        cfg.td_before_low = float(time[0]) + 3.0
+        cfg.td_after_high = float(time[-1]) - 4.0
+        cfg.fft_window.type = 3  # Hamming
+        sess.recompute(cfg)
+        check(sess, oracle_chain(cube, time, cfg), nx, ny)
+        # filters switched off (Filter::config().active == false, data_thread.rs:1140-1153)
+        cfg.fd_active = 0
+        cfg.td_before_active = 0
+        cfg.tilt_active = 0
+        sess.recompute(cfg)
+        check(sess, oracle_chain(cube, time, cfg), nx, ny)
+    finally:
+        sess.close()
+
+
+def test_session_tilted_scan_changes_trace_length(engine):
+    nx, ny, nt = 6, 5, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time, dx=0.5, dy=0.5)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        cfg = pkg.chain_cfg_default(time)
+        cfg.tilt_x_deg, cfg.tilt_y_deg = 2.0, -1.0
+        sess.recompute(cfg)
+        ref = oracle_chain(cube, time, cfg, 0.5, 0.5)
+        assert sess.nt_out > nt
+        check(sess, ref, nx, ny)
+        # back to zero tilt: outputs return to the original length
+        cfg.tilt_x_deg = cfg.tilt_y_deg = 0.0
+        sess.recompute(cfg)
+        assert sess.nt_out == nt
+        check(sess, oracle_chain(cube, time, cfg, 0.5, 0.5), nx, ny)
+    finally:
+        sess.close()
+
+
+def test_session_download_bounds_and_missing_means(engine):
+    time, cube = synth.make_cube(2, 2, 256)
+    sess = pkg.Session(engine, 2, 2, time)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        cfg = pkg.chain_cfg_default(time)
+        cfg.want_means = 0
+        sess.recompute(cfg)
+        with pytest.raises(pkg.ThzError):
+            sess.download(pkg.BUF_AVG_FFT)
+        with pytest.raises(pkg.ThzError):
+            sess.download(pkg.BUF_DATA, 3, 2)
+    finally:
+        sess.close()

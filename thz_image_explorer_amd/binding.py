@@ -74,6 +74,19 @@ def psf_from_npz(z) -> "Psf":
     return psf
 
 
+class ChainCfg(C.Structure):
+    _fields_ = [("tilt_active", C.c_int32), ("tilt_x_deg", C.c_double), ("tilt_y_deg", C.c_double),
+                ("td_before_active", C.c_int32), ("td_before_low", C.c_double), ("td_before_high", C.c_double),
+                ("td_before_width", C.c_double), ("fft_window", WindowCfg),
+                ("fd_active", C.c_int32), ("fd_low", C.c_double), ("fd_high", C.c_double), ("fd_width", C.c_double),
+                ("td_after_active", C.c_int32), ("td_after_low", C.c_double), ("td_after_high", C.c_double),
+                ("td_after_width", C.c_double), ("want_means", C.c_int32)]
+
+
+BUF_RAW, BUF_FFT, BUF_AMPLITUDES, BUF_PHASES, BUF_DATA, BUF_IMG, BUF_AVG_FFT, BUF_AVG_AMPLITUDES, \
+    BUF_AVG_PHASES = range(9)
+
+
 class ThzError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"{STATUS.get(code, code)}: {msg}")
@@ -132,6 +145,15 @@ SYMBOLS = [
     ("thz_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _SZ, _SZ, C.c_float, C.c_float,
                                  _P, _P, _P, _P, _P, _P]),
     ("thz_synth_cube", C.c_int, [_P, _P, _SZ, C.c_uint64, _P, C.c_uint32, C.c_int]),
+    ("thz_chain_cfg_default", C.c_int, [_P, _SZ, C.POINTER(ChainCfg)]),
+    ("thz_session_create", C.c_int, [_P, _SZ, _SZ, _SZ, _P, C.c_float, C.c_float, C.POINTER(_P)]),
+    ("thz_session_destroy", None, [_P]),
+    ("thz_session_upload", C.c_int, [_P, _P, C.c_int]),
+    ("thz_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg)]),
+    ("thz_session_nt_out", _SZ, [_P]),
+    ("thz_session_time_out", C.c_int, [_P, _P]),
+    ("thz_session_buffer", _P, [_P, C.c_int]),
+    ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
     ("thz_enable_timing", C.c_int, [_P, C.c_int]),
     ("thz_stage_time_ns", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
     ("thz_timing_collect", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -262,6 +284,59 @@ def host_band_psf(psf: Psf, center_freq, dx, dy, img_rows, img_cols):
     _rc(L.thz_host_band_psf(C.byref(psf), center_freq, dx, dy, img_rows, img_cols, out.ctypes.data,
                             C.byref(r), C.byref(c)), "band_psf")
     return out
+
+
+def chain_cfg_default(time) -> ChainCfg:
+    t = np.ascontiguousarray(time, np.float32)
+    cfg = ChainCfg()
+    _rc(load_library().thz_chain_cfg_default(t.ctypes.data, t.size, C.byref(cfg)), "chain_cfg_default")
+    return cfg
+
+
+class Session:
+    """thz_session: resident cube + whole-chain recompute"""
+
+    def __init__(self, eng: "Engine", nx, ny, time, dx=1.0, dy=1.0):
+        self.eng, self.nx, self.ny = eng, nx, ny
+        t = np.ascontiguousarray(time, np.float32)
+        self.nt = t.size
+        self.h = _P()
+        eng._check(eng.lib.thz_session_create(eng.ctx, nx, ny, t.size, t.ctypes.data, dx, dy, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.eng.lib.thz_session_destroy(self.h)
+            self.h = None
+
+    def upload(self, cube, subtract_bias=True):
+        c = np.ascontiguousarray(cube, np.float32)
+        self.eng._check(self.eng.lib.thz_session_upload(self.h, c.ctypes.data, int(subtract_bias)))
+
+    def recompute(self, cfg: ChainCfg):
+        self.eng._check(self.eng.lib.thz_session_recompute(self.h, C.byref(cfg)))
+
+    @property
+    def nt_out(self):
+        return int(self.eng.lib.thz_session_nt_out(self.h))
+
+    def time_out(self):
+        t = np.empty(self.nt_out, np.float32)
+        self.eng._check(self.eng.lib.thz_session_time_out(self.h, t.ctypes.data))
+        return t
+
+    def download(self, which, pix0=0, npix=None):
+        nto = self.nt_out
+        nf = nto // 2 + 1
+        per = {BUF_RAW: (self.nt,), BUF_FFT: (nf, 2), BUF_AMPLITUDES: (nf,), BUF_PHASES: (nf,), BUF_DATA: (nto,),
+               BUF_IMG: ()}
+        if which in per:
+            npix = self.nx * self.ny - pix0 if npix is None else npix
+            out = np.empty((npix,) + per[which], np.float32)
+        else:
+            out = np.empty((nf, 2) if which == BUF_AVG_FFT else (nf,), np.float32)
+            pix0, npix = 0, 1
+        self.eng._check(self.eng.lib.thz_session_download(self.h, which, pix0, npix, out.ctypes.data))
+        return out
 
 
 class DevBuf:

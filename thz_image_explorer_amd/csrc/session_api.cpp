@@ -1,0 +1,248 @@
+// session_api.cpp — resident cube + whole-chain recompute on top of the stage
+// entry points (include/thzgpu.h, "session" section).
+#include "ctx.hpp"
+#include "host_windows.hpp"
+
+#include <cstring>
+
+using namespace thz;
+
+struct thz_session {
+    thz_ctx *ctx = nullptr;
+    size_t nx = 0, ny = 0, nt = 0, nf = 0;
+    float dx = 1.0f, dy = 1.0f;
+    std::vector<float> time, time_out;
+    size_t nt_out = 0, nf_out = 0;
+    float *d_raw = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr, *d_data = nullptr,
+          *d_img = nullptr, *d_avg = nullptr;  // d_avg: [2 nf | nf | nf]
+    float *d_vec = nullptr;                    // pre | mask | post multipliers (+ tilt scratch)
+    float *d_tilt = nullptr;                   // extended cube when tilt != 0
+    int32_t *d_ins = nullptr;
+    bool have_means = false;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(thz_ctx *ctx, T **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    return THZ_OK;
+}
+
+int alloc_outputs(thz_session *s, size_t nt_out)
+{
+    thz_ctx *ctx = s->ctx;
+    const size_t npix = s->nx * s->ny, nf = nt_out / 2 + 1;
+    if (nt_out == s->nt_out && s->d_fft) return THZ_OK;
+    if (int rc = dev_alloc(ctx, &s->d_fft, npix * nf * 2)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_amp, npix * nf)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_ph, npix * nf)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_data, npix * nt_out)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_avg, 4 * nf)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_vec, 3 * nt_out + nf + 8)) return rc;
+    s->nt_out = nt_out;
+    s->nf_out = nf;
+    return THZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thz_chain_cfg_default(const float *time, size_t nt, thz_chain_cfg *out)
+{
+    if (!time || nt < 2 || !out) return THZ_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->tilt_active = 1;
+    out->td_before_active = 1;
+    out->td_before_low = (double)time[0];          // reset(), band_pass_td_before_fft.rs:66-72
+    out->td_before_high = (double)time[nt - 1];
+    out->td_before_width = 2.0;
+    out->fft_window = thz_window_cfg{THZ_WIN_ADAPTED_BLACKMAN, 1.0f, 7.0f};
+    out->fd_active = 1;
+    out->fd_low = 0.2; out->fd_high = 5.0; out->fd_width = 0.1;
+    out->td_after_active = 1;
+    out->td_after_low = (double)time[0];
+    out->td_after_high = (double)time[nt - 1];
+    out->td_after_width = 0.1;
+    out->want_means = 1;
+    return THZ_OK;
+}
+
+int thz_session_create(thz_ctx *ctx, size_t nx, size_t ny, size_t nt, const float *time, float dx,
+                       float dy, thz_session **out)
+{
+    if (!ctx || !out || !time || nx == 0 || ny == 0 || nt < 2) return THZ_ERR_INVALID;
+    *out = nullptr;
+    if (int rc = thz_set_time_axis(ctx, time, nt)) return rc;
+    thz_session *s = new thz_session();
+    s->ctx = ctx; s->nx = nx; s->ny = ny; s->nt = nt; s->nf = nt / 2 + 1; s->dx = dx; s->dy = dy;
+    s->time.assign(time, time + nt);
+    s->time_out = s->time;
+    int rc = dev_alloc(ctx, &s->d_raw, nx * ny * nt);
+    if (!rc) rc = dev_alloc(ctx, &s->d_img, nx * ny);
+    if (!rc) rc = alloc_outputs(s, nt);
+    if (rc) { thz_session_destroy(s); return rc; }
+    *out = s;
+    return THZ_OK;
+}
+
+void thz_session_destroy(thz_session *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
+                    (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins})
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+int thz_session_upload(thz_session *s, const float *cube, int subtract_bias)
+{
+    if (!s) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (int rc = use_device(ctx)) return rc;
+    const size_t npix = s->nx * s->ny;
+    if (int rc = thz_set_time_axis(ctx, s->time.data(), s->nt)) return rc;
+    if (cube) HIP_TRY(ctx, hipMemcpyAsync(s->d_raw, cube, npix * s->nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    launch_intensity(ctx->stream, npix, (int)s->nt, s->d_raw, s->d_img, subtract_bias ? 1 : 0);
+    if (int rc = check_launch(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
+{
+    if (!s || !cfg) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (int rc = use_device(ctx)) return rc;
+    const size_t npix = s->nx * s->ny;
+    const float *src = s->d_raw;
+    std::vector<float> time = s->time;
+    std::vector<float> tilt_taper;
+    size_t nt_cur = s->nt;
+    bool tilt_as_multiplier = false;
+
+    // ---- Tilt Compensation: zero tilt is just its tail taper (a multiplier); otherwise the
+    // cube is re-laid out on an extended axis and the chain continues at the new length
+    if (cfg->tilt_active) {
+        const size_t steps = tilt_plan(time.data(), nt_cur, s->nx, s->ny, cfg->tilt_x_deg, cfg->tilt_y_deg,
+                                       s->dx, s->dy, nullptr, nullptr);
+        tilt_taper.resize(nt_cur);
+        adapted_blackman(time.data(), nt_cur, 0.0f, 7.0f, tilt_taper.data());
+        if (steps == 0) {
+            tilt_as_multiplier = true;
+        } else {
+            const size_t nt2 = nt_cur + 2 * steps;
+            std::vector<float> new_time(nt2);
+            std::vector<int32_t> ins(npix);
+            tilt_plan(time.data(), nt_cur, s->nx, s->ny, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx, s->dy,
+                      new_time.data(), ins.data());
+            if (int rc = dev_alloc(ctx, &s->d_tilt, npix * nt2)) return rc;
+            if (int rc = dev_alloc(ctx, &s->d_ins, npix)) return rc;
+            if (int rc = alloc_outputs(s, nt2)) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(s->d_ins, ins.data(), npix * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(s->d_vec, tilt_taper.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            launch_tilt(ctx->stream, npix, (int)nt_cur, (int)nt2, s->d_raw, s->d_vec, s->d_ins, s->d_tilt);
+            if (int rc = check_launch(ctx)) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            src = s->d_tilt;
+            time = new_time;
+            nt_cur = nt2;
+        }
+    }
+    if (int rc = alloc_outputs(s, nt_cur)) return rc;
+    if (int rc = thz_set_time_axis(ctx, time.data(), nt_cur)) return rc;  // (re)plan, data_thread.rs:1194-1227
+    s->time_out = time;
+    const size_t nf = nt_cur / 2 + 1;
+
+    // ---- multipliers in the reference's f32 order: ((tilt * td_before) * fft_window)
+    std::vector<float> pre(nt_cur, 1.0f), w(nt_cur), post(nt_cur, 1.0f), mask(nf, 1.0f);
+    if (tilt_as_multiplier) pre = tilt_taper;
+    if (cfg->td_before_active) {
+        double lo = cfg->td_before_low, hi = cfg->td_before_high;
+        td_bandpass(time.data(), nt_cur, &lo, &hi, cfg->td_before_width, w.data(), nullptr, nullptr);
+        for (size_t i = 0; i < nt_cur; ++i) pre[i] = pre[i] * w[i];
+    }
+    fft_window(cfg->fft_window.type, time.data(), nt_cur, cfg->fft_window.lower, cfg->fft_window.upper, w.data());
+    for (size_t i = 0; i < nt_cur; ++i) pre[i] = pre[i] * w[i];
+    if (cfg->fd_active)
+        fd_bandpass(ctx->freq.data(), nf, cfg->fd_low, cfg->fd_high, cfg->fd_width, mask.data(), nullptr, nullptr);
+    if (cfg->td_after_active) {
+        double lo = cfg->td_after_low, hi = cfg->td_after_high;
+        td_bandpass(time.data(), nt_cur, &lo, &hi, cfg->td_after_width, post.data(), nullptr, nullptr);
+    }
+    float *d_pre = s->d_vec, *d_post = s->d_vec + nt_cur, *d_mask = s->d_vec + 2 * nt_cur;
+    // keep the mask 16-byte aligned for the kernels' vector reads
+    d_mask = s->d_vec + ((2 * nt_cur + 3) & ~(size_t)3);
+    HIP_TRY(ctx, hipMemcpyAsync(d_pre, pre.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_post, post.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_mask, mask.data(), nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die at return
+
+    if (int rc = thz_pipeline(ctx, npix, src, d_pre, d_mask, d_post, s->d_fft, s->d_amp, s->d_ph, s->d_data, s->d_img))
+        return rc;
+    s->have_means = false;
+    if (cfg->want_means) {
+        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 2, s->d_fft, s->d_avg)) return rc;
+        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 1, s->d_amp, s->d_avg + 2 * nf)) return rc;
+        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 1, s->d_ph, s->d_avg + 3 * nf)) return rc;
+        s->have_means = true;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return THZ_OK;
+}
+
+size_t thz_session_nt_out(const thz_session *s) { return s ? s->nt_out : 0; }
+
+int thz_session_time_out(const thz_session *s, float *time)
+{
+    if (!s || !time) return THZ_ERR_INVALID;
+    std::memcpy(time, s->time_out.data(), s->time_out.size() * sizeof(float));
+    return THZ_OK;
+}
+
+void *thz_session_buffer(thz_session *s, int which)
+{
+    if (!s) return nullptr;
+    const size_t nf = s->nf_out;
+    switch (which) {
+    case THZ_BUF_RAW: return s->d_raw;
+    case THZ_BUF_FFT: return s->d_fft;
+    case THZ_BUF_AMPLITUDES: return s->d_amp;
+    case THZ_BUF_PHASES: return s->d_ph;
+    case THZ_BUF_DATA: return s->d_data;
+    case THZ_BUF_IMG: return s->d_img;
+    case THZ_BUF_AVG_FFT: return s->have_means ? s->d_avg : nullptr;
+    case THZ_BUF_AVG_AMPLITUDES: return s->have_means ? s->d_avg + 2 * nf : nullptr;
+    case THZ_BUF_AVG_PHASES: return s->have_means ? s->d_avg + 3 * nf : nullptr;
+    default: return nullptr;
+    }
+}
+
+int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst)
+{
+    if (!s || !dst) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    const float *base = static_cast<const float *>(thz_session_buffer(s, which));
+    if (!base) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_download: buffer not available");
+    size_t per = 0;  // floats per pixel
+    const size_t total_pix = s->nx * s->ny;
+    switch (which) {
+    case THZ_BUF_RAW: per = s->nt; break;
+    case THZ_BUF_FFT: per = 2 * s->nf_out; break;
+    case THZ_BUF_AMPLITUDES: case THZ_BUF_PHASES: per = s->nf_out; break;
+    case THZ_BUF_DATA: per = s->nt_out; break;
+    case THZ_BUF_IMG: per = 1; break;
+    case THZ_BUF_AVG_FFT: return thz_memcpy_d2h(ctx, dst, base, 2 * s->nf_out * sizeof(float));
+    case THZ_BUF_AVG_AMPLITUDES: case THZ_BUF_AVG_PHASES: return thz_memcpy_d2h(ctx, dst, base, s->nf_out * sizeof(float));
+    default: return THZ_ERR_INVALID;
+    }
+    if (pix0 + npix > total_pix) return fail(ctx, THZ_ERR_INVALID, "thz_session_download: pixel range out of bounds");
+    return thz_memcpy_d2h(ctx, dst, base + pix0 * per, npix * per * sizeof(float));
+}
+
+}  // extern "C"
