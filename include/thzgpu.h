@@ -403,6 +403,60 @@ void *thz_session_buffer(thz_session *s, int which);
  * tile, or everything */
 int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst);
 
+/* ------------------------------------------------------------------ */
+/* 3-D voxel envelope (gui/threed_plot.rs:80-276)                       */
+/* ------------------------------------------------------------------ */
+/* The data thread rebuilds the voxel instances of the 3-D tab after every
+ * recompute (update_intensity_image, data_thread.rs:48-101): per trace
+ * (v^2)^contrast -> 1-D Gaussian -> max / min rule; then the max_instances-th
+ * largest opacity of the whole cube (select_nth_unstable_by, :205-214) becomes
+ * the effective threshold and every voxel >= it becomes one instance. */
+typedef struct thz_voxel_cfg {
+    float opacity_threshold; /* gui_settings.opacity_threshold, application.rs:202 (0.1) */
+    float contrast;          /* contrast_3d (2.0) */
+    float sigma;             /* kernel_sigma (3.0) */
+    int32_t radius;          /* kernel_radius (9); slider 1..50 */
+} thz_voxel_cfg;
+
+/* bevy_voxel_plot::InstanceData as filled at threed_plot.rs:260-264 */
+typedef struct thz_voxel_instance {
+    float position[3];
+    float scale;
+    float color[4]; /* linear RGB of the jet colour, alpha = opacity */
+} thz_voxel_instance;
+
+#define THZ_VOXEL_MAX_INSTANCES 2000000u /* threed_plot.rs:206 */
+
+int thz_voxel_cfg_default(thz_voxel_cfg *out);
+/* gaussian_kernel1d (:80-101); out has 2*radius+1 entries */
+int thz_host_gaussian_kernel1d(float sigma, int radius, float *out);
+/* d_data (npix, nt) -> d_opacity (npix, nt), nt <= 8192; the two may not alias */
+int thz_voxel_opacity(thz_ctx *ctx, size_t npix, size_t nt, const float *d_data, const thz_voxel_cfg *cfg,
+                      float *d_opacity);
+/* Radix select, one level: d_hist (2048 u64, device) += histogram of the level's
+ * bits among the n values whose higher bits equal `prefix` (level 0: 11 bits of
+ * all values; level 1: next 11; level 2: last 10).  Histograms of the tiles of a
+ * cube add up, so ranks all-reduce d_hist between levels. */
+int thz_select_histogram(thz_ctx *ctx, const float *d_vals, size_t n, int level, uint32_t prefix,
+                         uint64_t *d_hist);
+/* host walk of one level: the bin holding the k-th largest (k >= 1) and its rank
+ * inside the bin; nbins = 2048 (levels 0, 1) or 1024 (level 2) */
+int thz_host_select_step(const uint64_t *hist, int nbins, uint64_t k, int *bin, uint64_t *k_rem);
+/* value from the three bins of the levels */
+float thz_host_select_value(int bin0, int bin1, int bin2);
+/* the three levels on one GPU: k-th largest of n values (1 <= k <= n) */
+int thz_kth_largest(thz_ctx *ctx, const float *d_vals, size_t n, uint64_t k, float *out);
+/* effective threshold (:205-214): 0.0 when n <= max_instances */
+int thz_voxel_threshold(thz_ctx *ctx, const float *d_opacity, size_t n, uint64_t max_instances, float *out);
+/* Instance loop (:216-271) over a (gw, gh, gd) opacity cube, in x, y, z order.
+ * x0 / gw_total place a tile of x-rows inside the whole grid (x0 = 0, gw_total =
+ * gw for one GPU).  Writes at most `capacity` records to d_out and the number of
+ * voxels >= threshold to *count; cube_dims = {cube_width, cube_height, cube_depth}. */
+int thz_voxel_instances(thz_ctx *ctx, const float *d_opacity, size_t gw, size_t gh, size_t gd, size_t x0,
+                        size_t gw_total, float threshold, float time_span, int scaling, size_t orig_w,
+                        size_t orig_h, size_t orig_d, thz_voxel_instance *d_out, uint64_t capacity,
+                        uint64_t *count, float *cube_dims);
+
 /* Per-stage device time of the most recent call of each kind, the value the
  * reference shows next to each filter (filter.rs:607-621).  `stage` is one
  * of the THZ_STAGE_* ids. */
@@ -415,7 +469,10 @@ enum {
     THZ_STAGE_INTENSITY = 5,
     THZ_STAGE_MEAN = 6,
     THZ_STAGE_ROI = 7,
-    THZ_STAGE_COUNT = 8
+    THZ_STAGE_VOXEL_OPACITY = 8,
+    THZ_STAGE_VOXEL_SELECT = 9,
+    THZ_STAGE_VOXEL_EMIT = 10,
+    THZ_STAGE_COUNT = 11
 };
 /* hipEvent bracketing of every stage call on the context's stream.
  *   0  off (default)

@@ -682,6 +682,7 @@ void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny
 }
 
 #include "thz_oracle_deconv.c"
+#include "thz_oracle_voxel.c"
 
 int thz_oracle_max_threads(void)
 {

@@ -1,9 +1,12 @@
 """Prints VGPR/SGPR/scratch/occupancy per kernel from hipcc's
 -Rpass-analysis=kernel-resource-usage (developer tool)."""
 import re, subprocess, sys, os
+SRC = "kernels.hip"
+if len(sys.argv) > 1 and sys.argv[1].endswith(".hip"):
+    SRC = sys.argv.pop(1)
 src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "thz_image_explorer_amd", "csrc")
 out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-                      "kernels.hip", "-o", "/tmp/_k.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:],
+                      SRC, "-o", "/tmp/_k.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:],
                      cwd=src, stderr=subprocess.PIPE, text=True).stderr
 cur = None
 rows = []

@@ -74,3 +74,35 @@ extern "C" void emu_fast_atan2(const float *y, const float *x, int n, float *out
 {
     for (int i = 0; i < n; ++i) out[i] = thz::fast_atan2f(y[i], x[i]);
 }
+
+// ---- K15 voxel envelope (voxel.hip)
+extern "C" {
+
+int emu_voxel_opacity(size_t npix, int nt, const float *data, const float *kernel, int radius, float contrast,
+                      float opacity_threshold, float *out)
+{
+    VoxelTaps taps;
+    for (int i = 0; i < kVoxTaps; ++i) taps.c[i] = 0.0f;
+    if (radius <= kVoxPad)
+        for (int i = 0; i <= 2 * radius; ++i) taps.c[i + (kVoxPad - radius)] = kernel[i];
+    return launch_voxel_opacity(nullptr, npix, nt, data, taps, kernel, radius, contrast, opacity_threshold, out) ? 0 : -2;
+}
+
+int emu_select_hist(const float *vals, size_t n, int level, uint32_t prefix, unsigned long long *hist)
+{
+    launch_select_hist(nullptr, vals, n, level, prefix, hist);
+    return 0;
+}
+
+int emu_voxel_instances(size_t npix, int nt, size_t gh, const float *opacity, const float *geom8, size_t x0,
+                        float *out, unsigned long long capacity, unsigned long long *total)
+{
+    std::vector<uint32_t> counts(npix);
+    std::vector<unsigned long long> offsets(npix), tiles((npix + 2047) / 2048 + 1);
+    VoxelGeom g{geom8[0], geom8[1], geom8[2], geom8[3], geom8[4], geom8[5], geom8[6], geom8[7], x0};
+    launch_voxel_count(nullptr, npix, nt, opacity, g.threshold, counts.data());
+    launch_scan_counts(nullptr, counts.data(), npix, tiles.data(), offsets.data(), total);
+    launch_voxel_emit(nullptr, npix, nt, gh, opacity, offsets.data(), g, out, capacity);
+    return 0;
+}
+}

@@ -34,6 +34,10 @@ struct float2 {
 struct float4 {
     float x, y, z, w;
 };
+struct uint4 {
+    unsigned int x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned int x, unsigned int y, unsigned int z, unsigned int w) { return uint4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 

@@ -334,6 +334,47 @@ def deconvolution(data, time, dx, dy, psf, n_iterations, n_filters, start_freq, 
     return rc, out, img, gains, niter
 
 
+# ---- 3-D voxel envelope (oracle/thz_oracle_voxel.c) ------------------------------
+VOXEL_INSTANCE = np.dtype([("position", np.float32, 3), ("scale", np.float32), ("color", np.float32, 4)])
+
+
+def gaussian_kernel1d(sigma, radius):
+    out = np.empty(2 * radius + 1, np.float32)
+    lib().thz_oracle_gaussian_kernel1d(C.c_float(sigma), C.c_int(radius), _p(out))
+    return out
+
+
+def voxel_opacity(data, sigma=3.0, radius=9, contrast=2.0, opacity_threshold=0.1):
+    d = f32(data)
+    nt = d.shape[-1]
+    out = np.empty_like(d)
+    lib().thz_oracle_voxel_opacity(_p(d), C.c_size_t(d.size // nt), C.c_int(nt), C.c_float(sigma), C.c_int(radius),
+                                   C.c_float(contrast), C.c_float(opacity_threshold), _p(out))
+    return out
+
+
+def voxel_threshold(opacity, max_instances=2_000_000):
+    o = f32(opacity)
+    L = lib()
+    L.thz_oracle_voxel_threshold.restype = C.c_float
+    return float(L.thz_oracle_voxel_threshold(_p(o), C.c_size_t(o.size), C.c_size_t(max_instances)))
+
+
+def voxel_instances(opacity, threshold, time_span, scaling, orig_dims):
+    """-> (instances structured array, (cube_width, cube_height, cube_depth))"""
+    o = f32(opacity)
+    gw, gh, gd = o.shape
+    L = lib()
+    L.thz_oracle_voxel_instances.restype = C.c_size_t
+    dims = np.zeros(3, np.float32)
+    args = [_p(o), C.c_size_t(gw), C.c_size_t(gh), C.c_size_t(gd), C.c_float(threshold), C.c_float(time_span),
+            C.c_int(scaling), C.c_size_t(orig_dims[0]), C.c_size_t(orig_dims[1]), C.c_size_t(orig_dims[2])]
+    n = L.thz_oracle_voxel_instances(*args, None, C.c_size_t(0), _p(dims))
+    out = np.zeros(n, VOXEL_INSTANCE)
+    L.thz_oracle_voxel_instances(*args, _p(out), C.c_size_t(n), _p(dims))
+    return out, tuple(float(x) for x in dims)
+
+
 def max_threads():
     return int(lib().thz_oracle_max_threads())
 

@@ -21,7 +21,7 @@ STATUS = {0: "THZ_OK", -1: "THZ_ERR_INVALID", -2: "THZ_ERR_UNSUPPORTED", -3: "TH
 
 WIN_ADAPTED_BLACKMAN, WIN_BLACKMAN, WIN_HANNING, WIN_HAMMING, WIN_FLAT_TOP = range(5)
 STAGE_FFT, STAGE_FD_MASK, STAGE_IFFT, STAGE_PIPELINE, STAGE_TD_WINDOW, STAGE_INTENSITY, \
-    STAGE_MEAN, STAGE_ROI = range(8)
+    STAGE_MEAN, STAGE_ROI, STAGE_VOXEL_OPACITY, STAGE_VOXEL_SELECT, STAGE_VOXEL_EMIT = range(11)
 
 
 class WindowCfg(C.Structure):
@@ -72,6 +72,15 @@ def psf_from_npz(z) -> "Psf":
     psf.y0_spline = spline("y0_", "y0_knots_thz", "y0_values_mm")
     psf._keep = keep
     return psf
+
+
+class VoxelCfg(C.Structure):
+    _fields_ = [("opacity_threshold", C.c_float), ("contrast", C.c_float), ("sigma", C.c_float),
+                ("radius", C.c_int32)]
+
+
+VOXEL_INSTANCE = np.dtype([("position", np.float32, 3), ("scale", np.float32), ("color", np.float32, 4)])
+VOXEL_MAX_INSTANCES = 2_000_000
 
 
 class ChainCfg(C.Structure):
@@ -154,6 +163,16 @@ SYMBOLS = [
     ("thz_session_time_out", C.c_int, [_P, _P]),
     ("thz_session_buffer", _P, [_P, C.c_int]),
     ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
+    ("thz_voxel_cfg_default", C.c_int, [C.POINTER(VoxelCfg)]),
+    ("thz_host_gaussian_kernel1d", C.c_int, [C.c_float, C.c_int, _P]),
+    ("thz_voxel_opacity", C.c_int, [_P, _SZ, _SZ, _P, C.POINTER(VoxelCfg), _P]),
+    ("thz_select_histogram", C.c_int, [_P, _P, _SZ, C.c_int, C.c_uint32, _P]),
+    ("thz_host_select_step", C.c_int, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    ("thz_host_select_value", C.c_float, [C.c_int, C.c_int, C.c_int]),
+    ("thz_kth_largest", C.c_int, [_P, _P, _SZ, C.c_uint64, C.POINTER(C.c_float)]),
+    ("thz_voxel_threshold", C.c_int, [_P, _P, _SZ, C.c_uint64, C.POINTER(C.c_float)]),
+    ("thz_voxel_instances", C.c_int, [_P, _P, _SZ, _SZ, _SZ, _SZ, _SZ, C.c_float, C.c_float, C.c_int, _SZ, _SZ,
+                                      _SZ, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("thz_enable_timing", C.c_int, [_P, C.c_int]),
     ("thz_stage_time_ns", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
     ("thz_timing_collect", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -284,6 +303,30 @@ def host_band_psf(psf: Psf, center_freq, dx, dy, img_rows, img_cols):
     _rc(L.thz_host_band_psf(C.byref(psf), center_freq, dx, dy, img_rows, img_cols, out.ctypes.data,
                             C.byref(r), C.byref(c)), "band_psf")
     return out
+
+
+def voxel_cfg_default() -> VoxelCfg:
+    cfg = VoxelCfg()
+    _rc(load_library().thz_voxel_cfg_default(C.byref(cfg)), "voxel_cfg_default")
+    return cfg
+
+
+def host_gaussian_kernel1d(sigma, radius):
+    out = np.empty(2 * radius + 1, np.float32)
+    _rc(load_library().thz_host_gaussian_kernel1d(sigma, radius, out.ctypes.data), "gaussian_kernel1d")
+    return out
+
+
+def host_select_step(hist, k):
+    """one level of the radix select -> (bin, rank inside the bin)"""
+    h = np.ascontiguousarray(hist, np.uint64)
+    b, r = C.c_int(), C.c_uint64()
+    _rc(load_library().thz_host_select_step(h.ctypes.data, h.size, int(k), C.byref(b), C.byref(r)), "select_step")
+    return b.value, r.value
+
+
+def host_select_value(bin0, bin1, bin2) -> float:
+    return float(load_library().thz_host_select_value(bin0, bin1, bin2))
 
 
 def chain_cfg_default(time) -> ChainCfg:
@@ -506,6 +549,33 @@ class Engine:
         if rc < 0:
             self._check(rc)
         return rc
+
+    def voxel_opacity(self, npix, nt, d_data, cfg: VoxelCfg, d_opacity):
+        self._check(self.lib.thz_voxel_opacity(self.ctx, npix, nt, _dp(d_data), C.byref(cfg), _dp(d_opacity)))
+
+    def select_histogram(self, d_vals, n, level, prefix, d_hist):
+        self._check(self.lib.thz_select_histogram(self.ctx, _dp(d_vals), n, level, prefix, _dp(d_hist)))
+
+    def kth_largest(self, d_vals, n, k) -> float:
+        v = C.c_float()
+        self._check(self.lib.thz_kth_largest(self.ctx, _dp(d_vals), n, k, C.byref(v)))
+        return v.value
+
+    def voxel_threshold(self, d_opacity, n, max_instances=VOXEL_MAX_INSTANCES) -> float:
+        v = C.c_float()
+        self._check(self.lib.thz_voxel_threshold(self.ctx, _dp(d_opacity), n, max_instances, C.byref(v)))
+        return v.value
+
+    def voxel_instances(self, d_opacity, gw, gh, gd, threshold, time_span, scaling, orig_dims, d_out, capacity,
+                        x0=0, gw_total=None):
+        """-> (count, (cube_width, cube_height, cube_depth))"""
+        n = C.c_uint64()
+        dims = np.zeros(3, np.float32)
+        self._check(self.lib.thz_voxel_instances(self.ctx, _dp(d_opacity), gw, gh, gd, x0,
+                                                 gw if gw_total is None else gw_total, threshold, time_span,
+                                                 scaling, orig_dims[0], orig_dims[1], orig_dims[2], _dp(d_out),
+                                                 capacity, C.byref(n), dims.ctypes.data))
+        return n.value, tuple(float(x) for x in dims)
 
     def synth_cube(self, d_out, ntraces, first_trace, d_time, seed=0x7A3D2026, subtract_bias=True):
         self._check(self.lib.thz_synth_cube(self.ctx, _dp(d_out), ntraces, first_trace, _dp(d_time),

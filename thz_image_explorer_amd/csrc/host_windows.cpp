@@ -189,4 +189,57 @@ size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt
     return num_steps;
 }
 
+// ---- 3-D voxel envelope, gui/threed_plot.rs
+
+// gaussian_kernel1d, threed_plot.rs:80-101
+void gaussian_kernel1d(float sigma, int radius, float *out)
+{
+    const int size = 2 * radius + 1;
+    const float sigma2 = 2.0f * sigma * sigma;
+    float sum = 0.0f;
+    for (int i = 0; i < size; ++i) {
+        const float x = (float)i - (float)radius;
+        const float value = std::exp(-x * x / sigma2);
+        sum += value;
+        out[i] = value;
+    }
+    for (int i = 0; i < size; ++i) out[i] /= sum;
+}
+
+// cube size, spacing and half extents of instance_from_data, threed_plot.rs:147-160, 225-231
+VoxelLayout voxel_layout(float time_span, size_t gw, size_t gh, size_t gd, size_t ow, size_t oh, size_t od)
+{
+    VoxelLayout L;
+    const float base = 1.0f / 4.0f;
+    const float c = 300000000.0f;
+    L.cube_width = base;
+    L.cube_height = base;
+    L.cube_depth = base / (time_span * c / 1.0e9f * 2.0f);
+    L.spacing_w = ((float)ow * L.cube_width) / (float)gw;
+    L.spacing_h = ((float)oh * L.cube_height) / (float)gh;
+    L.spacing_d = ((float)od * L.cube_depth) / (float)gd;
+    L.half_w = ((float)ow * base) / 2.0f;
+    L.half_h = ((float)oh * base) / 2.0f;
+    L.half_d = ((float)od * L.cube_depth) / 2.0f;
+    return L;
+}
+
+// One level of the radix select for the k-th largest value (k >= 1): walks the
+// histogram from the top bin down; *bin holds the value, *k_rem its rank inside
+// that bin.  Returns 0, or -1 when the histogram holds fewer than k values.
+int select_step(const unsigned long long *hist, int nbins, unsigned long long k, int *bin,
+                unsigned long long *k_rem)
+{
+    unsigned long long above = 0;
+    for (int b = nbins - 1; b >= 0; --b) {
+        if (above + hist[b] >= k) {
+            *bin = b;
+            *k_rem = k - above;
+            return 0;
+        }
+        above += hist[b];
+    }
+    return -1;
+}
+
 }  // namespace thz

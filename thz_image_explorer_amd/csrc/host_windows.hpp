@@ -15,4 +15,12 @@ void water_line_mask(const float *freq, size_t nf, const float *lines, size_t n_
 void wiener_filter(const float *ref_fft, size_t nf, float eps_rel, float *out);
 size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
                  double tilt_y_deg, float dx, float dy, float *new_time, int32_t *insert_index);
+void gaussian_kernel1d(float sigma, int radius, float *out);
+struct VoxelLayout {
+    float cube_width, cube_height, cube_depth;
+    float spacing_w, spacing_h, spacing_d, half_w, half_h, half_d;
+};
+VoxelLayout voxel_layout(float time_span, size_t gw, size_t gh, size_t gd, size_t ow, size_t oh, size_t od);
+int select_step(const unsigned long long *hist, int nbins, unsigned long long k, int *bin,
+                unsigned long long *k_rem);
 }  // namespace thz

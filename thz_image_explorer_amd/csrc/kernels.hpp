@@ -91,6 +91,31 @@ void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size
 
 void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float *in,
                  const float *taper, const int *insert_index, float *out);
+// ---- K15 voxel envelope (voxel.hip)
+constexpr int kVoxPad = 12;                // register-window path: radius <= kVoxPad
+constexpr int kVoxTaps = 2 * kVoxPad + 1;  // zero-padded tap vector
+constexpr int kVoxMaxNt = 8192;
+constexpr int kSelBins = 2048;
+struct VoxelTaps {
+    float c[kVoxTaps];
+};
+struct VoxelGeom {
+    float spacing_w, spacing_h, spacing_d, half_w, half_h, half_d, scale, threshold;
+    size_t x0;  // first x-row of this tile in the whole grid
+};
+bool launch_voxel_opacity(hipStream_t st, size_t npix, int nt, const float *data, const VoxelTaps &taps,
+                          const float *wide_taps, int radius, float contrast, float opacity_threshold,
+                          float *out);
+void launch_select_hist(hipStream_t st, const float *vals, size_t n, int level, uint32_t prefix,
+                        unsigned long long *hist);
+void launch_voxel_count(hipStream_t st, size_t npix, int nt, const float *opacity, float threshold,
+                        uint32_t *counts);
+void launch_scan_counts(hipStream_t st, const uint32_t *counts, size_t n, unsigned long long *tile_ws,
+                        unsigned long long *offsets, unsigned long long *total);
+void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const float *opacity,
+                       const unsigned long long *offsets, const VoxelGeom &g, float *out,
+                       unsigned long long capacity);
+
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,
                   const float *time, uint32_t seed, int subtract_bias);
 

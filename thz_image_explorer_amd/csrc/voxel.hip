@@ -1,0 +1,537 @@
+// voxel.hip — K15: the 3-D voxel envelope the data thread rebuilds after every
+// recompute (update_intensity_image, data_thread.rs:48-101 ->
+// instance_from_data, gui/threed_plot.rs:132-276).
+//
+//   k_voxel_opacity   per trace: (v^2)^contrast, 1-D Gaussian, max/min rule     (HBM: 8 nt B/trace)
+//   k_select_hist     radix select of the max_instances-th largest opacity:
+//                     three 11/11/10-bit histogram levels over the cube          (HBM: 4 B/voxel/level)
+//   k_voxel_count / k_scan_* / k_voxel_emit
+//                     ordered compaction of the voxels >= threshold into
+//                     InstanceData records (position, scale, colour)             (HBM: 4 B/voxel each)
+//
+// Built with -ffp-contract=off: instance positions follow the reference's separate
+// multiply and subtract (HIP's __fmul_rn is a plain product and would still fuse);
+// the convolution asks for its FMAs explicitly.
+//
+// All of it is HBM-bound streaming over the (nx, ny, nt) f32 cube; one wave owns
+// one trace at a time like every other kernel of the engine.
+#include "kernels.hpp"
+#include "thz_device.hpp"
+
+#include <math.h>
+
+namespace thz {
+
+#ifndef THZ_EMU
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t wave_read_lane_u32(uint32_t v, int lane_uniform)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform);
+}
+__device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int ffs64(uint64_t m) { return __ffsll((unsigned long long)m); }
+#else
+inline uint64_t wave_ballot(bool p)
+{
+    uint64_t m = 0;
+    for (int i = 0; i < 64; ++i)
+        if (wave_shfl(p ? 1.0f : 0.0f, i) != 0.0f) m |= (uint64_t)1 << i;
+    return m;
+}
+inline uint32_t wave_read_lane_u32(uint32_t v, int lane)
+{
+    return __builtin_bit_cast(uint32_t, wave_shfl(__builtin_bit_cast(float, v), lane));
+}
+inline float hw_exp2(float x) { return exp2f(x); }
+inline float hw_log2(float x) { return log2f(x); }
+inline float mul_rn(float a, float b) { return a * b; }
+inline float sub_rn(float a, float b) { return a - b; }
+inline float div_rn(float a, float b) { return a / b; }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+inline int ffs64(uint64_t m) { return __builtin_ffsll((long long)m); }
+static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
+{
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+#endif
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, wave_shfl_xor(v, m));
+    return v;
+}
+
+// ------------------------------------------------------------------ opacity
+// (v^2)^contrast: powi(2) then powf(contrast), threed_plot.rs:169 and :113.
+// pow_mode 1 / 2: contrast is exactly 1 / 2 (the default) -> plain products.
+__device__ __forceinline__ float vox_pow(float v, float contrast, int pow_mode)
+{
+    const float q = v * v;
+    if (pow_mode == 2) return q * q;
+    if (pow_mode == 1) return q;
+    return hw_exp2(contrast * hw_log2(q));  // q = 0 -> exp2(-inf) = 0
+}
+
+template <int NQ, bool VEC>
+__device__ __forceinline__ void vox_load(const float *__restrict__ src, int nt, int lane, float4 (&cur)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = q * 256 + 4 * lane;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (VEC) {
+            if (e < nt) v = *reinterpret_cast<const float4 *>(src + e);
+        } else {
+            if (e + 0 < nt) v.x = src[e + 0];
+            if (e + 1 < nt) v.y = src[e + 1];
+            if (e + 2 < nt) v.z = src[e + 2];
+            if (e + 3 < nt) v.w = src[e + 3];
+        }
+        cur[q] = v;
+    }
+}
+
+// One wave per trace.  The powered samples go to the wave's LDS slice
+// [pad zeros | NQ*256 samples (zeros past nt) | pad zeros]; every lane then owns
+// the quads e = 256 q + 4 lane.
+//  * WIDE = false (radius <= kVoxPad): the 4 + 2*kVoxPad samples around a quad are
+//    read once with seven ds_read_b128 and the kernel runs over a zero-padded
+//    25-tap vector held in SGPRs — adding tap*0 keeps the reference's k-ascending
+//    summation of the real taps;
+//  * WIDE = true: any radius, one LDS read per tap and output.
+// Out-of-range taps are skipped by the reference (threed_plot.rs:112); reading a
+// zero adds +0.
+template <int NQ, bool VEC, bool WIDE>
+__global__ __launch_bounds__(256) void k_voxel_opacity(size_t npix, int nt, const float *__restrict__ data,
+                                                       VoxelTaps taps, const float *__restrict__ wide_taps,
+                                                       int radius, int pad, float contrast, int pow_mode,
+                                                       float opacity_threshold, float *__restrict__ out)
+{
+    constexpr bool PREFETCH = NQ <= 16;
+    THZ_DYN_LDS(smem);
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const int slice = NQ * 256 + 2 * pad;
+    float *lds = reinterpret_cast<float *>(smem) + (size_t)wave * slice;
+    for (int i = lane; i < slice; i += kWave) lds[i] = 0.0f;
+    wave_sync();
+
+    const size_t stride = (size_t)gridDim.x * wpb;
+    size_t trace = (size_t)blockIdx.x * wpb + wave;
+    float4 cur[NQ];
+    if (trace < npix) vox_load<NQ, VEC>(data + trace * (size_t)nt, nt, lane, cur);
+    for (; trace < npix; trace += stride) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = q * 256 + 4 * lane;
+            float4 p;
+            p.x = vox_pow(cur[q].x, contrast, pow_mode);
+            p.y = vox_pow(cur[q].y, contrast, pow_mode);
+            p.z = vox_pow(cur[q].z, contrast, pow_mode);
+            p.w = vox_pow(cur[q].w, contrast, pow_mode);
+            *reinterpret_cast<float4 *>(lds + pad + e) = p;  // samples past nt were loaded as 0
+        }
+        wave_sync();
+        const size_t next = trace + stride;
+        if (PREFETCH && next < npix) vox_load<NQ, VEC>(data + next * (size_t)nt, nt, lane, cur);
+
+        float4 o[NQ];
+        float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = q * 256 + 4 * lane;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if constexpr (!WIDE) {
+                // lds[e + j] = p[e + j - kVoxPad], j = 0 .. 27
+                float w[4 + 2 * kVoxPad];
+#pragma unroll
+                for (int j = 0; j < (4 + 2 * kVoxPad) / 4; ++j) {
+                    const float4 t = *reinterpret_cast<const float4 *>(lds + e + 4 * j);
+                    w[4 * j + 0] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
+                }
+#pragma unroll
+                for (int k = 0; k < kVoxTaps; ++k) {
+                    const float c = taps.c[k];
+                    a0 = fmaf(w[k + 0], c, a0);
+                    a1 = fmaf(w[k + 1], c, a1);
+                    a2 = fmaf(w[k + 2], c, a2);
+                    a3 = fmaf(w[k + 3], c, a3);
+                }
+            } else {
+                const float *w = lds + pad + e - radius;  // w[k + o] = p[e + o + k - radius]
+                for (int k = 0; k <= 2 * radius; ++k) {
+                    const float c = wide_taps[k];
+                    a0 = fmaf(w[k + 0], c, a0);
+                    a1 = fmaf(w[k + 1], c, a1);
+                    a2 = fmaf(w[k + 2], c, a2);
+                    a3 = fmaf(w[k + 3], c, a3);
+                }
+            }
+            if (e + 0 < nt) { mx = fmaxf(mx, a0); mn = fminf(mn, a0); }
+            if (e + 1 < nt) { mx = fmaxf(mx, a1); mn = fminf(mn, a1); }
+            if (e + 2 < nt) { mx = fmaxf(mx, a2); mn = fminf(mn, a2); }
+            if (e + 3 < nt) { mx = fmaxf(mx, a3); mn = fminf(mn, a3); }
+            o[q] = make_float4(a0, a1, a2, a3);
+        }
+        mx = wave_max(mx);
+        mn = wave_min(mn);
+        // threed_plot.rs:181-199: whole line zero below the opacity threshold or when flat
+        const bool keep = !(mx < opacity_threshold) && fabsf(mx - mn) > 1e-6f;
+        const float range = mx - mn;
+        float *dst = out + trace * (size_t)nt;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = q * 256 + 4 * lane;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (keep) {
+                r.x = div_rn(o[q].x - mn, range);
+                r.y = div_rn(o[q].y - mn, range);
+                r.z = div_rn(o[q].z - mn, range);
+                r.w = div_rn(o[q].w - mn, range);
+            }
+            if constexpr (VEC) {
+                if (e < nt) *reinterpret_cast<float4 *>(dst + e) = r;
+            } else {
+                if (e + 0 < nt) dst[e + 0] = r.x;
+                if (e + 1 < nt) dst[e + 1] = r.y;
+                if (e + 2 < nt) dst[e + 2] = r.z;
+                if (e + 3 < nt) dst[e + 3] = r.w;
+            }
+        }
+        wave_sync();  // the slice is rewritten by the next trace
+        if (!PREFETCH && next < npix) vox_load<NQ, VEC>(data + next * (size_t)nt, nt, lane, cur);
+    }
+}
+
+template <int NQ, bool VEC, bool WIDE>
+static void launch_voxel_opacity_t(hipStream_t st, size_t npix, int nt, const float *data, const VoxelTaps &taps,
+                                   const float *wide_taps, int radius, float contrast, int pow_mode,
+                                   float opacity_threshold, float *out)
+{
+    const int pad = WIDE ? ((radius + 3) & ~3) : kVoxPad;
+    const int wpb = 4;
+    const size_t lds = (size_t)wpb * (NQ * 256 + 2 * pad) * sizeof(float);
+    size_t blocks = (npix + wpb - 1) / wpb;
+    // persistent-ish grid: enough blocks for every CU's LDS, the waves stride over the traces
+    const size_t per_cu = lds ? (160 * 1024) / lds : 8;
+    const size_t cap = 256 * (per_cu ? (per_cu > 8 ? 8 : per_cu) : 1);
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) return;
+    THZ_LAUNCH((k_voxel_opacity<NQ, VEC, WIDE>), blocks, wpb * kWave, lds, st, npix, nt, data, taps, wide_taps,
+               radius, pad, contrast, pow_mode, opacity_threshold, out);
+}
+
+template <bool VEC, bool WIDE>
+static bool launch_voxel_opacity_q(hipStream_t st, size_t npix, int nt, const float *data, const VoxelTaps &taps,
+                                   const float *wide_taps, int radius, float contrast, int pow_mode,
+                                   float opacity_threshold, float *out)
+{
+    const int nq = (nt + 255) / 256;
+#define THZ_VOX_CASE(N)                                                                                      \
+    if (nq <= N) {                                                                                           \
+        launch_voxel_opacity_t<N, VEC, WIDE>(st, npix, nt, data, taps, wide_taps, radius, contrast, pow_mode, \
+                                             opacity_threshold, out);                                        \
+        return true;                                                                                         \
+    }
+    THZ_VOX_CASE(1)
+    THZ_VOX_CASE(2)
+    THZ_VOX_CASE(4)
+    THZ_VOX_CASE(8)
+    THZ_VOX_CASE(16)
+    THZ_VOX_CASE(32)
+#undef THZ_VOX_CASE
+    return false;
+}
+
+bool launch_voxel_opacity(hipStream_t st, size_t npix, int nt, const float *data, const VoxelTaps &taps,
+                          const float *wide_taps, int radius, float contrast, float opacity_threshold,
+                          float *out)
+{
+    if (nt < 1 || nt > kVoxMaxNt) return false;
+    const int pow_mode = contrast == 2.0f ? 2 : (contrast == 1.0f ? 1 : 0);
+    const bool vec = (nt % 4 == 0) && ((uintptr_t)data % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const bool wide = radius > kVoxPad;
+    if (wide && !wide_taps) return false;
+    if (vec)
+        return wide ? launch_voxel_opacity_q<true, true>(st, npix, nt, data, taps, wide_taps, radius, contrast,
+                                                         pow_mode, opacity_threshold, out)
+                    : launch_voxel_opacity_q<true, false>(st, npix, nt, data, taps, wide_taps, radius, contrast,
+                                                          pow_mode, opacity_threshold, out);
+    return wide ? launch_voxel_opacity_q<false, true>(st, npix, nt, data, taps, wide_taps, radius, contrast,
+                                                      pow_mode, opacity_threshold, out)
+                : launch_voxel_opacity_q<false, false>(st, npix, nt, data, taps, wide_taps, radius, contrast,
+                                                       pow_mode, opacity_threshold, out);
+}
+
+// ------------------------------------------------------------- radix select
+// Order-preserving key of an f32: larger float <=> larger key (negative values
+// included, although opacities are never negative).
+__device__ __forceinline__ uint32_t sel_key(uint32_t bits)
+{
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+
+// One key into the block's LDS histogram.  Neighbouring samples of a smooth
+// envelope (and the many exact zeros) fall into the same bin, which would
+// serialise a plain LDS atomic 64 ways; a few ballot rounds first merge the lanes
+// that agree with the lowest active lane, whatever is left goes in one by one.
+__device__ __forceinline__ void sel_add(unsigned int *h, uint32_t key, bool active, int level, uint32_t prefix)
+{
+    uint32_t bin;
+    if (level == 0) {
+        bin = key >> 21;
+    } else if (level == 1) {
+        active = active && (key >> 21) == prefix;
+        bin = (key >> 10) & 2047u;
+    } else {
+        active = active && (key >> 10) == prefix;
+        bin = key & 1023u;
+    }
+    const int lane = lane_id();
+    uint64_t m = wave_ballot(active);
+    for (int round = 0; round < 4 && m != 0; ++round) {
+        const int first = ffs64(m) - 1;
+        const uint32_t b0 = wave_read_lane_u32(bin, first);
+        const uint64_t same = wave_ballot(active && bin == b0);
+        if (lane == first) atomicAdd(&h[b0], (unsigned int)popc64(same));
+        active = active && bin != b0;
+        m &= ~same;
+    }
+    if (active) atomicAdd(&h[bin], 1u);
+}
+
+// hist[bin] += number of keys of this level's bin among the values whose higher
+// bits equal `prefix` (level 0: all values).  hist has kSelBins entries.
+__global__ __launch_bounds__(256) void k_select_hist(const uint32_t *__restrict__ vals, size_t n, int level,
+                                                     uint32_t prefix, unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned int h[kSelBins];
+    for (int i = (int)threadIdx.x; i < kSelBins; i += (int)blockDim.x) h[i] = 0u;
+    __syncthreads();
+    const size_t nq = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t iters = (nq + stride - 1) / stride;  // same trip count in every lane: the ballots stay wave-uniform
+    const uint4 *v4 = reinterpret_cast<const uint4 *>(vals);
+    for (size_t it = 0; it < iters; ++it) {
+        const size_t q = first + it * stride;
+        const bool in = q < nq;
+        uint4 k = make_uint4(0u, 0u, 0u, 0u);
+        if (in) k = v4[q];
+        sel_add(h, sel_key(k.x), in, level, prefix);
+        sel_add(h, sel_key(k.y), in, level, prefix);
+        sel_add(h, sel_key(k.z), in, level, prefix);
+        sel_add(h, sel_key(k.w), in, level, prefix);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kWave) {  // the n % 4 tail
+        const size_t i = nq * 4 + threadIdx.x;
+        const bool in = i < n;
+        const uint32_t k = in ? vals[i] : 0u;
+        sel_add(h, sel_key(k), in, level, prefix);
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < kSelBins; i += (int)blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+void launch_select_hist(hipStream_t st, const float *vals, size_t n, int level, uint32_t prefix,
+                        unsigned long long *hist)
+{
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    THZ_LAUNCH(k_select_hist, blocks, 256, 0, st, reinterpret_cast<const uint32_t *>(vals), n, level, prefix, hist);
+}
+
+// ------------------------------------------------- ordered compaction: counts
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_voxel_count(size_t npix, int nt, const float *__restrict__ opacity,
+                                                     float threshold, uint32_t *__restrict__ counts)
+{
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    const size_t stride = (size_t)gridDim.x * wpb;
+    for (size_t trace = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); trace < npix; trace += stride) {
+        const float *src = opacity + trace * (size_t)nt;
+        float c = 0.0f;  // <= nt < 2^24: exact
+        if constexpr (VEC) {
+            for (int e = 4 * lane; e < nt; e += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + e);
+                c += (v.x >= threshold ? 1.0f : 0.0f) + (v.y >= threshold ? 1.0f : 0.0f)
+                     + (v.z >= threshold ? 1.0f : 0.0f) + (v.w >= threshold ? 1.0f : 0.0f);
+            }
+        } else {
+            for (int e = lane; e < nt; e += kWave) c += src[e] >= threshold ? 1.0f : 0.0f;
+        }
+        c = wave_reduce_add(c);
+        if (lane == 0) counts[trace] = (uint32_t)c;
+    }
+}
+
+void launch_voxel_count(hipStream_t st, size_t npix, int nt, const float *opacity, float threshold,
+                        uint32_t *counts)
+{
+    size_t blocks = (npix + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return;
+    if (nt % 4 == 0 && (uintptr_t)opacity % 16 == 0)
+        THZ_LAUNCH(k_voxel_count<true>, blocks, 256, 0, st, npix, nt, opacity, threshold, counts);
+    else
+        THZ_LAUNCH(k_voxel_count<false>, blocks, 256, 0, st, npix, nt, opacity, threshold, counts);
+}
+
+// ---------------------------------------- exclusive scan counts(u32) -> offsets(u64)
+constexpr int kScanTile = 2048;  // counts per block: 256 threads x 8
+
+// exclusive scan of one value per thread over the block; returns the block total
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *sh,
+                                                              unsigned long long *total)
+{
+    const int t = (int)threadIdx.x, n = (int)blockDim.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < n; d <<= 1) {
+        const unsigned long long add = t >= d ? sh[t - d] : 0ull;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    const unsigned long long incl = sh[t];
+    *total = sh[n - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t *__restrict__ counts, size_t n,
+                                                        unsigned long long *__restrict__ tile_sums)
+{
+    __shared__ unsigned long long sh[256];
+    const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
+    unsigned long long s = 0;
+    for (int j = 0; j < 8; ++j)
+        if (base + j < n) s += counts[base + j];
+    unsigned long long total;
+    (void)block_excl_scan(s, sh, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single block: tile_sums -> exclusive offsets in place, grand total to *total
+__global__ __launch_bounds__(256) void k_scan_tile_offsets(unsigned long long *__restrict__ tile_sums, size_t ntiles,
+                                                           unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long sh[256];
+    unsigned long long carry = 0;
+    for (size_t base = 0; base < ntiles; base += blockDim.x) {
+        const size_t i = base + threadIdx.x;
+        const unsigned long long v = i < ntiles ? tile_sums[i] : 0ull;
+        unsigned long long chunk;
+        const unsigned long long ex = block_excl_scan(v, sh, &chunk);
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        carry += chunk;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ counts, size_t n,
+                                                    const unsigned long long *__restrict__ tile_offsets,
+                                                    unsigned long long *__restrict__ offsets)
+{
+    __shared__ unsigned long long sh[256];
+    const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
+    uint32_t c[8];
+    unsigned long long s = 0;
+    for (int j = 0; j < 8; ++j) {
+        c[j] = base + j < n ? counts[base + j] : 0u;
+        s += c[j];
+    }
+    unsigned long long total;
+    unsigned long long run = tile_offsets[blockIdx.x] + block_excl_scan(s, sh, &total);
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < n) offsets[base + j] = run;
+        run += c[j];
+    }
+}
+
+// counts[n] -> offsets[n] (exclusive), *total; tile_ws holds ceil(n / kScanTile) u64
+void launch_scan_counts(hipStream_t st, const uint32_t *counts, size_t n, unsigned long long *tile_ws,
+                        unsigned long long *offsets, unsigned long long *total)
+{
+    const size_t ntiles = (n + kScanTile - 1) / kScanTile;
+    if (ntiles == 0) return;
+    THZ_LAUNCH(k_scan_tile_sums, ntiles, 256, 0, st, counts, n, tile_ws);
+    THZ_LAUNCH(k_scan_tile_offsets, 1, 256, 0, st, tile_ws, ntiles, total);
+    THZ_LAUNCH(k_scan_apply, ntiles, 256, 0, st, counts, n, tile_ws, offsets);
+}
+
+// ------------------------------------------------------------------- emit
+__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+// bevy_color Srgba -> LinearRgba channel conversion (oracle/thz_oracle_voxel.c header)
+__device__ __forceinline__ float srgb_to_linear(float x)
+{
+    if (x <= 0.0f) return x;
+    if (x <= 0.04045f) return div_rn(x, 12.92f);
+    return powf(div_rn(x + 0.055f, 1.055f), 2.4f);
+}
+
+// Instance loop of threed_plot.rs:221-271 in its x, y, z order: trace by trace,
+// inside a trace 64 samples at a time with a ballot prefix.
+__global__ __launch_bounds__(256) void k_voxel_emit(size_t npix, int nt, size_t gh, const float *__restrict__ opacity,
+                                                    const unsigned long long *__restrict__ offsets, VoxelGeom g,
+                                                    float4 *__restrict__ out, unsigned long long capacity)
+{
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    const size_t stride = (size_t)gridDim.x * wpb;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    for (size_t trace = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); trace < npix; trace += stride) {
+        const size_t x = g.x0 + trace / gh, y = trace % gh;
+        const float px = sub_rn(mul_rn((float)y, g.spacing_h), g.half_h);
+        const float py = sub_rn(g.half_w, mul_rn((float)x, g.spacing_w));
+        const float *src = opacity + trace * (size_t)nt;
+        unsigned long long off = offsets[trace];
+        for (int z0 = 0; z0 < nt; z0 += kWave) {
+            const int z = z0 + lane;
+            const bool valid = z < nt;
+            const float o = valid ? src[z] : 0.0f;
+            const bool pred = valid && o >= g.threshold;
+            const uint64_t m = wave_ballot(pred);
+            const unsigned long long pos = off + (unsigned long long)popc64(m & below);
+            if (pred && pos < capacity) {
+                const float v = div_rn(o - g.threshold, 1.0f - g.threshold);
+                const float four = mul_rn(4.0f, v);
+                const float r = clamp01(four - 1.5f);
+                const float gg = clamp01(four - 0.5f) - clamp01(four - 2.5f);
+                const float b = 1.0f - clamp01(four - 1.5f);
+                const float pz = sub_rn(g.half_d, mul_rn((float)z, g.spacing_d));
+                out[2 * pos + 0] = make_float4(px, py, pz, g.scale);
+                out[2 * pos + 1] = make_float4(srgb_to_linear(r), srgb_to_linear(gg), srgb_to_linear(b), o);
+            }
+            off += (unsigned long long)popc64(m);
+        }
+    }
+}
+
+void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const float *opacity,
+                       const unsigned long long *offsets, const VoxelGeom &g, float *out,
+                       unsigned long long capacity)
+{
+    size_t blocks = (npix + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return;
+    THZ_LAUNCH(k_voxel_emit, blocks, 256, 0, st, npix, nt, gh, opacity, offsets, g, reinterpret_cast<float4 *>(out),
+               capacity);
+}
+
+}  // namespace thz
