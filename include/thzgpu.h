@@ -435,8 +435,11 @@ int thz_voxel_opacity(thz_ctx *ctx, size_t npix, size_t nt, const float *d_data,
                       float *d_opacity);
 /* Radix select, one level: d_hist (2048 u64, device) += histogram of the level's
  * bits among the n values whose higher bits equal `prefix` (level 0: 11 bits of
- * all values; level 1: next 11; level 2: last 10).  Histograms of the tiles of a
- * cube add up, so ranks all-reduce d_hist between levels. */
+ * all values; level 1: next 11; level 2: last 10).  At level 0 `prefix` is a floor
+ * bin instead: keys of lower bins are counted in it (0 = full histogram); if the
+ * walk ends in a non-zero floor bin, level 0 is repeated with floor 0.
+ * Histograms of the tiles of a cube add up, so ranks all-reduce d_hist between
+ * levels. */
 int thz_select_histogram(thz_ctx *ctx, const float *d_vals, size_t n, int level, uint32_t prefix,
                          uint64_t *d_hist);
 /* host walk of one level: the bin holding the k-th largest (k >= 1) and its rank

@@ -102,7 +102,7 @@ int emu_voxel_instances(size_t npix, int nt, size_t gh, const float *opacity, co
     VoxelGeom g{geom8[0], geom8[1], geom8[2], geom8[3], geom8[4], geom8[5], geom8[6], geom8[7], x0};
     launch_voxel_count(nullptr, npix, nt, opacity, g.threshold, counts.data());
     launch_scan_counts(nullptr, counts.data(), npix, tiles.data(), offsets.data(), total);
-    launch_voxel_emit(nullptr, npix, nt, gh, opacity, offsets.data(), g, out, capacity);
+    launch_voxel_emit(nullptr, npix, nt, gh, opacity, counts.data(), offsets.data(), g, out, capacity);
     return 0;
 }
 }

@@ -113,7 +113,7 @@ void launch_voxel_count(hipStream_t st, size_t npix, int nt, const float *opacit
 void launch_scan_counts(hipStream_t st, const uint32_t *counts, size_t n, unsigned long long *tile_ws,
                         unsigned long long *offsets, unsigned long long *total);
 void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const float *opacity,
-                       const unsigned long long *offsets, const VoxelGeom &g, float *out,
+                       const uint32_t *counts, const unsigned long long *offsets, const VoxelGeom &g, float *out,
                        unsigned long long capacity);
 
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,

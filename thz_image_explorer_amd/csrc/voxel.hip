@@ -61,6 +61,20 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 }
 #endif
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// (a.hi, b.lo) as one register pair: v_pk_mov_b32 picks a half of each source
+__device__ __forceinline__ f2 pair_hi_lo(f2 a, f2 b)
+{
+#ifndef THZ_EMU
+    f2 r;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return f2{a.y, b.x};
+#endif
+}
+
 __device__ __forceinline__ float wave_max(float v)
 {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
@@ -81,6 +95,15 @@ __device__ __forceinline__ float vox_pow(float v, float contrast, int pow_mode)
     if (pow_mode == 2) return q * q;
     if (pow_mode == 1) return q;
     return hw_exp2(contrast * hw_log2(q));  // q = 0 -> exp2(-inf) = 0
+}
+
+// n / d with inv = 1/d: quotient estimate plus one residual correction — the
+// result of the IEEE division for all but rare last-place cases, and exactly 1
+// for n == d, at 3 instructions instead of the ~10 of the full sequence.
+__device__ __forceinline__ float vox_div(float n, float d, float inv)
+{
+    const float q = n * inv;
+    return fmaf(fmaf(-d, q, n), inv, q);
 }
 
 template <int NQ, bool VEC>
@@ -122,8 +145,10 @@ __global__ __launch_bounds__(256) void k_voxel_opacity(size_t npix, int nt, cons
     THZ_DYN_LDS(smem);
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const int slice = NQ * 256 + 2 * pad;
-    float *lds = reinterpret_cast<float *>(smem) + (size_t)wave * slice;
+    const int padc = WIDE ? (pad & ~3) : kVoxPad;  // multiple of 4: every quad access is 16-byte aligned
+    const int slice = NQ * 256 + 2 * padc;
+    float *lds = static_cast<float *>(__builtin_assume_aligned(
+        reinterpret_cast<float *>(smem) + (size_t)wave * slice, 16));
     for (int i = lane; i < slice; i += kWave) lds[i] = 0.0f;
     wave_sync();
 
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(256) void k_voxel_opacity(size_t npix, int nt, cons
             p.y = vox_pow(cur[q].y, contrast, pow_mode);
             p.z = vox_pow(cur[q].z, contrast, pow_mode);
             p.w = vox_pow(cur[q].w, contrast, pow_mode);
-            *reinterpret_cast<float4 *>(lds + pad + e) = p;  // samples past nt were loaded as 0
+            *static_cast<float4 *>(__builtin_assume_aligned(lds + padc + e, 16)) = p;  // samples past nt were loaded as 0
         }
         wave_sync();
         const size_t next = trace + stride;
@@ -153,23 +178,34 @@ __global__ __launch_bounds__(256) void k_voxel_opacity(size_t npix, int nt, cons
             const int e = q * 256 + 4 * lane;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             if constexpr (!WIDE) {
-                // lds[e + j] = p[e + j - kVoxPad], j = 0 .. 27
-                float w[4 + 2 * kVoxPad];
+                // lds[e + j] = p[e + j - kVoxPad], j = 0 .. 27, as 14 register pairs P[m] =
+                // (w[2m], w[2m+1]) plus the 13 odd-aligned pairs S[m] = (w[2m+1], w[2m+2]), so
+                // that every tap is two packed FMAs: (a0,a1) += (w[k],w[k+1]) c, (a2,a3) += (w[k+2],w[k+3]) c
+                constexpr int NP = (4 + 2 * kVoxPad) / 2;
+                f2 P[NP], S[NP - 1];
 #pragma unroll
-                for (int j = 0; j < (4 + 2 * kVoxPad) / 4; ++j) {
-                    const float4 t = *reinterpret_cast<const float4 *>(lds + e + 4 * j);
-                    w[4 * j + 0] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
+                for (int j = 0; j < NP / 2; ++j) {
+                    const float4 t = *static_cast<const float4 *>(__builtin_assume_aligned(lds + e + 4 * j, 16));
+                    P[2 * j] = f2{t.x, t.y};
+                    P[2 * j + 1] = f2{t.z, t.w};
                 }
+#pragma unroll
+                for (int m = 0; m < NP - 1; ++m) S[m] = pair_hi_lo(P[m], P[m + 1]);
+                f2 a01 = f2{0.f, 0.f}, a23 = f2{0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < kVoxTaps; ++k) {
-                    const float c = taps.c[k];
-                    a0 = fmaf(w[k + 0], c, a0);
-                    a1 = fmaf(w[k + 1], c, a1);
-                    a2 = fmaf(w[k + 2], c, a2);
-                    a3 = fmaf(w[k + 3], c, a3);
+                    const f2 c = f2{taps.c[k], taps.c[k]};
+                    if (k % 2 == 0) {
+                        a01 = __builtin_elementwise_fma(P[k / 2], c, a01);
+                        a23 = __builtin_elementwise_fma(P[k / 2 + 1], c, a23);
+                    } else {
+                        a01 = __builtin_elementwise_fma(S[k / 2], c, a01);
+                        a23 = __builtin_elementwise_fma(S[k / 2 + 1], c, a23);
+                    }
                 }
+                a0 = a01.x; a1 = a01.y; a2 = a23.x; a3 = a23.y;
             } else {
-                const float *w = lds + pad + e - radius;  // w[k + o] = p[e + o + k - radius]
+                const float *w = lds + padc + e - radius;  // w[k + o] = p[e + o + k - radius]
                 for (int k = 0; k <= 2 * radius; ++k) {
                     const float c = wide_taps[k];
                     a0 = fmaf(w[k + 0], c, a0);
@@ -189,16 +225,17 @@ __global__ __launch_bounds__(256) void k_voxel_opacity(size_t npix, int nt, cons
         // threed_plot.rs:181-199: whole line zero below the opacity threshold or when flat
         const bool keep = !(mx < opacity_threshold) && fabsf(mx - mn) > 1e-6f;
         const float range = mx - mn;
+        const float inv = div_rn(1.0f, range);
         float *dst = out + trace * (size_t)nt;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = q * 256 + 4 * lane;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (keep) {
-                r.x = div_rn(o[q].x - mn, range);
-                r.y = div_rn(o[q].y - mn, range);
-                r.z = div_rn(o[q].z - mn, range);
-                r.w = div_rn(o[q].w - mn, range);
+                r.x = vox_div(o[q].x - mn, range, inv);
+                r.y = vox_div(o[q].y - mn, range, inv);
+                r.z = vox_div(o[q].z - mn, range, inv);
+                r.w = vox_div(o[q].w - mn, range, inv);
             }
             if constexpr (VEC) {
                 if (e < nt) *reinterpret_cast<float4 *>(dst + e) = r;
@@ -282,63 +319,100 @@ __device__ __forceinline__ uint32_t sel_key(uint32_t bits)
     return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
 }
 
-// One key into the block's LDS histogram.  Neighbouring samples of a smooth
+// Keys into the block's LDS histogram.  Neighbouring samples of a smooth
 // envelope (and the many exact zeros) fall into the same bin, which would
-// serialise a plain LDS atomic 64 ways; a few ballot rounds first merge the lanes
-// that agree with the lowest active lane, whatever is left goes in one by one.
-__device__ __forceinline__ void sel_add(unsigned int *h, uint32_t key, bool active, int level, uint32_t prefix)
+// serialise a plain LDS atomic 64 ways.
+// level 0 lumps every key below bin `prefix` (the "floor") into that bin: the k-th
+// largest of a cube sits near the top, and the lump turns the tails and zero lines
+// into long runs.  The caller repeats level 0 with floor 0 if the walk ends in the lump.
+__device__ __forceinline__ uint32_t sel_bin(uint32_t key, int level, uint32_t prefix)
 {
-    uint32_t bin;
     if (level == 0) {
-        bin = key >> 21;
-    } else if (level == 1) {
-        active = active && (key >> 21) == prefix;
-        bin = (key >> 10) & 2047u;
-    } else {
-        active = active && (key >> 10) == prefix;
-        bin = key & 1023u;
+        const uint32_t b = key >> 21;
+        return b > prefix ? b : prefix;
     }
+    return level == 1 ? (key >> 10) & 2047u : key & 1023u;
+}
+__device__ __forceinline__ bool sel_match(uint32_t key, int level, uint32_t prefix)
+{
+    return level == 0 ? true : (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix);
+}
+
+// The 64 lanes hold consecutive (stride-4) samples, so equal bins come in runs:
+// the first lane of each run adds the run's length.  One step, no loop; a noisy
+// wave degenerates to one atomic per lane.
+__device__ __forceinline__ void sel_add(unsigned int *h, uint32_t bin, bool active, unsigned int weight)
+{
     const int lane = lane_id();
-    uint64_t m = wave_ballot(active);
-    for (int round = 0; round < 4 && m != 0; ++round) {
-        const int first = ffs64(m) - 1;
-        const uint32_t b0 = wave_read_lane_u32(bin, first);
-        const uint64_t same = wave_ballot(active && bin == b0);
-        if (lane == first) atomicAdd(&h[b0], (unsigned int)popc64(same));
-        active = active && bin != b0;
-        m &= ~same;
+    const uint32_t tag = active ? bin : 0xFFFFFFFFu;  // no bin has this value
+    const uint32_t prev = __builtin_bit_cast(uint32_t, wave_shr1(__builtin_bit_cast(float, tag)));
+    const bool head = lane == 0 || tag != prev;
+    const uint64_t heads = wave_ballot(head);
+    if (active && head) {
+        const uint64_t above = (heads >> lane) >> 1;
+        const int len = above ? __builtin_ctzll(above) + 1 : kWave - lane;
+        atomicAdd(&h[bin], (unsigned int)len * weight);
     }
-    if (active) atomicAdd(&h[bin], 1u);
+}
+
+// four consecutive values of one lane: when they share a bin in every lane of the wave
+// (zero lines, smooth envelopes) one weighted round does the work of four
+__device__ __forceinline__ void sel_add4(unsigned int *h, uint4 k, bool in, int level, uint32_t prefix)
+{
+    const uint32_t kx = sel_key(k.x), ky = sel_key(k.y), kz = sel_key(k.z), kw = sel_key(k.w);
+    const uint32_t bx = sel_bin(kx, level, prefix), by = sel_bin(ky, level, prefix);
+    const uint32_t bz = sel_bin(kz, level, prefix), bw = sel_bin(kw, level, prefix);
+    const bool ax = in && sel_match(kx, level, prefix), ay = in && sel_match(ky, level, prefix);
+    const bool az = in && sel_match(kz, level, prefix), aw = in && sel_match(kw, level, prefix);
+    const bool any = ax || ay || az || aw;
+    if (wave_ballot(any) == 0) return;
+    const bool uniform4 = !any || (ax && ay && az && aw && bx == by && by == bz && bz == bw);
+    if (wave_ballot(!uniform4) == 0) {
+        sel_add(h, bx, any, 4u);
+    } else {
+        sel_add(h, bx, ax, 1u);
+        sel_add(h, by, ay, 1u);
+        sel_add(h, bz, az, 1u);
+        sel_add(h, bw, aw, 1u);
+    }
 }
 
 // hist[bin] += number of keys of this level's bin among the values whose higher
-// bits equal `prefix` (level 0: all values).  hist has kSelBins entries.
+// bits equal `prefix` (level 0: all values, `prefix` is the floor bin).  hist has
+// kSelBins entries.
 __global__ __launch_bounds__(256) void k_select_hist(const uint32_t *__restrict__ vals, size_t n, int level,
                                                      uint32_t prefix, unsigned long long *__restrict__ hist)
 {
     __shared__ unsigned int h[kSelBins];
     for (int i = (int)threadIdx.x; i < kSelBins; i += (int)blockDim.x) h[i] = 0u;
     __syncthreads();
+    constexpr int U = 4;           // loads in flight per lane
+    constexpr size_t kChunk = 1024;  // quads per wave step: 16 KB contiguous, like a trace
     const size_t nq = n / 4;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t iters = (nq + stride - 1) / stride;  // same trip count in every lane: the ballots stay wave-uniform
+    const int lane = lane_id();
+    const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
     const uint4 *v4 = reinterpret_cast<const uint4 *>(vals);
-    for (size_t it = 0; it < iters; ++it) {
-        const size_t q = first + it * stride;
-        const bool in = q < nq;
-        uint4 k = make_uint4(0u, 0u, 0u, 0u);
-        if (in) k = v4[q];
-        sel_add(h, sel_key(k.x), in, level, prefix);
-        sel_add(h, sel_key(k.y), in, level, prefix);
-        sel_add(h, sel_key(k.z), in, level, prefix);
-        sel_add(h, sel_key(k.w), in, level, prefix);
+    for (size_t c = wave_id; c * kChunk < nq; c += n_waves) {  // wave-uniform trip counts: ballots stay uniform
+        for (int it = 0; it < (int)(kChunk / (U * kWave)); ++it) {
+            uint4 k[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t q = c * kChunk + (size_t)(it * U + u) * kWave + lane;
+                in[u] = q < nq;
+                k[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (in[u]) k[u] = v4[q];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) sel_add4(h, k[u], in[u], level, prefix);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < kWave) {  // the n % 4 tail
         const size_t i = nq * 4 + threadIdx.x;
         const bool in = i < n;
-        const uint32_t k = in ? vals[i] : 0u;
-        sel_add(h, sel_key(k), in, level, prefix);
+        const uint32_t key = sel_key(in ? vals[i] : 0u);
+        sel_add(h, sel_bin(key, level, prefix), in && sel_match(key, level, prefix), 1u);
     }
     __syncthreads();
     for (int i = (int)threadIdx.x; i < kSelBins; i += (int)blockDim.x)
@@ -348,7 +422,7 @@ __global__ __launch_bounds__(256) void k_select_hist(const uint32_t *__restrict_
 void launch_select_hist(hipStream_t st, const float *vals, size_t n, int level, uint32_t prefix,
                         unsigned long long *hist)
 {
-    size_t blocks = (n / 4 + 255) / 256;
+    size_t blocks = (n / 4 + 4095) / 4096;  // 4 waves x 1024 quads
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     THZ_LAUNCH(k_select_hist, blocks, 256, 0, st, reinterpret_cast<const uint32_t *>(vals), n, level, prefix, hist);
@@ -485,9 +559,25 @@ __device__ __forceinline__ float srgb_to_linear(float x)
     return powf(div_rn(x + 0.055f, 1.055f), 2.4f);
 }
 
-// Instance loop of threed_plot.rs:221-271 in its x, y, z order: trace by trace,
-// inside a trace 64 samples at a time with a ballot prefix.
+__device__ __forceinline__ void vox_emit_one(float4 *__restrict__ out, unsigned long long pos, float px, float py,
+                                             int z, float o, const VoxelGeom &g)
+{
+    const float v = div_rn(o - g.threshold, 1.0f - g.threshold);
+    const float four = mul_rn(4.0f, v);
+    const float r = clamp01(four - 1.5f);
+    const float gg = clamp01(four - 0.5f) - clamp01(four - 2.5f);
+    const float b = 1.0f - clamp01(four - 1.5f);
+    const float pz = sub_rn(g.half_d, mul_rn((float)z, g.spacing_d));
+    out[2 * pos + 0] = make_float4(px, py, pz, g.scale);
+    out[2 * pos + 1] = make_float4(srgb_to_linear(r), srgb_to_linear(gg), srgb_to_linear(b), o);
+}
+
+// Instance loop of threed_plot.rs:221-271 in its x, y, z order: trace by trace
+// (traces without a voxel are not read again), inside a trace 256 samples at a
+// time — a lane owns four consecutive samples, four ballots give its offset.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_voxel_emit(size_t npix, int nt, size_t gh, const float *__restrict__ opacity,
+                                                    const uint32_t *__restrict__ counts,
                                                     const unsigned long long *__restrict__ offsets, VoxelGeom g,
                                                     float4 *__restrict__ out, unsigned long long capacity)
 {
@@ -496,42 +586,51 @@ __global__ __launch_bounds__(256) void k_voxel_emit(size_t npix, int nt, size_t 
     const size_t stride = (size_t)gridDim.x * wpb;
     const uint64_t below = ((uint64_t)1 << lane) - 1;
     for (size_t trace = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); trace < npix; trace += stride) {
+        if (counts[trace] == 0u) continue;
         const size_t x = g.x0 + trace / gh, y = trace % gh;
         const float px = sub_rn(mul_rn((float)y, g.spacing_h), g.half_h);
         const float py = sub_rn(g.half_w, mul_rn((float)x, g.spacing_w));
         const float *src = opacity + trace * (size_t)nt;
         unsigned long long off = offsets[trace];
-        for (int z0 = 0; z0 < nt; z0 += kWave) {
-            const int z = z0 + lane;
-            const bool valid = z < nt;
-            const float o = valid ? src[z] : 0.0f;
-            const bool pred = valid && o >= g.threshold;
-            const uint64_t m = wave_ballot(pred);
-            const unsigned long long pos = off + (unsigned long long)popc64(m & below);
-            if (pred && pos < capacity) {
-                const float v = div_rn(o - g.threshold, 1.0f - g.threshold);
-                const float four = mul_rn(4.0f, v);
-                const float r = clamp01(four - 1.5f);
-                const float gg = clamp01(four - 0.5f) - clamp01(four - 2.5f);
-                const float b = 1.0f - clamp01(four - 1.5f);
-                const float pz = sub_rn(g.half_d, mul_rn((float)z, g.spacing_d));
-                out[2 * pos + 0] = make_float4(px, py, pz, g.scale);
-                out[2 * pos + 1] = make_float4(srgb_to_linear(r), srgb_to_linear(gg), srgb_to_linear(b), o);
+        for (int z0 = 0; z0 < nt; z0 += 4 * kWave) {
+            const int z = z0 + 4 * lane;
+            float4 o = make_float4(-1.f, -1.f, -1.f, -1.f);
+            if constexpr (VEC) {
+                if (z < nt) o = *reinterpret_cast<const float4 *>(src + z);
+            } else {
+                if (z + 0 < nt) o.x = src[z + 0];
+                if (z + 1 < nt) o.y = src[z + 1];
+                if (z + 2 < nt) o.z = src[z + 2];
+                if (z + 3 < nt) o.w = src[z + 3];
             }
-            off += (unsigned long long)popc64(m);
+            const bool p0 = z + 0 < nt && o.x >= g.threshold, p1 = z + 1 < nt && o.y >= g.threshold;
+            const bool p2 = z + 2 < nt && o.z >= g.threshold, p3 = z + 3 < nt && o.w >= g.threshold;
+            const uint64_t m0 = wave_ballot(p0), m1 = wave_ballot(p1), m2 = wave_ballot(p2), m3 = wave_ballot(p3);
+            if ((m0 | m1 | m2 | m3) == 0) continue;
+            unsigned long long pos = off + (unsigned long long)(popc64(m0 & below) + popc64(m1 & below)
+                                                                + popc64(m2 & below) + popc64(m3 & below));
+            if (p0) { if (pos < capacity) vox_emit_one(out, pos, px, py, z + 0, o.x, g); ++pos; }
+            if (p1) { if (pos < capacity) vox_emit_one(out, pos, px, py, z + 1, o.y, g); ++pos; }
+            if (p2) { if (pos < capacity) vox_emit_one(out, pos, px, py, z + 2, o.z, g); ++pos; }
+            if (p3) { if (pos < capacity) vox_emit_one(out, pos, px, py, z + 3, o.w, g); ++pos; }
+            off += (unsigned long long)(popc64(m0) + popc64(m1) + popc64(m2) + popc64(m3));
         }
     }
 }
 
-void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const float *opacity,
+void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const float *opacity, const uint32_t *counts,
                        const unsigned long long *offsets, const VoxelGeom &g, float *out,
                        unsigned long long capacity)
 {
     size_t blocks = (npix + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) return;
-    THZ_LAUNCH(k_voxel_emit, blocks, 256, 0, st, npix, nt, gh, opacity, offsets, g, reinterpret_cast<float4 *>(out),
-               capacity);
+    if (nt % 4 == 0 && (uintptr_t)opacity % 16 == 0)
+        THZ_LAUNCH(k_voxel_emit<true>, blocks, 256, 0, st, npix, nt, gh, opacity, counts, offsets, g,
+                   reinterpret_cast<float4 *>(out), capacity);
+    else
+        THZ_LAUNCH(k_voxel_emit<false>, blocks, 256, 0, st, npix, nt, gh, opacity, counts, offsets, g,
+                   reinterpret_cast<float4 *>(out), capacity);
 }
 
 }  // namespace thz

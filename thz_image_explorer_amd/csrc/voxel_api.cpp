@@ -106,13 +106,25 @@ int thz_kth_largest(thz_ctx *ctx, const float *d_vals, size_t n, uint64_t k, flo
     int bins[3] = {0, 0, 0};
     uint32_t prefix = 0;
     uint64_t rank = k;
+    // level 0 first with everything below 2^-10 lumped into one bin (cheap: long runs); the
+    // full histogram only if the k-th largest turns out to be that small
+    uint32_t floor_bin = (0x80000000u | 0x3A800000u) >> 21;
     for (int level = 0; level < 3; ++level) {
-        HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, kSelBins * sizeof(uint64_t), ctx->stream));
-        if (int rc = thz_select_histogram(ctx, d_vals, n, level, prefix, d_hist)) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(hist.data(), d_hist, kSelBins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (thz_host_select_step(hist.data(), level == 2 ? 1024 : kSelBins, rank, &bins[level], &rank))
-            return fail(ctx, THZ_ERR_INVALID, "thz_kth_largest: histogram holds fewer than k values");
+        for (;;) {
+            HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, kSelBins * sizeof(uint64_t), ctx->stream));
+            if (int rc = thz_select_histogram(ctx, d_vals, n, level, level == 0 ? floor_bin : prefix, d_hist)) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(hist.data(), d_hist, kSelBins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            uint64_t r = 0;
+            if (thz_host_select_step(hist.data(), level == 2 ? 1024 : kSelBins, rank, &bins[level], &r))
+                return fail(ctx, THZ_ERR_INVALID, "thz_kth_largest: histogram holds fewer than k values");
+            if (level == 0 && floor_bin != 0 && (uint32_t)bins[0] == floor_bin) {
+                floor_bin = 0;
+                continue;
+            }
+            rank = r;
+            break;
+        }
         prefix = level == 0 ? (uint32_t)bins[0] : (((uint32_t)bins[0] << 11) | (uint32_t)bins[1]);
     }
     *out = thz_host_select_value(bins[0], bins[1], bins[2]);
@@ -165,7 +177,7 @@ int thz_voxel_instances(thz_ctx *ctx, const float *d_opacity, size_t gw, size_t 
     StageTimer t(ctx, THZ_STAGE_VOXEL_EMIT);
     launch_voxel_count(ctx->stream, npix, (int)gd, d_opacity, threshold, d_counts);
     launch_scan_counts(ctx->stream, d_counts, npix, d_tiles, d_offsets, d_total);
-    launch_voxel_emit(ctx->stream, npix, (int)gd, gh, d_opacity, d_offsets, g, reinterpret_cast<float *>(d_out),
+    launch_voxel_emit(ctx->stream, npix, (int)gd, gh, d_opacity, d_counts, d_offsets, g, reinterpret_cast<float *>(d_out),
                       capacity);
     if (int rc = check_launch(ctx)) return rc;
     unsigned long long total = 0;
