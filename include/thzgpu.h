@@ -403,6 +403,29 @@ void *thz_session_buffer(thz_session *s, int which);
  * tile, or everything */
 int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst);
 
+/* Plot copy-out of UpdateType::Plot (data_thread.rs:1337-1432): everything the
+ * right-hand panel plots for the selected pixel, in one call.  Host pointers, any
+ * may be NULL.  px, py index the (nx, ny) grid (pixel_selected / scaling). */
+typedef struct thz_plot_out {
+    float *signal;              /* nt      raw trace, filter_data.first()               :1344-1362 */
+    float *signal_fft;          /* nf_out  amplitudes right after the fft stage         :1366-1380 */
+    float *phase_fft;           /* nf_out  phases right after the fft stage                        */
+    float *filtered_signal;     /* nt_out  final trace, filter_data.last()              :1384-1396 */
+    float *filtered_signal_fft; /* nf_out  band-passed amplitudes                       :1398-1408 */
+    float *filtered_phase_fft;  /* nf_out                                               :1409-1419 */
+    float *avg_signal;          /* nt_out  pixel mean of the final cube                 :1422-1430 */
+    float *avg_signal_fft;      /* nf_out  pixel mean of the amplitudes (needs want_means) :1434   */
+    float *avg_phase_fft;       /* nf_out                                                  :1435   */
+} thz_plot_out;
+int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *out);
+
+/* calculate_optical_properties (math_tools.rs:663-701): refractive index, absorption
+ * coefficient and extinction coefficient per bin from sample and reference amplitude /
+ * phase spectra (host vectors; f32 in the reference's operation order). */
+int thz_host_optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
+                                const float *ref_phase, const float *freq, size_t nf, float thickness,
+                                float *refractive_index, float *absorption_coeff, float *extinction_coeff);
+
 /* ------------------------------------------------------------------ */
 /* 3-D voxel envelope (gui/threed_plot.rs:80-276)                       */
 /* ------------------------------------------------------------------ */

@@ -681,6 +681,30 @@ void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny
     rplan_free_f(r);
 }
 
+/* calculate_optical_properties, math_tools.rs:663-701: refractive index, absorption
+ * and extinction coefficient per frequency bin from sample / reference spectra */
+void thz_oracle_optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
+                                   const float *ref_phase, const float *freq, size_t nf, float thickness,
+                                   float *n_out, float *alpha_out, float *kappa_out)
+{
+    const float C = 2.99792458e8f;
+    for (size_t i = 0; i < nf; ++i) {
+        const float frequency_hz = freq[i] * 1.0e12f;
+        const float delta_phi = sample_phase[i] - ref_phase[i];
+        const float omega = 2.0f * PI_F * frequency_hz;
+        const float n = 1.0f + C * delta_phi / (omega * thickness);
+        const float amp = fmaxf(sample_amp[i], 1e-12f);
+        const float amp_ref = fmaxf(ref_amp[i], 1e-12f);
+        const float n_safe = fmaxf(n, 1e-6f);
+        const float np1 = n_safe + 1.0f;
+        const float alpha = -2.0f / thickness * logf((np1 * np1) / (4.0f * n_safe) * amp / amp_ref);
+        const float kappa = alpha * C / (4.0f * PI_F * frequency_hz);
+        n_out[i] = n;
+        alpha_out[i] = alpha;
+        kappa_out[i] = kappa;
+    }
+}
+
 #include "thz_oracle_deconv.c"
 #include "thz_oracle_voxel.c"
 

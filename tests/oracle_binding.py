@@ -375,6 +375,14 @@ def voxel_instances(opacity, threshold, time_span, scaling, orig_dims):
     return out, tuple(float(x) for x in dims)
 
 
+def optical_properties(sample_amp, sample_phase, ref_amp, ref_phase, freq, thickness):
+    a, p, ra, rp, f = (f32(x) for x in (sample_amp, sample_phase, ref_amp, ref_phase, freq))
+    out = [np.empty(f.size, np.float32) for _ in range(3)]
+    lib().thz_oracle_optical_properties(_p(a), _p(p), _p(ra), _p(rp), _p(f), C.c_size_t(f.size), C.c_float(thickness),
+                                        *[_p(o) for o in out])
+    return tuple(out)
+
+
 def max_threads():
     return int(lib().thz_oracle_max_threads())
 

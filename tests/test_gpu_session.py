@@ -7,7 +7,7 @@ import pytest
 import oracle_binding as ob
 import synth
 import thz_image_explorer_amd as pkg
-from test_gpu_parity import TOL, rel
+from test_gpu_parity import TOL, phase_ok, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -102,6 +102,38 @@ def test_session_tilted_scan_changes_trace_length(engine):
         check(sess, oracle_chain(cube, time, cfg, 0.5, 0.5), nx, ny)
     finally:
         sess.close()
+
+
+def test_session_plot_copy_out(engine):
+    """UpdateType::Plot, data_thread.rs:1337-1436: selected-pixel and average vectors in one call"""
+    nx, ny, nt = 5, 6, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    for tilt in (0.0, 1.5):
+        sess = pkg.Session(engine, nx, ny, time, dx=0.5, dy=0.5)
+        try:
+            sess.upload(cube, subtract_bias=False)
+            with pytest.raises(pkg.ThzError):
+                sess.plot(1, 1)                                # nothing computed yet
+            assert np.array_equal(sess.plot(1, 1, want=["signal"])["signal"], cube[1, 1])
+            cfg = pkg.chain_cfg_default(time)
+            cfg.tilt_x_deg = tilt
+            sess.recompute(cfg)
+            ref = oracle_chain(cube, time, cfg, 0.5, 0.5)
+            px, py = 3, 4
+            got = sess.plot(px, py)
+            scale = np.abs(ref["fft"]).max()
+            assert np.array_equal(got["signal"], cube[px, py])
+            assert rel(got["signal_fft"], ref["amp_unmasked"][px, py], scale) < TOL
+            assert phase_ok(got["phase_fft"][None], ref["ph"][px, py][None], ref["amp_unmasked"][px, py][None])
+            assert rel(got["filtered_signal"], ref["data"][px, py], np.abs(ref["data"]).max()) < TOL
+            assert rel(got["filtered_signal_fft"], ref["amp"][px, py], scale) < TOL
+            assert phase_ok(got["filtered_phase_fft"][None], ref["ph"][px, py][None], ref["amp_unmasked"][px, py][None])
+            assert rel(got["avg_signal"], ob.pixel_mean(ref["data"]), np.abs(ref["data"]).max()) < TOL
+            assert rel(got["avg_signal_fft"], ref["avg"]["amp"]) < TOL
+            with pytest.raises(pkg.ThzError):
+                sess.plot(nx, 0)
+        finally:
+            sess.close()
 
 
 def test_session_download_bounds_and_missing_means(engine):

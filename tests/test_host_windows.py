@@ -110,3 +110,28 @@ def test_wiener_filter_definition():
     assert np.abs(H - ref).max() / np.abs(ref).max() < 1e-5
     strong = np.abs(Rf) > 0.5 * np.abs(Rf).max()
     assert np.abs(H[strong] * Rf[strong] - 1).max() < 5e-3  # inverts where the reference has signal
+
+
+def test_optical_properties_match_oracle_and_known_answers():
+    """calculate_optical_properties, math_tools.rs:663-701"""
+    rng = np.random.default_rng(3)
+    nf = 513
+    freq = (np.arange(nf, dtype=np.float32) / np.float32(51.15)).astype(np.float32)
+    ra = rng.uniform(0.1, 5.0, nf).astype(np.float32)
+    rp = np.cumsum(rng.uniform(-0.5, 0.0, nf)).astype(np.float32)
+    sa = (ra * rng.uniform(0.2, 0.9, nf)).astype(np.float32)
+    sp = (rp - rng.uniform(0.0, 3.0, nf)).astype(np.float32)
+    sa[5] = 0.0                                   # clamped to 1e-12
+    got = pkg.host_optical_properties(sa, sp, ra, rp, freq, 0.7)
+    ref = ob.optical_properties(sa, sp, ra, rp, freq, 0.7)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r, equal_nan=True)
+    # identical sample and reference: n = 1, alpha = -2/d * ln((2^2)/(4*1)) = 0, kappa = 0 (bin 0: 0/0 -> NaN in n)
+    n, alpha, kappa = pkg.host_optical_properties(ra, rp, ra, rp, freq, 1.0)
+    assert np.isnan(n[0]) and np.all(n[1:] == 1.0)
+    assert np.all(alpha[1:] == 0.0) and np.all(kappa[1:] == 0.0)
+    # a phase lag of omega*d/c*(n-1) gives back n: n = 1.5, d = 1 mm... (thickness in metres)
+    d = np.float32(1e-3)
+    lag = (2 * np.pi * freq.astype(np.float64) * 1e12 * d / 2.99792458e8 * 0.5).astype(np.float32)
+    n2, _, _ = pkg.host_optical_properties(ra, rp + lag, ra, rp, freq, float(d))
+    assert np.abs(n2[1:] - 1.5).max() < 1e-3

@@ -92,6 +92,11 @@ class ChainCfg(C.Structure):
                 ("td_after_width", C.c_double), ("want_means", C.c_int32)]
 
 
+class PlotOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("signal", "signal_fft", "phase_fft", "filtered_signal", "filtered_signal_fft",
+                                  "filtered_phase_fft", "avg_signal", "avg_signal_fft", "avg_phase_fft")]
+
+
 BUF_RAW, BUF_FFT, BUF_AMPLITUDES, BUF_PHASES, BUF_DATA, BUF_IMG, BUF_AVG_FFT, BUF_AVG_AMPLITUDES, \
     BUF_AVG_PHASES = range(9)
 
@@ -163,6 +168,8 @@ SYMBOLS = [
     ("thz_session_time_out", C.c_int, [_P, _P]),
     ("thz_session_buffer", _P, [_P, C.c_int]),
     ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
+    ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
+    ("thz_host_optical_properties", C.c_int, [_P, _P, _P, _P, _P, _SZ, C.c_float, _P, _P, _P]),
     ("thz_voxel_cfg_default", C.c_int, [C.POINTER(VoxelCfg)]),
     ("thz_host_gaussian_kernel1d", C.c_int, [C.c_float, C.c_int, _P]),
     ("thz_voxel_opacity", C.c_int, [_P, _SZ, _SZ, _P, C.POINTER(VoxelCfg), _P]),
@@ -305,6 +312,15 @@ def host_band_psf(psf: Psf, center_freq, dx, dy, img_rows, img_cols):
     return out
 
 
+def host_optical_properties(sample_amp, sample_phase, ref_amp, ref_phase, freq, thickness):
+    """-> (refractive index, absorption coefficient, extinction coefficient)"""
+    arrs = [np.ascontiguousarray(x, np.float32) for x in (sample_amp, sample_phase, ref_amp, ref_phase, freq)]
+    out = [np.empty(arrs[4].size, np.float32) for _ in range(3)]
+    _rc(load_library().thz_host_optical_properties(*[a.ctypes.data for a in arrs], arrs[4].size, thickness,
+                                                   *[o.ctypes.data for o in out]), "optical_properties")
+    return tuple(out)
+
+
 def voxel_cfg_default() -> VoxelCfg:
     cfg = VoxelCfg()
     _rc(load_library().thz_voxel_cfg_default(C.byref(cfg)), "voxel_cfg_default")
@@ -366,6 +382,18 @@ class Session:
         t = np.empty(self.nt_out, np.float32)
         self.eng._check(self.eng.lib.thz_session_time_out(self.h, t.ctypes.data))
         return t
+
+    def plot(self, px, py, want=None):
+        """UpdateType::Plot copy-out for pixel (px, py) -> dict of host vectors"""
+        nto = self.nt_out
+        nf = nto // 2 + 1
+        sizes = dict(signal=self.nt, signal_fft=nf, phase_fft=nf, filtered_signal=nto, filtered_signal_fft=nf,
+                     filtered_phase_fft=nf, avg_signal=nto, avg_signal_fft=nf, avg_phase_fft=nf)
+        want = list(sizes) if want is None else want
+        res = {k: np.empty(sizes[k], np.float32) for k in want}
+        po = PlotOut(**{k: v.ctypes.data for k, v in res.items()})
+        self.eng._check(self.eng.lib.thz_session_plot(self.h, px, py, C.byref(po)))
+        return res
 
     def download(self, which, pix0=0, npix=None):
         nto = self.nt_out

@@ -259,6 +259,18 @@ size_t thz_host_tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, do
     return tilt_plan(time, nt, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy, new_time, insert_index);
 }
 
+int thz_host_optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
+                                const float *ref_phase, const float *freq, size_t nf, float thickness,
+                                float *refractive_index, float *absorption_coeff, float *extinction_coeff)
+{
+    if (!sample_amp || !sample_phase || !ref_amp || !ref_phase || !freq || !refractive_index || !absorption_coeff
+        || !extinction_coeff)
+        return THZ_ERR_INVALID;
+    optical_properties(sample_amp, sample_phase, ref_amp, ref_phase, freq, nf, thickness, refractive_index,
+                       absorption_coeff, extinction_coeff);
+    return THZ_OK;
+}
+
 /* ------------------------------------------------------------ stages */
 
 int thz_fft(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win_a,

@@ -189,6 +189,28 @@ size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt
     return num_steps;
 }
 
+// calculate_optical_properties, math_tools.rs:663-701 (f32, the reference's operation order)
+void optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
+                        const float *ref_phase, const float *freq, size_t nf, float thickness, float *n_out,
+                        float *alpha_out, float *kappa_out)
+{
+    const float c = 2.99792458e8f;
+    for (size_t i = 0; i < nf; ++i) {
+        const float frequency_hz = freq[i] * 1.0e12f;
+        const float delta_phi = sample_phase[i] - ref_phase[i];
+        const float omega = 2.0f * kPiF * frequency_hz;
+        const float n = 1.0f + c * delta_phi / (omega * thickness);
+        const float amp = std::fmax(sample_amp[i], 1e-12f);
+        const float amp_ref = std::fmax(ref_amp[i], 1e-12f);
+        const float n_safe = std::fmax(n, 1e-6f);
+        const float alpha =
+            -2.0f / thickness * std::log(((n_safe + 1.0f) * (n_safe + 1.0f)) / (4.0f * n_safe) * amp / amp_ref);
+        n_out[i] = n;
+        alpha_out[i] = alpha;
+        kappa_out[i] = alpha * c / (4.0f * kPiF * frequency_hz);
+    }
+}
+
 // ---- 3-D voxel envelope, gui/threed_plot.rs
 
 // gaussian_kernel1d, threed_plot.rs:80-101

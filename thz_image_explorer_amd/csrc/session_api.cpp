@@ -19,6 +19,8 @@ struct thz_session {
     float *d_tilt = nullptr;                   // extended cube when tilt != 0
     int32_t *d_ins = nullptr;
     bool have_means = false;
+    bool have_outputs = false;   // a recompute has run
+    bool src_is_tilt = false;    // the fft stage read d_tilt (extended axis) instead of d_raw
 };
 
 namespace {
@@ -186,6 +188,8 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     if (int rc = thz_pipeline(ctx, npix, src, d_pre, d_mask, d_post, s->d_fft, s->d_amp, s->d_ph, s->d_data, s->d_img))
         return rc;
     s->have_means = false;
+    s->have_outputs = true;
+    s->src_is_tilt = src != s->d_raw;
     if (cfg->want_means) {
         if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 2, s->d_fft, s->d_avg)) return rc;
         if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 1, s->d_amp, s->d_avg + 2 * nf)) return rc;
@@ -243,6 +247,54 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     }
     if (pix0 + npix > total_pix) return fail(ctx, THZ_ERR_INVALID, "thz_session_download: pixel range out of bounds");
     return thz_memcpy_d2h(ctx, dst, base + pix0 * per, npix * per * sizeof(float));
+}
+
+int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *out)
+{
+    if (!s || !out) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (px >= s->nx || py >= s->ny) return fail(ctx, THZ_ERR_INVALID, "thz_session_plot: pixel out of bounds");
+    if (int rc = use_device(ctx)) return rc;
+    const size_t pix = px * s->ny + py;
+    if (out->signal)
+        if (int rc = thz_session_download(s, THZ_BUF_RAW, pix, 1, out->signal)) return rc;
+    const bool need_outputs = out->signal_fft || out->phase_fft || out->filtered_signal || out->filtered_signal_fft
+                              || out->filtered_phase_fft || out->avg_signal || out->avg_signal_fft || out->avg_phase_fft;
+    if (!need_outputs) return THZ_OK;
+    if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_plot: no recompute has run");
+    const size_t nt = s->nt_out, nf = s->nf_out;
+    if (out->filtered_signal)
+        if (int rc = thz_session_download(s, THZ_BUF_DATA, pix, 1, out->filtered_signal)) return rc;
+    if (out->filtered_signal_fft)
+        if (int rc = thz_session_download(s, THZ_BUF_AMPLITUDES, pix, 1, out->filtered_signal_fft)) return rc;
+    if (out->filtered_phase_fft)
+        if (int rc = thz_session_download(s, THZ_BUF_PHASES, pix, 1, out->filtered_phase_fft)) return rc;
+    if (out->avg_signal_fft)
+        if (int rc = thz_session_download(s, THZ_BUF_AVG_AMPLITUDES, 0, 1, out->avg_signal_fft)) return rc;
+    if (out->avg_phase_fft)
+        if (int rc = thz_session_download(s, THZ_BUF_AVG_PHASES, 0, 1, out->avg_phase_fft)) return rc;
+    if (out->signal_fft || out->phase_fft || out->avg_signal) {
+        // scratch behind the multipliers: [amp nf | phase nf | mean nt]
+        float *d_tmp = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&d_tmp, (2 * nf + nt) * sizeof(float)));
+        int rc = THZ_OK;
+        if (out->signal_fft || out->phase_fft) {
+            // the fft stage's own amplitudes / phases (no band-pass yet): one trace through K1-K3 again
+            if (ctx->time.size() != nt) rc = thz_set_time_axis(ctx, s->time_out.data(), nt);
+            const float *src = (s->src_is_tilt ? s->d_tilt : s->d_raw) + pix * nt;
+            if (!rc) rc = thz_fft(ctx, 1, src, s->d_vec /* pre */, nullptr, nullptr, nullptr, d_tmp, d_tmp + nf, nullptr);
+            if (!rc && out->signal_fft) rc = thz_memcpy_d2h(ctx, out->signal_fft, d_tmp, nf * sizeof(float));
+            if (!rc && out->phase_fft) rc = thz_memcpy_d2h(ctx, out->phase_fft, d_tmp + nf, nf * sizeof(float));
+        }
+        if (!rc && out->avg_signal) {
+            rc = thz_pixel_mean(ctx, s->nx, s->ny, nt, 1, s->d_data, d_tmp + 2 * nf);
+            if (!rc) rc = thz_memcpy_d2h(ctx, out->avg_signal, d_tmp + 2 * nf, nt * sizeof(float));
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tmp);
+        if (rc) return rc;
+    }
+    return THZ_OK;
 }
 
 }  // extern "C"
