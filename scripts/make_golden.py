@@ -170,6 +170,17 @@ def gen_unit_signals():
     np.savez_compressed(os.path.join(OUT, "unit_signals.npz"), **out)
 
 
+def gen_knife_edge_thz():
+    """tests/golden/knife_edge_2groups.thz: two measurement groups of the reference's real
+    sample file, copied verbatim with h5copy (a data file for the dotTHz reader tests)"""
+    f = os.path.join(REF, "sample_data/example_beam_width/measurement_x/data/1750085285.8557956_data.thz")
+    out = os.path.join(OUT, "knife_edge_2groups.thz")
+    if os.path.exists(out):
+        os.remove(out)
+    for g in ("Beam Width Measurement x=-0.10", "Beam Width Measurement x=-0.20"):
+        subprocess.run(["/opt/conda/bin/h5copy", "-i", f, "-o", out, "-s", "/" + g, "-d", "/" + g], check=True)
+
+
 def gen_knife_edge():
     f = os.path.join(REF, "sample_data/example_beam_width/measurement_x/data/1750085285.8557956_data.thz")
     ls = subprocess.run(["/opt/conda/bin/h5ls", "-r", f], stdout=subprocess.PIPE, text=True, check=True).stdout
@@ -257,5 +268,6 @@ if __name__ == "__main__":
     gen_roi_masks()
     if os.path.isdir(REF):
         gen_knife_edge()
+        gen_knife_edge_thz()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -12,6 +12,7 @@ import pytest
 
 import oracle_binding as ob
 import synth
+from thz_image_explorer_amd import io_binding as tio
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,12 +30,16 @@ def test_host_mirror_selftest_and_default_chain():
             np.array([0.5, 0.5], np.float32).tofile(f)
             time.tofile(f)
             raw.tofile(f)
+        if tio.available():
+            tio.save_scan(os.path.join(d, "scan.thzimg"), time, raw,
+                          {"width": nx, "height": ny, "dx [mm]": "0.5", "dy [mm]": "0.25", "user": "test"})
         r = subprocess.run([EXE, d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         print(r.stdout)
         assert r.returncode == 0, r.stdout
         assert "SELFTEST OK" in r.stdout and "FAIL" not in r.stdout
         out = np.fromfile(os.path.join(d, "out.bin"), np.float32)
         out2 = np.fromfile(os.path.join(d, "out2.bin"), np.float32)
+        out3 = np.fromfile(os.path.join(d, "out3.bin"), np.float32) if tio.available() else None
     nf = nt // 2 + 1
     npix = nx * ny
     sizes = [npix * nf * 2, npix * nf, npix * nf, npix * nt, npix, nf, nf, nt]
@@ -78,3 +83,10 @@ def test_host_mirror_selftest_and_default_chain():
     assert np.abs(avg_sig2 - m_amp).max() / np.abs(ref2["fft"]).max() < 1e-5
     assert np.isfinite(avg_data2).all() and np.abs(avg_data2).max() > 0
     assert np.isfinite(roi2).all() and roi2.size == nt
+
+    # ---- third run: the same cube opened from a .thzimg file, streamed in 3-row slabs
+    if out3 is not None:
+        raw3, img3, data3 = np.split(out3, [npix * nt, npix * nt + npix])
+        assert np.array_equal(raw3.reshape(cube.shape), cube)                  # bias subtraction is exact
+        assert np.abs(img3.reshape(nx, ny) - ob.intensity(cube)).max() / ob.intensity(cube).max() < 1e-5
+        assert np.abs(data3.reshape(ref["data"].shape) - ref["data"]).max() / np.abs(ref["data"]).max() < 1e-5

@@ -253,6 +253,35 @@ static void run_default_chain(const std::string &dir)
     std::printf("PASS? default chain done (%zux%zux%zu)\n", nx, ny, nt);
 }
 
+// OpenFile on a .thzimg (io.rs:496-631 through libthzio.so): streamed in 3-row slabs, then
+// the default chain; <dir>/scan.thzimg in, <dir>/out3.bin out (raw cube after the bias
+// subtraction, image of the loader, final cube)
+static void run_file_chain(const std::string &dir)
+{
+    const std::string path = dir + "/scan.thzimg";
+    std::FILE *probe = std::fopen(path.c_str(), "rb");
+    if (!probe) { std::printf("SKIP file chain: no scan.thzimg\n"); return; }
+    std::fclose(probe);
+    std::map<std::string, std::string> md;
+    ScannedImageFilterData scan = io::open_scan_from_thz(path, &md, 3);
+    CHECK(md.count("width") == 1 && md.count("dx [mm]") == 1, "metadata map");
+    CHECK(scan.dx && *scan.dx == 0.5f && scan.dy && *scan.dy == 0.25f && !scan.x_min, "geometry from metadata");
+    std::FILE *fo = std::fopen((dir + "/out3.bin").c_str(), "wb");
+    auto put = [&](const std::vector<float> &v) { std::fwrite(v.data(), 4, v.size(), fo); };
+    put(scan.data.download());
+    put(scan.img.download());
+    Pipeline pipe;
+    pipe.open(std::move(scan));
+    pipe.update_filter(1);
+    put(pipe.filter_data.back().data.download());
+    std::fclose(fo);
+    const auto pulse = io::open_pulse_from_thz(path);  // a scan file is not a pulse file
+    CHECK(pulse.first.empty() && pulse.second.empty(), "open_pulse_from_thz on a scan file");
+    bool threw = false;
+    try { io::open_scan_from_thz(dir + "/missing.thz"); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw, "missing file throws");
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -262,6 +291,7 @@ int main(int argc, char **argv)
         test_tilt();
         test_deconvolution_small();
         if (argc > 1) run_default_chain(argv[1]);
+        if (argc > 1) run_file_chain(argv[1]);
     } catch (const std::exception &e) {
         std::printf("FAIL exception: %s\n", e.what());
         return 2;

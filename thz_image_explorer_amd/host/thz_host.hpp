@@ -111,6 +111,18 @@ struct ScannedImageFilterData {
                                                  const std::vector<float> &time, float dx, float dy);
 };
 
+// io.rs:496-631 through libthzio.so (include/thzio.h; loaded at run time, so the mirror
+// itself has no HDF5 dependency): the cube goes to the device in x-slabs of `slab_rows`
+// rows (0 = about 256 MiB each) — a reader thread fills the next slab while the current
+// one is copied — then bias subtraction + image run once on the device.  Throws
+// std::runtime_error when the file cannot be read.  metadata: mdDescription -> md values.
+namespace io {
+ScannedImageFilterData open_scan_from_thz(const std::string &path, std::map<std::string, std::string> *metadata = nullptr,
+                                          size_t slab_rows = 0);
+// open_pulse_from_thz, io.rs:435-477: (time, signal); both empty when the first dataset is not 2-D
+std::pair<std::vector<float>, std::vector<float>> open_pulse_from_thz(const std::string &path);
+}  // namespace io
+
 // math_tools.rs:35-46
 enum class FftWindowType { AdaptedBlackman = 0, Blackman = 1, Hanning = 2, Hamming = 3, FlatTop = 4 };
 
