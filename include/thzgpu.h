@@ -419,6 +419,22 @@ typedef struct thz_plot_out {
 } thz_plot_out;
 int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *out);
 
+/* ConfigCommand::OpenRef (data_thread.rs:372-588): a reference pulse read from its own file
+ * becomes a length-nt vector on the scan's time axis — zero-padded index shift by
+ * round((scan_time[0] - ref_time[0]) / ref_dt) (:405-481) — is windowed with the *reference
+ * file's* time axis (:490-515) and transformed with the scan's plan (:517-533).
+ * thz_host_align_reference returns 0 (lengths and origin already match), 1 (shifted) or
+ * 2 (naive pad / truncate for degenerate axes). */
+int thz_host_align_reference(const float *scan_time, size_t nt, const float *ref_time, const float *ref_signal,
+                             size_t nref, float *out /* nt */);
+/* all host pointers; reference_out (nt) = aligned and windowed pulse (roi_data), amplitudes /
+ * phases (nf) = |X| and numpy_unwrap(arg X) (roi_signal_fft / roi_phase_fft).  Plans for
+ * scan_time if the context's axis differs.  THZ_ERR_INVALID where the reference panics: a
+ * non-adapted window with nref != nt. */
+int thz_reference_spectrum(thz_ctx *ctx, const float *scan_time, size_t nt, const float *ref_time,
+                           const float *ref_signal, size_t nref, const thz_window_cfg *window,
+                           float *reference_out, float *amplitudes, float *phases);
+
 /* calculate_optical_properties (math_tools.rs:663-701): refractive index, absorption
  * coefficient and extinction coefficient per bin from sample and reference amplitude /
  * phase spectra (host vectors; f32 in the reference's operation order). */

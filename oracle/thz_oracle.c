@@ -19,6 +19,7 @@
  */
 #define _GNU_SOURCE
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -679,6 +680,73 @@ void thz_oracle_pipeline(const float *data_in, const float *time, int nx, int ny
         free(work); free(spec); free(ph); free(tr);
     }
     rplan_free_f(r);
+}
+
+/* ConfigCommand::OpenRef, data_thread.rs:372-588: index-shift alignment of a reference pulse
+ * to the scan's time axis (:405-481), window with the reference file's own time axis
+ * (:490-515; zip stops at the shorter of the two), transform with the scan's plan, |X| and
+ * unwrapped phase (:517-533).  Returns 0; -1 where the reference would panic (ndarray Zip of
+ * unequal lengths in the non-adapted windows); align_mode: 0 untouched, 1 shifted, 2 naive. */
+int thz_oracle_open_ref(const float *scan_time, int nt, const float *ref_time, const float *ref_signal, int nref,
+                        int window_type, float win_lo, float win_hi, float *reference_out, float *amp_out,
+                        float *phase_out, int *align_mode)
+{
+    float *ref = reference_out;
+    int mode = 0;
+    if (nt != nref || (nref > 0 && fabsf(scan_time[0] - ref_time[0]) > 1e-9f)) {
+        if (nt > 1 && nref > 1) {
+            mode = 1;
+            for (int i = 0; i < nt; ++i) ref[i] = 0.0f;
+            const float ref_dt = ref_time[1] - ref_time[0];
+            const float time_offset = scan_time[0] - ref_time[0];
+            const float q = roundf(time_offset / ref_dt);
+            long index_offset;
+            if (isnan(q)) index_offset = 0;            /* Rust `as isize`: NaN -> 0, saturating */
+            else if (q >= 9.2e18f) index_offset = LONG_MAX;
+            else if (q <= -9.2e18f) index_offset = LONG_MIN;
+            else index_offset = (long)q;
+            size_t src_start = index_offset > 0 ? (size_t)index_offset : 0;
+            size_t dst_start = index_offset < 0 ? (size_t)(-(index_offset + 1)) + 1 : 0;
+            size_t src_len = (size_t)nref > src_start ? (size_t)nref - src_start : 0;
+            size_t dst_len = (size_t)nt > dst_start ? (size_t)nt - dst_start : 0;
+            size_t copy_len = src_len < dst_len ? src_len : dst_len;
+            for (size_t i = 0; i < copy_len; ++i) ref[dst_start + i] = ref_signal[src_start + i];
+        } else {
+            mode = 2;
+            for (int i = 0; i < nt; ++i) ref[i] = i < nref ? ref_signal[i] : 0.0f;
+        }
+    } else {
+        for (int i = 0; i < nt; ++i) ref[i] = ref_signal[i];
+    }
+    if (align_mode) *align_mode = mode;
+    if (window_type == WIN_ADAPTED_BLACKMAN) {
+        const int m = nt < nref ? nt : nref;
+        if (nref > 0) {
+            const float t0 = ref_time[0], tn = ref_time[nref - 1];
+            for (int i = 0; i < m; ++i) {
+                const float t = ref_time[i];
+                if (t <= win_lo + t0) ref[i] *= thz_oracle_blackman_window(t - t0, 2.0f * win_lo);
+                else if (t >= tn - win_hi) ref[i] *= thz_oracle_blackman_window(t - (tn - win_hi * 2.0f), 2.0f * win_hi);
+            }
+        }
+    } else {
+        if (nt != nref) return -1;
+        thz_oracle_apply_window(window_type, ref, ref_time, nt, win_lo, win_hi);
+    }
+    const int nf = nt / 2 + 1;
+    rplan_f *r = rplan_new_f(nt);
+    cpx_f *spec = (cpx_f *)malloc(sizeof(cpx_f) * (size_t)nf);
+    cpx_f *work = (cpx_f *)malloc(sizeof(cpx_f) * (size_t)(2 * nt + 4));
+    float *ph = (float *)malloc(sizeof(float) * (size_t)nf);
+    rfft_f(r, ref, spec, work);
+    for (int k = 0; k < nf; ++k) {
+        amp_out[k] = hypotf(spec[k].re, spec[k].im);
+        ph[k] = atan2f(spec[k].im, spec[k].re);
+    }
+    thz_oracle_numpy_unwrap(ph, nf, 2.0f * PI_F, phase_out);
+    free(ph); free(work); free(spec);
+    rplan_free_f(r);
+    return 0;
 }
 
 /* calculate_optical_properties, math_tools.rs:663-701: refractive index, absorption

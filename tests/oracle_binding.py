@@ -375,6 +375,17 @@ def voxel_instances(opacity, threshold, time_span, scaling, orig_dims):
     return out, tuple(float(x) for x in dims)
 
 
+def open_ref(scan_time, ref_time, ref_signal, wtype=0, lo=1.0, hi=7.0):
+    """OpenRef -> (reference, amplitudes, phases, align_mode) or None where the reference panics"""
+    st, rt, rs = f32(scan_time), f32(ref_time), f32(ref_signal)
+    nt, nf = st.size, st.size // 2 + 1
+    ref, amp, ph = np.empty(nt, np.float32), np.empty(nf, np.float32), np.empty(nf, np.float32)
+    mode = C.c_int()
+    rc = lib().thz_oracle_open_ref(_p(st), C.c_int(nt), _p(rt), _p(rs), C.c_int(rs.size), C.c_int(wtype),
+                                   C.c_float(lo), C.c_float(hi), _p(ref), _p(amp), _p(ph), C.byref(mode))
+    return None if rc else (ref, amp, ph, mode.value)
+
+
 def optical_properties(sample_amp, sample_phase, ref_amp, ref_phase, freq, thickness):
     a, p, ra, rp, f = (f32(x) for x in (sample_amp, sample_phase, ref_amp, ref_phase, freq))
     out = [np.empty(f.size, np.float32) for _ in range(3)]

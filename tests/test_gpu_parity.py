@@ -475,3 +475,36 @@ def test_wiener_and_water_lines_chain(engine):
     assert np.all(F[:, 0, 1] == 0) and np.all(F[:, -1, 1] == 0)  # C2R precondition (SURVEY a'-4)
     for b in (d_ref, d_w, d_rf, d_x, d_fft, d_amp, d_ph, d_H, d_n, d_out):
         b.free()
+
+
+# ---- reference pulse ingestion (ConfigCommand::OpenRef, data_thread.rs:372-588) -------------
+@pytest.mark.parametrize("nt,shift,nref,wtype", [(1024, 0, 1024, 0), (1024, 40, 1024, 0), (1024, -25, 900, 0),
+                                                 (1001, 3, 1200, 0), (2048, 0, 2048, 3), (256, 0, 256, 4)])
+def test_reference_spectrum_vs_oracle(engine, nt, shift, nref, wtype):
+    scan_t = synth.make_time(nt)
+    ref_t = (np.float32(1000.0 + 0.05 * shift) + np.float32(0.05) * np.arange(nref, dtype=np.float32)).astype(np.float32)
+    z = (ref_t - (ref_t[0] + np.float32(9.0))) / np.float32(0.35)
+    ref_s = (-z * np.exp(-z * z) + 0.002 * np.sin(ref_t)).astype(np.float32)
+    got = engine.reference_spectrum(scan_t, ref_t, ref_s, wtype, 1.0, 7.0)
+    want = ob.open_ref(scan_t, ref_t, ref_s, wtype, 1.0, 7.0)
+    assert want is not None
+    assert np.array_equal(got[0], want[0])                       # aligned + windowed pulse: f32 products
+    assert rel(got[1], want[1]) < TOL
+    # unwrapped phase: bins at the fp32 rounding floor (this pulse has no noise floor of its own)
+    # carry no phase information; compare where the amplitude is above 1e-3 of the maximum
+    strong = want[1] > 1e-3 * want[1].max()
+    d = got[2].astype(np.float64) - want[2]
+    jumps = np.round(d / (2 * np.pi))
+    assert np.abs(d - 2 * np.pi * jumps)[strong].max() < 3e-3
+    lead = np.argmin(strong[1:]) + 1 if not strong[1:].all() else strong.size
+    assert not jumps[:lead].any()
+
+
+def test_reference_spectrum_rejects_what_the_reference_panics_on(engine):
+    scan_t = synth.make_time(512)
+    ref_t = synth.make_time(400)
+    ref_s = np.ones(400, np.float32)
+    assert ob.open_ref(scan_t, ref_t, ref_s, 3) is None             # Hamming + unequal lengths: ndarray Zip panic
+    with pytest.raises(pkg.ThzError):
+        engine.reference_spectrum(scan_t, ref_t, ref_s, 3)
+    engine.reference_spectrum(scan_t, ref_t, ref_s, 0)              # the adapted Blackman zips to the shorter one

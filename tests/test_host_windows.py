@@ -135,3 +135,39 @@ def test_optical_properties_match_oracle_and_known_answers():
     lag = (2 * np.pi * freq.astype(np.float64) * 1e12 * d / 2.99792458e8 * 0.5).astype(np.float32)
     n2, _, _ = pkg.host_optical_properties(ra, rp + lag, ra, rp, freq, float(d))
     assert np.abs(n2[1:] - 1.5).max() < 1e-3
+
+
+def _pulse(t, tc):
+    z = (t - np.float32(tc)) / np.float32(0.35)
+    return (-z * np.exp(-z * z)).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["same", "later_start", "earlier_start", "shorter", "longer", "single_point"])
+def test_align_reference_matches_oracle(case):
+    """ConfigCommand::OpenRef alignment, data_thread.rs:405-481"""
+    nt = 400
+    scan_t = (np.float32(1000.0) + np.float32(0.05) * np.arange(nt, dtype=np.float32)).astype(np.float32)
+    if case == "same":
+        ref_t = scan_t.copy()
+    elif case == "later_start":       # reference axis starts 37 samples after the scan's -> shifted right
+        ref_t = (scan_t + np.float32(0.05 * 37)).astype(np.float32)
+    elif case == "earlier_start":     # -> shifted left, head dropped
+        ref_t = (scan_t - np.float32(0.05 * 21)).astype(np.float32)
+    elif case == "shorter":
+        ref_t = scan_t[:300].copy()
+    elif case == "longer":
+        ref_t = (np.float32(998.0) + np.float32(0.05) * np.arange(520, dtype=np.float32)).astype(np.float32)
+    else:
+        ref_t = scan_t[:1].copy()
+    ref_s = _pulse(ref_t, ref_t[0] + 8.0) if ref_t.size > 1 else np.array([2.5], np.float32)
+    got, mode = pkg.host_align_reference(scan_t, ref_t, ref_s)
+    ref = ob.open_ref(scan_t, ref_t, ref_s, 0, 0.0, 0.0)     # window bounds 0 -> identity taper
+    assert ref is not None
+    assert mode == ref[3] == {"same": 0, "single_point": 2}.get(case, 1)
+    assert np.array_equal(got, ref[0])
+    if case == "later_start":
+        assert np.array_equal(got[37:], ref_s[:nt - 37]) and not got[:37].any()
+    if case == "earlier_start":
+        assert np.array_equal(got[:nt - 21], ref_s[21:])
+    if case == "shorter":
+        assert np.array_equal(got[:300], ref_s) and not got[300:].any()

@@ -169,6 +169,8 @@ SYMBOLS = [
     ("thz_session_buffer", _P, [_P, C.c_int]),
     ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
+    ("thz_host_align_reference", C.c_int, [_P, _SZ, _P, _P, _SZ, _P]),
+    ("thz_reference_spectrum", C.c_int, [_P, _P, _SZ, _P, _P, _SZ, C.POINTER(WindowCfg), _P, _P, _P]),
     ("thz_host_optical_properties", C.c_int, [_P, _P, _P, _P, _P, _SZ, C.c_float, _P, _P, _P]),
     ("thz_voxel_cfg_default", C.c_int, [C.POINTER(VoxelCfg)]),
     ("thz_host_gaussian_kernel1d", C.c_int, [C.c_float, C.c_int, _P]),
@@ -310,6 +312,17 @@ def host_band_psf(psf: Psf, center_freq, dx, dy, img_rows, img_cols):
     _rc(L.thz_host_band_psf(C.byref(psf), center_freq, dx, dy, img_rows, img_cols, out.ctypes.data,
                             C.byref(r), C.byref(c)), "band_psf")
     return out
+
+
+def host_align_reference(scan_time, ref_time, ref_signal):
+    """OpenRef alignment -> (aligned reference of the scan's length, mode 0/1/2)"""
+    st, rt, rs = (np.ascontiguousarray(x, np.float32) for x in (scan_time, ref_time, ref_signal))
+    out = np.empty(st.size, np.float32)
+    mode = load_library().thz_host_align_reference(st.ctypes.data, st.size, rt.ctypes.data, rs.ctypes.data, rs.size,
+                                                   out.ctypes.data)
+    if mode < 0:
+        raise ThzError(mode, "thz_host_align_reference")
+    return out, mode
 
 
 def host_optical_properties(sample_amp, sample_phase, ref_amp, ref_phase, freq, thickness):
@@ -577,6 +590,17 @@ class Engine:
         if rc < 0:
             self._check(rc)
         return rc
+
+    def reference_spectrum(self, scan_time, ref_time, ref_signal, window_type=0, lower=1.0, upper=7.0):
+        """OpenRef -> (aligned + windowed reference, amplitudes, unwrapped phases)"""
+        st, rt, rs = (np.ascontiguousarray(x, np.float32) for x in (scan_time, ref_time, ref_signal))
+        nf = st.size // 2 + 1
+        ref, amp, ph = np.empty(st.size, np.float32), np.empty(nf, np.float32), np.empty(nf, np.float32)
+        w = WindowCfg(window_type, lower, upper)
+        self._check(self.lib.thz_reference_spectrum(self.ctx, st.ctypes.data, st.size, rt.ctypes.data, rs.ctypes.data,
+                                                    rs.size, C.byref(w), ref.ctypes.data, amp.ctypes.data,
+                                                    ph.ctypes.data))
+        return ref, amp, ph
 
     def voxel_opacity(self, npix, nt, d_data, cfg: VoxelCfg, d_opacity):
         self._check(self.lib.thz_voxel_opacity(self.ctx, npix, nt, _dp(d_data), C.byref(cfg), _dp(d_opacity)))

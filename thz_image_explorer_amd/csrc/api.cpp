@@ -259,6 +259,42 @@ size_t thz_host_tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, do
     return tilt_plan(time, nt, nx, ny, tilt_x_deg, tilt_y_deg, dx, dy, new_time, insert_index);
 }
 
+int thz_host_align_reference(const float *scan_time, size_t nt, const float *ref_time, const float *ref_signal,
+                             size_t nref, float *out)
+{
+    if (!scan_time || !out || nt == 0 || (nref && (!ref_time || !ref_signal))) return THZ_ERR_INVALID;
+    return align_reference(scan_time, nt, ref_time, ref_signal, nref, out);
+}
+
+int thz_reference_spectrum(thz_ctx *ctx, const float *scan_time, size_t nt, const float *ref_time,
+                           const float *ref_signal, size_t nref, const thz_window_cfg *window,
+                           float *reference_out, float *amplitudes, float *phases)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (!scan_time || nt < 2 || !window || !reference_out || !amplitudes || !phases
+        || (nref && (!ref_time || !ref_signal)))
+        return fail(ctx, THZ_ERR_INVALID, "thz_reference_spectrum: bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    std::vector<float> win(nt);
+    if (!reference_window(window->type, ref_time, nref, window->lower, window->upper, nt, win.data()))
+        return fail(ctx, THZ_ERR_INVALID,
+                    "thz_reference_spectrum: this window needs a reference of the scan's length (the reference panics)");
+    align_reference(scan_time, nt, ref_time, ref_signal, nref, reference_out);
+    for (size_t i = 0; i < nt; ++i) reference_out[i] *= win[i];
+    if (!ctx->have_plan || ctx->time.size() != nt || std::memcmp(ctx->time.data(), scan_time, nt * sizeof(float)) != 0)
+        if (int rc = thz_set_time_axis(ctx, scan_time, nt)) return rc;
+    const size_t nf = nt / 2 + 1;
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, (nt + 2 * nf) * sizeof(float)));
+    int rc = thz_memcpy_h2d(ctx, d, reference_out, nt * sizeof(float));
+    if (!rc) rc = thz_fft(ctx, 1, d, nullptr, nullptr, nullptr, nullptr, d + nt, d + nt + nf, nullptr);
+    if (!rc) rc = thz_memcpy_d2h(ctx, amplitudes, d + nt, nf * sizeof(float));
+    if (!rc) rc = thz_memcpy_d2h(ctx, phases, d + nt + nf, nf * sizeof(float));
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
 int thz_host_optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
                                 const float *ref_phase, const float *freq, size_t nf, float thickness,
                                 float *refractive_index, float *absorption_coeff, float *extinction_coeff)

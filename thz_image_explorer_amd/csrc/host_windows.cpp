@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <limits>
+#include <vector>
 
 namespace thz {
 
@@ -187,6 +188,51 @@ size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt
             }
     }
     return num_steps;
+}
+
+// ConfigCommand::OpenRef, data_thread.rs:405-481: zero-padded index-shift alignment of a
+// reference pulse to the scan's time axis.  Returns 0 untouched, 1 shifted, 2 naive resize.
+int align_reference(const float *scan_time, size_t nt, const float *ref_time, const float *ref_signal, size_t nref,
+                    float *out)
+{
+    if (!(nt != nref || (nref > 0 && std::fabs(scan_time[0] - ref_time[0]) > 1e-9f))) {
+        for (size_t i = 0; i < nt; ++i) out[i] = ref_signal[i];
+        return 0;
+    }
+    if (nt > 1 && nref > 1) {
+        for (size_t i = 0; i < nt; ++i) out[i] = 0.0f;
+        const float ref_dt = ref_time[1] - ref_time[0];
+        const float time_offset = scan_time[0] - ref_time[0];
+        const float q = std::round(time_offset / ref_dt);
+        // Rust `as isize`: NaN -> 0, saturating at the ends
+        long long index_offset = 0;
+        if (q >= 9.2e18f) index_offset = std::numeric_limits<long long>::max();
+        else if (q <= -9.2e18f) index_offset = std::numeric_limits<long long>::min();
+        else if (q == q) index_offset = (long long)q;
+        const size_t src_start = index_offset > 0 ? (size_t)index_offset : 0;
+        const size_t dst_start = index_offset < 0 ? (size_t)(-(index_offset + 1)) + 1 : 0;
+        const size_t src_len = nref > src_start ? nref - src_start : 0;
+        const size_t dst_len = nt > dst_start ? nt - dst_start : 0;
+        const size_t copy_len = src_len < dst_len ? src_len : dst_len;
+        for (size_t i = 0; i < copy_len; ++i) out[dst_start + i] = ref_signal[src_start + i];
+        return 1;
+    }
+    for (size_t i = 0; i < nt; ++i) out[i] = i < nref ? ref_signal[i] : 0.0f;
+    return 2;
+}
+
+// Window step of OpenRef (:490-515): the multiplier comes from the reference file's own time
+// axis; the adapted Blackman stops at the shorter of signal and axis (iter().zip()), the
+// other windows need equal lengths (ndarray Zip panics otherwise) -> false.
+bool reference_window(int type, const float *ref_time, size_t nref, float lower, float upper, size_t nt, float *win)
+{
+    for (size_t i = 0; i < nt; ++i) win[i] = 1.0f;
+    if (type != 0 && nref != nt) return false;
+    if (nref == 0) return true;
+    std::vector<float> w(nref);
+    fft_window(type, ref_time, nref, lower, upper, w.data());
+    for (size_t i = 0; i < nt && i < nref; ++i) win[i] = w[i];
+    return true;
 }
 
 // calculate_optical_properties, math_tools.rs:663-701 (f32, the reference's operation order)

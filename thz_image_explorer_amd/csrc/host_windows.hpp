@@ -15,6 +15,9 @@ void water_line_mask(const float *freq, size_t nf, const float *lines, size_t n_
 void wiener_filter(const float *ref_fft, size_t nf, float eps_rel, float *out);
 size_t tilt_plan(const float *time, size_t nt, size_t nx, size_t ny, double tilt_x_deg,
                  double tilt_y_deg, float dx, float dy, float *new_time, int32_t *insert_index);
+int align_reference(const float *scan_time, size_t nt, const float *ref_time, const float *ref_signal, size_t nref,
+                    float *out);
+bool reference_window(int type, const float *ref_time, size_t nref, float lower, float upper, size_t nt, float *win);
 void optical_properties(const float *sample_amp, const float *sample_phase, const float *ref_amp,
                         const float *ref_phase, const float *freq, size_t nf, float thickness, float *n_out,
                         float *alpha_out, float *kappa_out);
