@@ -89,3 +89,72 @@ def test_slab_partition_covers_grid():
             assert sum(n for _, n in rows) == nx
             for (a, n), (b, _) in zip(rows, rows[1:]):
                 assert a + n == b
+
+
+# ---- voxel threshold of a cube spread over two ranks (shard.voxel_threshold) -----------------
+def _float_keys(v):
+    b = np.ascontiguousarray(v, np.float32).view(np.uint32)
+    return np.where(b & 0x80000000, ~b, b | 0x80000000).astype(np.uint32)
+
+
+def _numpy_hist(vals):
+    """stand-in for thz_select_histogram on a CPU-only box: same bins, same floor rule"""
+    keys = _float_keys(vals)
+
+    def hist(level, prefix):
+        if level == 0:
+            return np.bincount(np.maximum(keys >> 21, prefix), minlength=2048).astype(np.uint64)
+        if level == 1:
+            return np.bincount((keys[(keys >> 21) == prefix] >> 10) & 2047, minlength=2048).astype(np.uint64)
+        return np.bincount(keys[(keys >> 10) == prefix] & 1023, minlength=2048).astype(np.uint64)
+
+    return hist
+
+
+def _voxel_worker(rank, world, port, seed, n, k, tiny, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from thz_image_explorer_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vals = _voxel_values(seed, n, tiny)
+    x0, nl = shard.slab(n, world, rank)
+    thr = shard.voxel_threshold(_numpy_hist(vals[x0:x0 + nl]), nl, k, dist)
+    q.put((rank, thr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _voxel_values(seed, n, tiny):
+    rng = np.random.default_rng(seed)
+    v = rng.random(n).astype(np.float32)
+    v[rng.random(n) < 0.5] = 0.0
+    v[rng.random(n) < 0.05] = np.float32(1.0)
+    if tiny:
+        v *= np.float32(1e-5)      # the k-th largest falls below the level-0 floor -> second level-0 round
+    return v
+
+
+@pytest.mark.parametrize("n,k,tiny", [(50_001, 2_000, False), (50_001, 30_000, False), (20_000, 500, True),
+                                      (1_000, 5_000, False)])
+def test_two_rank_voxel_threshold(n, k, tiny):
+    import torch.multiprocessing as mp
+
+    world, seed = 2, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_voxel_worker, args=(r, world, port, seed, n, k, tiny, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vals = _voxel_values(seed, n, tiny)
+    want = 0.0 if n <= k else float(np.sort(vals)[::-1][k - 1])
+    assert got[0] == got[1] == want

@@ -159,3 +159,28 @@ def test_full_size_properties(engine):
     assert np.array_equal(inst["color"][:, 3], op[op >= thr])     # x, y, z order == C order of the cube
     for b in (d_time, d_cube, d_gain, d_op, d_inst):
         b.free()
+
+
+def test_sharded_select_matches_single_gpu(engine):
+    """shard.select_kth_largest over two x-slab tiles of one cube (histograms add up; on N GPUs the
+    sum is an all-reduce) gives the element thz_kth_largest finds on the whole cube"""
+    from thz_image_explorer_amd import shard
+
+    rng = np.random.default_rng(8)
+    n = 400_003
+    v = rng.random(n).astype(np.float32)
+    v[rng.random(n) < 0.5] = 0.0
+    d = engine.to_device(v)
+    cut = 4 * (n // 8)                       # second tile starts 16-byte aligned
+    d_hist = engine.alloc(2048 * 8)
+
+    def local_hist(level, prefix):
+        d_hist.zero()
+        engine.select_histogram(d.ptr, cut, level, prefix, d_hist)
+        engine.select_histogram(d.ptr + 4 * cut, n - cut, level, prefix, d_hist)
+        return d_hist.download((2048,), np.uint64)
+
+    for k in (1, 777, 150_000, 250_000):
+        bins = shard.select_kth_largest(local_hist, k)
+        assert pkg.host_select_value(*bins) == engine.kth_largest(d, n, k) == np.sort(v)[::-1][k - 1]
+    d.free(); d_hist.free()

@@ -65,3 +65,58 @@ def all_reduce_cube(t_out, dist=None):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t_out)
     return t_out
+
+
+# ---- 3-D voxel envelope across x-slabs (gui/threed_plot.rs:205-214) ------------------------------
+SELECT_FLOOR_BIN = (0x80000000 | 0x3A800000) >> 21   # keys below 2^-10 are lumped at level 0 (voxel_api.cpp)
+
+
+def select_kth_largest(local_hist, k: int, dist=None, device=None):
+    """Radix select of the k-th largest value (1-based) of a cube that is spread over the ranks.
+
+    `local_hist(level, prefix)` returns this rank's 2048-bin histogram of the level (numpy uint64 /
+    sequence; on the GPU: thz_select_histogram into a zeroed buffer, then a 16 KB download).
+    Histograms of tiles add up, so every level costs one all-reduce of 2048 int64 — the only exchange
+    step; every rank ends with the same three bins.  Returns (bin0, bin1, bin2); the value is
+    binding.host_select_value(*bins)."""
+    import numpy as np
+    import torch
+
+    from . import binding
+
+    def reduced(level, prefix):
+        h = torch.from_numpy(np.ascontiguousarray(local_hist(level, prefix), np.uint64).view(np.int64).copy())
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            if device is not None:
+                h = h.to(device)
+            dist.all_reduce(h)
+            h = h.cpu()
+        return h.numpy().view(np.uint64)
+
+    floor = SELECT_FLOOR_BIN
+    while True:
+        b0, rank_in = binding.host_select_step(reduced(0, floor), k)
+        if floor == 0 or b0 != floor:
+            break
+        floor = 0     # the k-th largest lies in the lump: repeat level 0 in full
+    b1, rank_in = binding.host_select_step(reduced(1, b0), rank_in)
+    b2, _ = binding.host_select_step(reduced(2, (b0 << 11) | b1)[:1024], rank_in)
+    return b0, b1, b2
+
+
+def voxel_threshold(local_hist, n_local: int, max_instances: int, dist=None, device=None) -> float:
+    """effective threshold of instance_from_data for a sharded opacity cube: 0.0 when the whole cube
+    has no more than max_instances voxels, else the max_instances-th largest opacity."""
+    import torch
+
+    from . import binding
+
+    n = torch.tensor([n_local], dtype=torch.int64)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None:
+            n = n.to(device)
+        dist.all_reduce(n)
+        n = n.cpu()
+    if int(n.item()) <= max_instances:
+        return 0.0
+    return binding.host_select_value(*select_kth_largest(local_hist, max_instances, dist, device))
