@@ -333,6 +333,13 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
 int thz_synth_cube(thz_ctx *ctx, float *d_out, size_t ntraces, uint64_t first_trace,
                    const float *d_time, uint32_t seed, int subtract_bias);
 
+/* Measurement aid (not a reference function): moves the bytes of thz_pipeline in its access
+ * shape — per trace read nt floats, write 2 nf + nf + nf + nt floats to four arrays — with no
+ * arithmetic, so that the roofline can be quoted against what the memory system gives this
+ * traffic pattern as well as against the 8 TB/s spec.  nt % 8 == 0; time under THZ_STAGE_PROBE. */
+int thz_traffic_probe(thz_ctx *ctx, size_t npix, size_t nt, const float *d_in, float *d_fft, float *d_amp,
+                      float *d_phase, float *d_data_out);
+
 /* ------------------------------------------------------------------ */
 /* Resident cube + whole-chain recompute ("session")                    */
 /* ------------------------------------------------------------------ */
@@ -514,7 +521,8 @@ enum {
     THZ_STAGE_VOXEL_OPACITY = 8,
     THZ_STAGE_VOXEL_SELECT = 9,
     THZ_STAGE_VOXEL_EMIT = 10,
-    THZ_STAGE_COUNT = 11
+    THZ_STAGE_PROBE = 11,
+    THZ_STAGE_COUNT = 12
 };
 /* hipEvent bracketing of every stage call on the context's stream.
  *   0  off (default)

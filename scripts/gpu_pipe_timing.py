@@ -16,8 +16,12 @@ d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empt
 cases = [("pipeline", lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img), 16 * nt + 20),
          ("fwd M_fwd", lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, None, None, d_fd), 8 * nt + 8),
          ("fwd all", lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, d_amp, d_ph, d_fd), 4 * nt + 16 * nf),
+         ("probe", lambda: eng.traffic_probe(npix, nt, d_raw, d_fft, d_amp, d_ph, d_out), 16 * nt + 16),
          ("inv", lambda: eng.ifft(npix, d_fft, d_post, d_out, d_img), 8 * nf + 4 * nt + 4)]
+only = os.environ.get('THZ_ONLY')
 for name, fn, b in cases:
+    if only and name != only:
+        continue
     fn(); eng.sync()
     ts = []
     for _ in range(7):

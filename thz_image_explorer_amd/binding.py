@@ -21,7 +21,7 @@ STATUS = {0: "THZ_OK", -1: "THZ_ERR_INVALID", -2: "THZ_ERR_UNSUPPORTED", -3: "TH
 
 WIN_ADAPTED_BLACKMAN, WIN_BLACKMAN, WIN_HANNING, WIN_HAMMING, WIN_FLAT_TOP = range(5)
 STAGE_FFT, STAGE_FD_MASK, STAGE_IFFT, STAGE_PIPELINE, STAGE_TD_WINDOW, STAGE_INTENSITY, \
-    STAGE_MEAN, STAGE_ROI, STAGE_VOXEL_OPACITY, STAGE_VOXEL_SELECT, STAGE_VOXEL_EMIT = range(11)
+    STAGE_MEAN, STAGE_ROI, STAGE_VOXEL_OPACITY, STAGE_VOXEL_SELECT, STAGE_VOXEL_EMIT, STAGE_PROBE = range(12)
 
 
 class WindowCfg(C.Structure):
@@ -172,6 +172,7 @@ SYMBOLS = [
     ("thz_host_align_reference", C.c_int, [_P, _SZ, _P, _P, _SZ, _P]),
     ("thz_reference_spectrum", C.c_int, [_P, _P, _SZ, _P, _P, _SZ, C.POINTER(WindowCfg), _P, _P, _P]),
     ("thz_host_optical_properties", C.c_int, [_P, _P, _P, _P, _P, _SZ, C.c_float, _P, _P, _P]),
+    ("thz_traffic_probe", C.c_int, [_P, _SZ, _SZ, _P, _P, _P, _P, _P]),
     ("thz_voxel_cfg_default", C.c_int, [C.POINTER(VoxelCfg)]),
     ("thz_host_gaussian_kernel1d", C.c_int, [C.c_float, C.c_int, _P]),
     ("thz_voxel_opacity", C.c_int, [_P, _SZ, _SZ, _P, C.POINTER(VoxelCfg), _P]),
@@ -628,6 +629,10 @@ class Engine:
                                                  scaling, orig_dims[0], orig_dims[1], orig_dims[2], _dp(d_out),
                                                  capacity, C.byref(n), dims.ctypes.data))
         return n.value, tuple(float(x) for x in dims)
+
+    def traffic_probe(self, npix, nt, d_in, d_fft, d_amp, d_phase, d_out):
+        self._check(self.lib.thz_traffic_probe(self.ctx, npix, nt, _dp(d_in), _dp(d_fft), _dp(d_amp), _dp(d_phase),
+                                               _dp(d_out)))
 
     def synth_cube(self, d_out, ntraces, first_trace, d_time, seed=0x7A3D2026, subtract_bias=True):
         self._check(self.lib.thz_synth_cube(self.ctx, _dp(d_out), ntraces, first_trace, _dp(d_time),

@@ -156,9 +156,21 @@ struct FPlan {
     static constexpr int T2_ENTRIES = R2 * R3;
     static constexpr int MASK_ENTRIES = (N + 4) / 2;  // N + 1 floats, padded to 16 bytes
     static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
+    // Small trace-invariant tables the trace loop reads, staged once per block so that no
+    // vector-memory load sits between the loop's stores (a load's result can only be waited
+    // for together with every store issued before it):
+    //   W2N_HEAD  split twiddles w2n[0 .. 255] (the per-lane factors of both epilogues)
+    //   WG        w2n[M1 * j], j < R1 (their wave-uniform partners; 256 g = M1 * (256 g / M1))
+    //   WIN_SLOTS edge blocks of the time multipliers that are not all ones (f_edge_only)
+    static constexpr int W2N_HEAD = 256;
+    static constexpr int WG_ENTRIES = 16;
+    static constexpr int WIN_BLK = NT / R1;  // floats per window block = 2 C1 * 64
+    static constexpr int WIN_SLOTS = (N >= 2048) ? 4 : 6;  // 160 KB LDS leaves room for 4 at nt = 4096
+    static constexpr int EXTRA_ENTRIES = W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
+    static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
     static constexpr size_t lds_bytes(int waves)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + EXTRA_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -448,6 +460,34 @@ __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane
     }
 }
 
+// Edge block j of a time multiplier: from its LDS slot when it was staged, else from memory.
+template <class P>
+__device__ __forceinline__ void f_win_block(const float *__restrict__ w, const float *win_s, int slot, int lane,
+                                            int j1, float (&out)[2 * P::C1])
+{
+    if (slot >= 0) {
+        const float *src = win_s + slot * P::WIN_BLK + 2 * P::C1 * lane;
+        if constexpr (P::C1 == 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(src);
+            out[0] = v.x; out[1] = v.y;
+        }
+    } else {
+        f_load_win<P>(w, lane, j1, out);
+    }
+}
+
+// slot of edge block j (0, R1-2 or R1-1) in a packed slot word: 4 bits each, 15 = not staged
+template <class P>
+__device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
+{
+    const int e = j == 0 ? 0 : (j == P::R1 - 2 ? 1 : 2);
+    const int v = (int)((slots >> (4 * e)) & 15u);
+    return v == 15 ? -1 : v;
+}
+
 // Spectrum epilogue.  buf holds Z[0..N] in the nat() layout; on return it holds
 // the (unmasked) spectrum X[0..N] in the same layout.
 //   groups g <  NG/2: the lane owns bins k = 256 g + 4 lane + c AND their mirrors
@@ -459,7 +499,7 @@ __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane
 //   bin N           : lane 0, after the last group
 // so the unwrap scan always runs over ascending bins.
 template <class P, bool AMP_PHASE>
-__device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *__restrict__ w2n,
+__device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane)
 {
@@ -470,7 +510,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *__restric
     constexpr bool want_phase = AMP_PHASE;
     cx wl[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) wl[c] = w2n[4 * lane + c];
+    for (int c = 0; c < 4; ++c) wl[c] = w2n_s[4 * lane + c];
     float carry = 0.0f;       // sum of adjusted differences of all previous groups
     float prev_tail = 0.0f;   // raw phase of the last bin of the previous group
     float first = 0.0f;       // raw phase of bin 0
@@ -490,7 +530,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *__restric
         cx X[4];
         if (g < NG / 2) {
             cx *zm = buf - 256 * g;
-            const cx wg = w2n[256 * g];  // wave-uniform
+            const cx wg = wg_s[(256 / P::M1) * g];  // w2n[256 g], wave-uniform
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const cx a = zf[fb[c]], b = zm[mb[c]];
@@ -580,14 +620,14 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *__restric
 // the band-pass mask on the way (fused chain; the stored copy is unmasked so
 // that the phases of the whole spectrum could be taken).
 template <class P, bool MASKED>
-__device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *__restrict__ w2n,
+__device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, const cx *wg_s,
                                                 const float *__restrict__ mask, int lane,
                                                 cx (&r)[P::C1][P::R1])
 {
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
     cx wl[C1];
 #pragma unroll
-    for (int c = 0; c < C1; ++c) wl[c] = w2n[C1 * lane + c];
+    for (int c = 0; c < C1; ++c) wl[c] = w2n_s[C1 * lane + c];
     // n = M1 j1 + C1 lane + c and its mirror N - n; M1 is a multiple of 32*4 only for
     // C1 = 2 (M1 = 128), so (n >> 5) & 3 is lane-constant there; for C1 = 1 (M1 = 64)
     // it alternates with j1 & 1 -> two base variants cover both plans.
@@ -604,7 +644,7 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *__restr
     const int mk_r = launder_v(N - TOP - C1 * lane);       // mask[N - n] = mask[mk_r + TOP - (M1 j1 + c)]
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
-        const cx wg = w2n[M1 * j1];  // wave-uniform
+        const cx wg = wg_s[j1];  // w2n[M1 j1], wave-uniform
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
             const int off = M1 * j1 + c;
@@ -655,7 +695,8 @@ __device__ __forceinline__ bool f_block_on(uint32_t blocks, int j)
 
 template <class P, bool WIN_FULL>
 __device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const FArgs &A,
-                                                uint32_t post_blocks, int lane)
+                                                uint32_t post_blocks, const float *win_s, uint32_t post_slots,
+                                                int lane)
 {
     constexpr int NT = P::NT, R1 = P::R1, C1 = P::C1;
     const float fnt = (float)NT;
@@ -683,7 +724,8 @@ __device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const F
         }
         if (f_block_on<P, WIN_FULL>(post_blocks, j)) {
             float w[2 * C1];
-            f_load_win<P>(post_w, lane, j, w);
+            if constexpr (WIN_FULL) f_load_win<P>(post_w, lane, j, w);
+            else f_win_block<P>(post_w, win_s, f_slot_of<P>(post_slots, j), lane, j, w);
 #pragma unroll
             for (int i = 0; i < 2 * C1; ++i) v[i] *= w[i];
         }
@@ -715,7 +757,12 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     cx *t1 = reinterpret_cast<cx *>(lds);
     cx *t2 = t1 + P::T1_ENTRIES;
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES);
-    cx *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    cx *w2n_s = t2 + P::T2_ENTRIES + P::MASK_ENTRIES;
+    cx *wg_s = w2n_s + P::W2N_HEAD;
+    float *win_s = reinterpret_cast<float *>(wg_s + P::WG_ENTRIES);
+    cx *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + P::EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = T.w2n[i];
+    if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[P::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
     if (MODE != kInv)
@@ -739,6 +786,32 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     const uint32_t post_blocks = THZ_UNIFORM((int)bits[1]);
     const bool pre_edge = f_edge_only<P>(pre_blocks);
     const bool post_edge = f_edge_only<P>(post_blocks);
+    // LDS slots for the edge blocks that are on (4 bits per candidate, 15 = stays in memory)
+    uint32_t pre_slots = 0xfffu, post_slots = 0xfffu;
+    {
+        int next = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int j = e == 0 ? 0 : (e == 1 ? R1 - 2 : R1 - 1);
+            if (MODE != kInv && pre_edge && ((pre_blocks >> j) & 1u) && next < P::WIN_SLOTS) {
+                pre_slots = (pre_slots & ~(15u << (4 * e))) | ((uint32_t)next << (4 * e));
+                for (int i = (int)threadIdx.x; i < P::WIN_BLK; i += (int)blockDim.x)
+                    win_s[next * P::WIN_BLK + i] = A.pre_win[j * P::WIN_BLK + i];
+                ++next;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int j = e == 0 ? 0 : (e == 1 ? R1 - 2 : R1 - 1);
+            if (MODE != kFwd && post_edge && ((post_blocks >> j) & 1u) && next < P::WIN_SLOTS) {
+                post_slots = (post_slots & ~(15u << (4 * e))) | ((uint32_t)next << (4 * e));
+                for (int i = (int)threadIdx.x; i < P::WIN_BLK; i += (int)blockDim.x)
+                    win_s[next * P::WIN_BLK + i] = A.post_win[j * P::WIN_BLK + i];
+                ++next;
+            }
+        }
+    }
+    __syncthreads();
 
     FAddr<P> ad;
     ad.init(lane);
@@ -767,7 +840,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 for (int j1 = 0; j1 < R1; ++j1) {
                     if (f_block_on<P, false>(pre_blocks, j1)) {
                         float w[2 * C1];
-                        f_load_win<P>(pre_w, lane, j1, w);
+                        f_win_block<P>(pre_w, win_s, f_slot_of<P>(pre_slots, j1), lane, j1, w);
 #pragma unroll
                         for (int i = 0; i < 2 * C1; ++i) raw[j1][i] *= w[i];
                     }
@@ -793,15 +866,17 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             f_core_pass1<P>(r, buf, t1, ad, lane);
             if (MODE == kFwd && p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
             f_core_pass23<P>(buf, t2, ad, lane);
-            f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform(T.w2n), mask_l, p, A, lane);
+            f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
+                                              mask_l, p, A, lane);
             if constexpr (MODE == kPipe) {
-                f_inverse_input<P, true>(buf, launder_uniform(T.w2n), mask_l, lane, r);
+                f_inverse_input<P, true>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
+                                         lane, r);
                 wave_sync();  // every lane has read Z before the core overwrites buf
                 f_core_pass1<P>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
                 f_core_pass23<P>(buf, t2, ad, lane);
-                if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);
-                else f_time_epilogue<P, true>(buf, p, A, post_blocks, lane);
+                if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
+                else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
                 wave_sync();
             } else {
                 wave_sync();
@@ -825,7 +900,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 if (lane == 0) buf[N] = cx{x_nyq_next, 0.0f};
             }
             wave_sync();
-            f_inverse_input<P, false>(buf, launder_uniform(T.w2n), nullptr, lane, r);
+            f_inverse_input<P, false>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), nullptr,
+                                      lane, r);
             wave_sync();
             f_core_pass1<P>(r, buf, t1, ad, lane);
             if (p + stride < A.npix) {
@@ -833,8 +909,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 x_nyq_next = A.fft_in[(p + stride) * nf + N].x;
             }
             f_core_pass23<P>(buf, t2, ad, lane);
-            if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, lane);
-            else f_time_epilogue<P, true>(buf, p, A, post_blocks, lane);
+            if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
+            else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
             wave_sync();
         }
     }

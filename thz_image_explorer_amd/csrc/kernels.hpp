@@ -116,6 +116,9 @@ void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const flo
                        const uint32_t *counts, const unsigned long long *offsets, const VoxelGeom &g, float *out,
                        unsigned long long capacity);
 
+void launch_traffic_probe(hipStream_t st, size_t npix, int nt, const float *in, float *fft, float *amp, float *ph,
+                          float *out);
+
 void launch_synth(hipStream_t st, float *out, size_t ntraces, int nt, uint64_t first_trace,
                   const float *time, uint32_t seed, int subtract_bias);
 

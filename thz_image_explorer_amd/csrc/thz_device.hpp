@@ -83,8 +83,13 @@ __device__ __forceinline__ float wave_reduce_add(float v) { return wave_bcast<kW
 template <class T>
 __device__ __forceinline__ const T *launder_uniform(const T *p)
 {
-    asm volatile("" : "+s"(p));
-    return p;
+    // p + (opaque 0), not an opaque p: the pointer keeps its provenance, so the compiler still
+    // knows it is global (kernel argument) or LDS and emits global_load / ds_read.  An opaque
+    // pointer turns every access into flat_load, and a flat result can only be waited for with
+    // vmcnt(0) lgkmcnt(0) — which also waits for every store the wave has in flight.
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return p + z;
 }
 
 // Same for a per-lane integer: makes a lane-dependent base index opaque, so that

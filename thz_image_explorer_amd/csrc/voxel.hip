@@ -19,6 +19,7 @@
 #include "thz_device.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace thz {
 
@@ -631,6 +632,66 @@ void launch_voxel_emit(hipStream_t st, size_t npix, int nt, size_t gh, const flo
     else
         THZ_LAUNCH(k_voxel_emit<false>, blocks, 256, 0, st, npix, nt, gh, opacity, counts, offsets, g,
                    reinterpret_cast<float4 *>(out), capacity);
+}
+
+// ---------------------------------------------------------------- traffic probe
+// Measurement aid, not a stage: moves exactly the bytes of the fused chain in its access shape
+// (one wave per trace: read nt floats, write 2 nf + nf + nf + nt floats to four arrays, 16-byte
+// accesses, persistent 256 x 512 grid) with no arithmetic.  Its rate is the ceiling the memory
+// system offers this traffic pattern; bench.py / DESIGN.md quote it beside the 8 TB/s spec.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool NT>
+__device__ __forceinline__ void probe_store(f4u *p, f4u v)
+{
+#ifndef THZ_EMU
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+#else
+    *p = v;
+#endif
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512) void k_traffic_probe(size_t npix, int nt, const float *__restrict__ in,
+                                                       float *__restrict__ fft, float *__restrict__ amp,
+                                                       float *__restrict__ ph, float *__restrict__ out)
+{
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    const size_t stride = (size_t)gridDim.x * wpb;
+    const int nf = nt / 2 + 1;
+    for (size_t trace = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); trace < npix; trace += stride) {
+        const float *src = in + trace * (size_t)nt;
+        float *f = fft + trace * (size_t)(2 * nf), *a = amp + trace * (size_t)nf, *p = ph + trace * (size_t)nf;
+        float *o = out + trace * (size_t)nt;
+        // rows of the spectrum arrays start at 8- / 4-byte boundaries: unaligned 16-byte stores,
+        // like the epilogue of the real kernel
+        for (int e = 4 * lane; e < nt; e += 4 * kWave) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + e);
+            probe_store<NT>(reinterpret_cast<f4u *>(o + e), f4u{v.x, v.y, v.z, v.w});
+            probe_store<NT>(reinterpret_cast<f4u *>(f + e), f4u{v.x, v.y, v.z, v.w});
+        }
+        for (int e = 4 * lane; e < nt / 2; e += 4 * kWave) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + e);
+            probe_store<NT>(reinterpret_cast<f4u *>(a + e), f4u{v.x, v.y, v.z, v.w});
+            probe_store<NT>(reinterpret_cast<f4u *>(p + e), f4u{v.w, v.z, v.y, v.x});
+        }
+        if (lane == 0) { f[nt] = 0.f; f[nt + 1] = 0.f; a[nf - 1] = 0.f; p[nf - 1] = 0.f; }
+    }
+}
+
+void launch_traffic_probe(hipStream_t st, size_t npix, int nt, const float *in, float *fft, float *amp, float *ph,
+                          float *out)
+{
+    // developer knobs for the access-shape experiments of DESIGN.md §6
+    const char *eb = getenv("THZ_PROBE_BLOCKS"), *et = getenv("THZ_PROBE_THREADS"), *en = getenv("THZ_PROBE_NT");
+    const int blocks = eb ? atoi(eb) : 256, threads = et ? atoi(et) : 512;
+    if (blocks < 1 || blocks > 65536 || threads < 64 || threads > 512 || threads % 64) return;
+    if (en && atoi(en))
+        THZ_LAUNCH(k_traffic_probe<true>, blocks, threads, 0, st, npix, nt, in, fft, amp, ph, out);
+    else
+        THZ_LAUNCH(k_traffic_probe<false>, blocks, threads, 0, st, npix, nt, in, fft, amp, ph, out);
 }
 
 }  // namespace thz

@@ -187,4 +187,17 @@ int thz_voxel_instances(thz_ctx *ctx, const float *d_opacity, size_t gw, size_t 
     return THZ_OK;
 }
 
+int thz_traffic_probe(thz_ctx *ctx, size_t npix, size_t nt, const float *d_in, float *d_fft, float *d_amp,
+                      float *d_phase, float *d_data_out)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (!d_in || !d_fft || !d_amp || !d_phase || !d_data_out || nt < 8 || nt % 8 != 0 || nt > (1u << 20))
+        return fail(ctx, THZ_ERR_INVALID, "thz_traffic_probe: bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    if (npix == 0) return THZ_OK;
+    StageTimer t(ctx, THZ_STAGE_PROBE);
+    launch_traffic_probe(ctx->stream, npix, (int)nt, d_in, d_fft, d_amp, d_phase, d_data_out);
+    return check_launch(ctx);
+}
+
 }  // extern "C"
