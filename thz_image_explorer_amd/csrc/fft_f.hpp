@@ -461,11 +461,11 @@ __device__ __forceinline__ void f_load_win(const float *__restrict__ w, int lane
 }
 
 // Edge block j of a time multiplier: from its LDS slot when it was staged, else from memory.
-template <class P>
+template <class P, bool STAGED_ONLY>
 __device__ __forceinline__ void f_win_block(const float *__restrict__ w, const float *win_s, int slot, int lane,
                                             int j1, float (&out)[2 * P::C1])
 {
-    if (slot >= 0) {
+    if (STAGED_ONLY || slot >= 0) {
         const float *src = win_s + slot * P::WIN_BLK + 2 * P::C1 * lane;
         if constexpr (P::C1 == 2) {
             const float4 v = *reinterpret_cast<const float4 *>(src);
@@ -693,7 +693,7 @@ __device__ __forceinline__ bool f_block_on(uint32_t blocks, int j)
     else return false;
 }
 
-template <class P, bool WIN_FULL>
+template <class P, bool WIN_FULL, bool STAGED_ONLY = false>
 __device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const FArgs &A,
                                                 uint32_t post_blocks, const float *win_s, uint32_t post_slots,
                                                 int lane)
@@ -725,7 +725,7 @@ __device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const F
         if (f_block_on<P, WIN_FULL>(post_blocks, j)) {
             float w[2 * C1];
             if constexpr (WIN_FULL) f_load_win<P>(post_w, lane, j, w);
-            else f_win_block<P>(post_w, win_s, f_slot_of<P>(post_slots, j), lane, j, w);
+            else f_win_block<P, STAGED_ONLY>(post_w, win_s, f_slot_of<P>(post_slots, j), lane, j, w);
 #pragma unroll
             for (int i = 0; i < 2 * C1; ++i) v[i] *= w[i];
         }
@@ -743,6 +743,23 @@ __device__ __forceinline__ void f_time_epilogue(const cx *buf, size_t p, const F
         if (lane == 0) A.img[p] = acc;
     }
 }
+
+// Makes the prefetched next trace land *now*.  On gfx9 a vector-memory load can only be waited
+// for with vmcnt(0) while stores of the same wave are in flight (the compiler treats loads and
+// stores in the one counter as unordered), so the wait is taken right before a store phase
+// starts — when the previous stores have long completed — instead of at the top of the next
+// trace, where it would drain the stores just issued.
+template <class P>
+__device__ __forceinline__ void f_land_prefetch(float (&raw)[P::R1][2 * P::C1])
+{
+#pragma unroll
+    for (int j = 0; j < P::R1; ++j)
+#pragma unroll
+        for (int i = 0; i < 2 * P::C1; ++i) raw[j][i] = launder_f(raw[j][i]);
+}
+
+struct FTrue { static constexpr bool value = true; };
+struct FFalse { static constexpr bool value = false; };
 
 template <class P, int MODE, int CFG>
 __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
@@ -828,6 +845,20 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
         }
     }
 
+    // The trace loop exists twice: FAST when every time multiplier is an edge taper whose
+    // blocks all sit in LDS (the default chain) — then the loop issues no vector-memory load
+    // other than the prefetch of the next trace — and the general form.  They are separate
+    // loops rather than branches inside one because the compiler merges the memory-counter
+    // state of all paths at every join: with a memory fallback anywhere in the loop, the common
+    // path waits for vmcnt(0) at the top of each trace, i.e. for all of its own stores.
+    // The first trace's loads are made to land before the loop is entered: at the loop header
+    // the compiler merges "entered from above" with "came around the back edge", and with loads
+    // pending on entry (nothing issued after them) it would wait for vmcnt(0) at the top of
+    // every trace — the back edge has this trace's 16+ stores behind the prefetch, which need
+    // not have completed.
+    f_land_prefetch<P>(raw);
+    auto trace_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     for (; p < A.npix; p += stride) {
         cx r[C1][R1];
         ad.refresh();
@@ -835,12 +866,12 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             const float *pre_w = launder_uniform(A.pre_win);
             const float *mask_l = launder_uniform((const float *)mask_s);
             // window, then hand the samples to pass 1
-            if (pre_edge) {
+            if (FAST || pre_edge) {
 #pragma unroll
                 for (int j1 = 0; j1 < R1; ++j1) {
                     if (f_block_on<P, false>(pre_blocks, j1)) {
                         float w[2 * C1];
-                        f_win_block<P>(pre_w, win_s, f_slot_of<P>(pre_slots, j1), lane, j1, w);
+                        f_win_block<P, FAST>(pre_w, win_s, f_slot_of<P>(pre_slots, j1), lane, j1, w);
 #pragma unroll
                         for (int i = 0; i < 2 * C1; ++i) raw[j1][i] *= w[i];
                     }
@@ -866,6 +897,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             f_core_pass1<P>(r, buf, t1, ad, lane);
             if (MODE == kFwd && p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
             f_core_pass23<P>(buf, t2, ad, lane);
+            if (MODE == kFwd) f_land_prefetch<P>(raw);
             f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
                                               mask_l, p, A, lane);
             if constexpr (MODE == kPipe) {
@@ -875,7 +907,9 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 f_core_pass1<P>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
                 f_core_pass23<P>(buf, t2, ad, lane);
-                if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
+                f_land_prefetch<P>(raw);
+                if (FAST) f_time_epilogue<P, false, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
+                else if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
                 else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
                 wave_sync();
             } else {
@@ -909,11 +943,24 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 x_nyq_next = A.fft_in[(p + stride) * nf + N].x;
             }
             f_core_pass23<P>(buf, t2, ad, lane);
-            if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
+            f_land_prefetch<P>(raw);
+            x_nyq_next = launder_f(x_nyq_next);
+            if (FAST) f_time_epilogue<P, false, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
+                else if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
             else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
             wave_sync();
         }
     }
+    };
+    bool all_staged = true;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int j = e == 0 ? 0 : (e == 1 ? R1 - 2 : R1 - 1);
+        if (MODE != kInv && ((pre_blocks >> j) & 1u) && ((pre_slots >> (4 * e)) & 15u) == 15u) all_staged = false;
+        if (MODE != kFwd && ((post_blocks >> j) & 1u) && ((post_slots >> (4 * e)) & 15u) == 15u) all_staged = false;
+    }
+    if (pre_edge && post_edge && all_staged) trace_loop(FTrue{});
+    else trace_loop(FFalse{});
 }
 
 }  // namespace thz

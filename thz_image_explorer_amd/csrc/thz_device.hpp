@@ -101,6 +101,13 @@ __device__ __forceinline__ int launder_v(int x)
     return x;
 }
 
+// a float the optimiser must have in a register here (forces pending loads of it to complete)
+__device__ __forceinline__ float launder_f(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // value known to be the same in every lane of the wave -> keep it in an SGPR
 #define THZ_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 
