@@ -15,11 +15,13 @@ chain = synth.default_chain(tm)
 npix = nx * ny
 d_t = eng.to_device(tm); d_raw = eng.empty((npix, nt)); eng.synth_cube(d_raw, npix, 0, d_t)
 d_pre = eng.to_device(chain["w_pre"]); d_fd = eng.to_device(chain["fd_mask"]); d_post = eng.to_device(chain["w_post"])
-d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
+nfp = nf + 64  # room for the pitched-row probe variants
+d_fft = eng.empty((npix, nfp, 2)); d_amp = eng.empty((npix, nfp)); d_ph = eng.empty((npix, nfp)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
 eng.enable_timing(1)
-def probe_cfg(blocks, threads, nt_store):
+def probe_cfg(blocks, threads, nt_store, pitch=0):
     def run():
         os.environ["THZ_PROBE_BLOCKS"], os.environ["THZ_PROBE_THREADS"], os.environ["THZ_PROBE_NT"] = str(blocks), str(threads), str(nt_store)
+        os.environ["THZ_PROBE_PITCH"] = str(pitch)
         eng.traffic_probe(npix, nt, d_raw, d_fft, d_amp, d_ph, d_out)
     return run
 
@@ -29,6 +31,9 @@ cases = {"pipeline": (lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_f
 if os.environ.get("THZ_AB_SWEEP"):
     for b_, t_, n_ in [(256, 512, 0), (256, 512, 1), (512, 512, 0), (1024, 512, 0), (2048, 256, 0), (4096, 256, 0), (8192, 64, 0), (512, 256, 0)]:
         cases[f"p{b_}x{t_}{'nt' if n_ else ''}"] = (probe_cfg(b_, t_, n_), pkg.binding.STAGE_PROBE)
+    for pitch in (nf + 3, nf + 31, nf + 63):   # 16-byte, 128-byte and 256-byte aligned rows
+        cases[f"pitch{pitch}"] = (probe_cfg(256, 512, 0, pitch), pkg.binding.STAGE_PROBE)
+    cases["p256x512 "] = (probe_cfg(256, 512, 0), pkg.binding.STAGE_PROBE)
     del cases["probe"]
 acc = {k: [] for k in cases}
 for r in range(rounds):

@@ -19,6 +19,7 @@
 //   load-time bias subtraction          src/io.rs:578-596
 #include "kernels.hpp"
 #include "fft_f.hpp"
+#include "fft_fb.hpp"
 
 #include <cstdlib>
 
@@ -1094,10 +1095,39 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
     THZ_LAUNCH(k_fft_inv, grid, block, lds, st, P, npix, fft_in, win, out, img);
 }
 
+template <class PL>
+static void launch_fb(hipStream_t st, const PlanDev &P, const FBArgs &A)
+{
+    const unsigned kBlock = 512, kWpb = kBlock / kWave;
+    const size_t lds = FBLayout<PL>::lds_bytes((int)kWpb, P.nt, P.nf);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    size_t g = (A.npix + kWpb - 1) / kWpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (g < 1) g = 1;
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
+    allow_dynamic_lds(k_fb<PL>, lds);
+    THZ_LAUNCH((k_fb<PL>), (unsigned)g, kBlock, lds, st, A, T);
+}
+
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img)
 {
+    if (P.family == kFamilyFB && fft_out && amp_out && ph_out && data_out) {
+        FBArgs A{};
+        A.npix = npix; A.nt = P.nt; A.nf = P.nf; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
+        A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        A.data_out = data_out; A.img = img;
+        A.w = reinterpret_cast<const cx *>(P.chirp_conj); A.bf = reinterpret_cast<const cx *>(P.bfft);
+        switch (1 << P.log2n) {
+        case 2048: launch_fb<FPlan4096>(st, P, A); break;
+        case 1024: launch_fb<FPlan2048>(st, P, A); break;
+        default: launch_fb<FPlan1024>(st, P, A); break;
+        }
+        return;
+    }
     if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
         FArgs A{};
         A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;

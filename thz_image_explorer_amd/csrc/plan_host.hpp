@@ -76,6 +76,7 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
         P.mode = kModeBluestein;
         N = 1;
         while (N < 2 * nt - 1) N <<= 1;
+        if (allow_f && N < 512) N = 512;  // smallest convolution length of the FB kernels (fft_fb.hpp)
         P.variant = "g-bluestein-stockham-lds-r4r2";
     }
     int lg = 0;
@@ -127,10 +128,13 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
     P.family = kFamilyG;
     P.f_t1.clear(); P.f_t2.clear(); P.f_w2n.clear();
     int r1, r2, r3;
-    if (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3)) {
-        P.family = kFamilyF;
-        P.variant = "f-regs-3pass-lds-xor";
-        const size_t Nc = nt / 2, m1 = (size_t)r2 * r3;
+    // F core of complex length Nc: the half-length transform of a power-of-two trace (family F), or
+    // the length-M convolution transform of a chirp-z length with M <= 2048 (family FB)
+    const bool fb = allow_f && P.mode == kModeBluestein && f_factors(2 * N, r1, r2, r3);
+    if (fb || (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3))) {
+        P.family = fb ? kFamilyFB : kFamilyF;
+        P.variant = fb ? "fb-bluestein-regs-3pass-lds-xor" : "f-regs-3pass-lds-xor";
+        const size_t Nc = fb ? N : nt / 2, m1 = (size_t)r2 * r3;
         P.f_t1.resize((size_t)r1 * m1);
         for (int k1 = 0; k1 < r1; ++k1)
             for (size_t m = 0; m < m1; ++m) {
@@ -169,7 +173,9 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     D.tw_split = tw_split;
     D.chirp_conj = chirp_conj;
     D.bfft = bfft;
-    D.family = (f_t1 && f_t2 && f_w2n && ones) ? H.family : kFamilyG;
+    D.family = kFamilyG;
+    if (H.family == kFamilyF && f_t1 && f_t2 && f_w2n && ones) D.family = kFamilyF;
+    if (H.family == kFamilyFB && f_t1 && f_t2 && ones && chirp_conj && bfft) D.family = kFamilyFB;
     D.ones = ones;
     D.f_t1 = f_t1;
     D.f_t2 = f_t2;

@@ -653,14 +653,13 @@ __device__ __forceinline__ void probe_store(f4u *p, f4u v)
 }
 
 template <bool NT>
-__global__ __launch_bounds__(512) void k_traffic_probe(size_t npix, int nt, const float *__restrict__ in,
+__global__ __launch_bounds__(512) void k_traffic_probe(size_t npix, int nt, int nf, const float *__restrict__ in,
                                                        float *__restrict__ fft, float *__restrict__ amp,
                                                        float *__restrict__ ph, float *__restrict__ out)
 {
     const int lane = lane_id();
     const int wpb = (int)(blockDim.x >> 6);
     const size_t stride = (size_t)gridDim.x * wpb;
-    const int nf = nt / 2 + 1;
     for (size_t trace = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); trace < npix; trace += stride) {
         const float *src = in + trace * (size_t)nt;
         float *f = fft + trace * (size_t)(2 * nf), *a = amp + trace * (size_t)nf, *p = ph + trace * (size_t)nf;
@@ -686,12 +685,14 @@ void launch_traffic_probe(hipStream_t st, size_t npix, int nt, const float *in, 
 {
     // developer knobs for the access-shape experiments of DESIGN.md §6
     const char *eb = getenv("THZ_PROBE_BLOCKS"), *et = getenv("THZ_PROBE_THREADS"), *en = getenv("THZ_PROBE_NT");
+    const char *ep = getenv("THZ_PROBE_PITCH");  // row pitch of the spectrum arrays in floats (>= nt/2+1)
     const int blocks = eb ? atoi(eb) : 256, threads = et ? atoi(et) : 512;
+    const int nf = ep && atoi(ep) >= nt / 2 + 1 ? atoi(ep) : nt / 2 + 1;
     if (blocks < 1 || blocks > 65536 || threads < 64 || threads > 512 || threads % 64) return;
     if (en && atoi(en))
-        THZ_LAUNCH(k_traffic_probe<true>, blocks, threads, 0, st, npix, nt, in, fft, amp, ph, out);
+        THZ_LAUNCH(k_traffic_probe<true>, blocks, threads, 0, st, npix, nt, nf, in, fft, amp, ph, out);
     else
-        THZ_LAUNCH(k_traffic_probe<false>, blocks, threads, 0, st, npix, nt, in, fft, amp, ph, out);
+        THZ_LAUNCH(k_traffic_probe<false>, blocks, threads, 0, st, npix, nt, nf, in, fft, amp, ph, out);
 }
 
 }  // namespace thz
