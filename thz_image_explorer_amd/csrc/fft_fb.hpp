@@ -43,6 +43,14 @@ struct FBLayout {
     }
 };
 
+// base[idx] with the byte offset formed in 32 bits: the load then takes the uniform base in SGPRs
+// and one offset VGPR (global_load ... v_off, s[base]) instead of a 64-bit address pair per element
+template <class T>
+__device__ __forceinline__ T ld_off(const T *base, unsigned idx)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx * (unsigned)sizeof(T)));
+}
+
 // r[c][j1] <- swap(A[n] * bf[n]), n = M1 j1 + C1 lane + c, A in buf in the nat() layout
 template <class P>
 __device__ __forceinline__ void fb_multiply_swapped(const cx *buf, const cx *__restrict__ bf, int lane,
@@ -54,13 +62,13 @@ __device__ __forceinline__ void fb_multiply_swapped(const cx *buf, const cx *__r
     for (int v = 0; v < 2; ++v)
 #pragma unroll
         for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
-    const cx *bl = bf + launder_v(C1 * lane);
+    const unsigned bl = (unsigned)launder_v(C1 * lane);
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
             const cx a = buf[fbase[j1 & 1][c] + M1 * j1];
-            const cx t = cx_mul(a, bl[M1 * j1 + c]);
+            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(M1 * j1 + c)));
             r[c][j1] = cx{t.y, t.x};
         }
         if ((j1 & 3) == 3) THZ_SCHED_FENCE();
@@ -109,23 +117,41 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         const float *pre_l = launder_uniform((const float *)pre_s);
         const float *post_l = launder_uniform((const float *)post_s);
         const float *mask_l = launder_uniform((const float *)mask_s);
+        // lane parts of the indices, opaque per trace: otherwise every clamped index, compare mask and
+        // address of the unrolled loops below is hoisted out of the trace loop and lives (spills) forever
+        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
 
-        // ---- a[n] = x[n] pre[n] w[n] (zero from nt on), in the core's input layout
+        // ---- a[n] = x[n] pre[n] w[n] (zero from nt on), in the core's input layout.  Branch-free:
+        // indices are clamped and the value selected, so that the loads of a trace are issued
+        // together instead of one exec-masked round trip each
         {
             const float *x = A.in + p * (size_t)L;
+            constexpr int H = R1 / 2;  // two batches: 3 registers per element in flight, not for all 32
 #pragma unroll
-            for (int j1 = 0; j1 < R1; ++j1) {
+            for (int h = 0; h < 2; ++h) {
+                float xv[C1][H];
+                cx wv[C1][H];
 #pragma unroll
-                for (int c = 0; c < C1; ++c) {
-                    const int n = M1 * j1 + C1 * lane + c;
-                    cx v = cx{0.0f, 0.0f};
-                    if (n < L) {
-                        const float xv = x[n] * pre_l[n];
-                        const cx wv = wl[n];
-                        v = cx{xv * wv.x, xv * wv.y};
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lb + c;
+                        const unsigned nn = (unsigned)(n < L ? n : L - 1);  // unsigned: SGPR base + 32-bit offset
+                        xv[c][j] = ld_off(x, nn);
+                        wv[c][j] = ld_off(wl, nn);
                     }
-                    r[c][j1] = v;
                 }
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lb + c;
+                        const int nn = n < L ? n : L - 1;
+                        const float t = n < L ? xv[c][j] * pre_l[nn] : 0.0f;
+                        r[c][H * h + j] = cx{t * wv[c][j].x, t * wv[c][j].y};
+                    }
+                }
+                THZ_SCHED_FENCE();
             }
         }
         f_core_pass1<P>(r, buf, t1, ad, lane);
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         {
             float carry = 0.0f, prev_tail = 0.0f, first = 0.0f;
             for (int g = 0; g < n_groups; ++g) {
-                const int k0 = 256 * g + 4 * lane;
+                const int k0 = 256 * g + lb4;
                 cx X[4];
                 float m[4];
                 bool ok[4];
@@ -147,14 +173,11 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                 for (int c = 0; c < 4; ++c) {
                     const int k = k0 + c;
                     ok[c] = k < nf;
-                    X[c] = cx{0.0f, 0.0f};
-                    m[c] = 0.0f;
-                    if (ok[c]) {
-                        const cx s = buf[256 * g + fb4[c]];
-                        X[c] = cx_mul(cx{s.y, s.x}, wl[k]);
-                        m[c] = mask_l[k];
-                        if (k == 0 || ((L & 1) == 0 && k == nf - 1)) X[c].y = 0.0f;  // real input
-                    }
+                    const int kc = ok[c] ? k : nf - 1;
+                    const cx s = buf[nat(kc)];
+                    X[c] = cx_mul(cx{s.y, s.x}, ld_off(wl, (unsigned)kc));
+                    m[c] = mask_l[kc];
+                    if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) X[c].y = 0.0f;  // real input
                 }
                 float a[4], ph[4];
 #pragma unroll
@@ -209,20 +232,31 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         // ---- inverse: a'[n] = conj(Yfull[n]) w[n];  Yfull[n] = Y[n] (n <= nt/2), conj(Y[nt-n]) above
         {
             const int half = L / 2;
+            constexpr int H = R1 / 2;
 #pragma unroll
-            for (int j1 = 0; j1 < R1; ++j1) {
+            for (int h = 0; h < 2; ++h) {
+                cx wv[C1][H];
 #pragma unroll
-                for (int c = 0; c < C1; ++c) {
-                    const int n = M1 * j1 + C1 * lane + c;
-                    cx v = cx{0.0f, 0.0f};
-                    if (n < L) {
-                        const int kk = n <= half ? n : L - n;
-                        cx y = buf[nat(kk)];
-                        if (n <= half) y.y = -y.y;  // conj(Y[n]); above: conj(conj(Y[nt-n])) = Y[nt-n]
-                        v = cx_mul(y, wl[n]);
+                for (int j = 0; j < H; ++j)
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lb + c;
+                        wv[c][j] = ld_off(wl, (unsigned)(n < L ? n : L - 1));
                     }
-                    r[c][j1] = v;
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lb + c;
+                        const int nn = n < L ? n : L - 1;
+                        const int kk = nn <= half ? nn : L - nn;
+                        cx y = buf[nat(kk)];
+                        y.y = nn <= half ? -y.y : y.y;  // conj(Y[n]); above: conj(conj(Y[nt-n])) = Y[nt-n]
+                        const cx v = cx_mul(y, wv[c][j]);
+                        r[c][H * h + j] = n < L ? v : cx{0.0f, 0.0f};
+                    }
                 }
+                THZ_SCHED_FENCE();
             }
         }
         wave_sync();
@@ -237,9 +271,10 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         {
             float *o = A.data_out + p * (size_t)L;
             float acc = 0.0f;
-            for (int n = lane; n < L; n += kWave) {
+#pragma unroll 4
+            for (int n = lb1; n < L; n += kWave) {
                 const cx s = buf[nat(n)];
-                const cx wv = wl[n];
+                const cx wv = ld_off(wl, (unsigned)n);
                 // Re( swap(s) * w ) = s.y w.x - s.x w.y
                 float v = (s.y * wv.x - s.x * wv.y) / fnt;
                 v *= post_l[n];
