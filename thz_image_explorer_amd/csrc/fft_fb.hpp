@@ -6,9 +6,10 @@
 //
 // i.e. one circular convolution of length M >= 2 nt - 1 (M = 512 / 1024 / 2048 = the complex
 // sizes of the three F plans) = two M-point FFTs through f_core_pass1/f_core_pass23; the inverse
-// real transform is the same machinery applied to conj(Y) (y = Re DFT(conj Y) / nt).  Four
-// M-point FFTs per trace: the kernel is VALU-bound, not HBM-bound (algorithmic bytes are
-// 16 nt + 20 per trace as for the power-of-two chain).
+// real transform is the same machinery applied to conj(Y) (y = Re DFT(conj Y) / nt).  Two real
+// traces share each convolution (packed as x1 + i x2), so a trace costs two M-point FFTs like a
+// power-of-two trace of 2 M samples — for a quarter of its bytes: the kernel is VALU-bound, not
+// HBM-bound (algorithmic bytes are 16 nt + 20 per trace as for the power-of-two chain).
 //
 // Same parity rules as the G kernels it replaces for these lengths (kernels.hip k_fft_fwd /
 // k_fft_inv): DC (and Nyquist for even nt) imaginary parts are zero, phases are taken before the
@@ -75,6 +76,63 @@ __device__ __forceinline__ void fb_multiply_swapped(const cx *buf, const cx *__r
     }
 }
 
+// One spectrum's share of the epilogue for the four bins of a lane: |X| m, arg X, numpy_unwrap
+// (two-level scan over ascending bins, state carried across the groups), stores, and the masked
+// value for the inverse.
+struct FBUnwrap {
+    float carry = 0.0f, prev_tail = 0.0f, first = 0.0f;
+};
+
+template <bool STORE>
+__device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m)[4], const bool (&ok)[4], int g,
+                                               int lane, FBUnwrap &u, cx *f, float *ao, float *po)
+{
+    const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
+    float a[4], ph[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+        ph[c] = fast_atan2f(X[c].y, X[c].x);
+    }
+    if (g == 0) u.first = wave_bcast<0>(ph[0]);
+    float prev = wave_shr1(ph[3]);
+    if (lane == 0) prev = u.prev_tail;
+    float s_[4], run = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float d = ph[c] - (c == 0 ? prev : ph[c - 1]);
+        d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);  // numpy_unwrap's if / else if
+        if ((g == 0 && c == 0 && lane == 0) || !ok[c]) d = 0.0f;
+        run += d;
+        s_[c] = run;
+    }
+    const float incl = wave_scan_add(run);
+    const float excl = wave_shr1(incl);
+    const float base = u.carry + excl;
+    u.carry += wave_bcast<kWave - 1>(incl);
+    u.prev_tail = wave_bcast<kWave - 1>(ph[3]);
+    if (!STORE) return;
+    if (ok[3]) {
+        store_f4(reinterpret_cast<float *>(f), X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
+        store_f4(reinterpret_cast<float *>(f) + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+        store_f4(ao, a[0], a[1], a[2], a[3]);
+        store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
+                 u.first + (base + s_[3]));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ok[c]) {
+                f[c] = cx{X[c].x * m[c], X[c].y * m[c]};
+                ao[c] = a[c];
+                po[c] = u.first + (base + s_[c]);
+            }
+    }
+}
+
+// Two real traces per convolution: z = (x1 + i x2) w goes through the chirp-z machinery once,
+// F[k] = X1[k] + i X2[k] is split with F[nt-k] (w[nt-k] = (-1)^nt w[k], so no second table read),
+// and the inverse transforms conj(Y1full + i Y2full): y1 = Re U / nt, y2 = -Im U / nt.  Four
+// M-point FFTs per pair instead of per trace.
 template <class P>
 __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
 {
@@ -101,15 +159,17 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
 
     FAddr<P> ad;
     ad.init(lane);
-    const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
     const float fnt = (float)L;
     const int n_groups = (nf + 255) / 256;  // epilogue groups of 256 bins: bin = 256 g + 4 lane + c
-    int fb4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) fb4[c] = nat(4 * lane + c);  // nat(256 g + 4 lane + c) = 256 g + fb4[c]
+    const int half = L / 2;
+    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
+    const int y2_base = (L + 4) & ~3;          // Y2[k] lives at nat(y2_base + k): behind everything F uses
+    const size_t n_pairs = (A.npix + 1) / 2;
     const size_t stride = (size_t)gridDim.x * wpb;
 
-    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < A.npix; p += stride) {
+    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
+        const size_t p = 2 * q;
+        const bool has2 = p + 1 < A.npix;  // wave-uniform
         cx r[C1][R1];
         ad.refresh();
         const cx *wl = launder_uniform(A.w);
@@ -121,23 +181,25 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         // address of the unrolled loops below is hoisted out of the trace loop and lives (spills) forever
         const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
 
-        // ---- a[n] = x[n] pre[n] w[n] (zero from nt on), in the core's input layout.  Branch-free:
-        // indices are clamped and the value selected, so that the loads of a trace are issued
-        // together instead of one exec-masked round trip each
+        // ---- a[n] = (x1[n] + i x2[n]) pre[n] w[n] (zero from nt on), in the core's input layout.
+        // Branch-free: indices are clamped and the value selected, so that the loads of a trace are
+        // issued together instead of one exec-masked round trip each
         {
-            const float *x = A.in + p * (size_t)L;
-            constexpr int H = R1 / 2;  // two batches: 3 registers per element in flight, not for all 32
+            const float *x1 = A.in + p * (size_t)L;
+            const float *x2 = has2 ? x1 + L : x1;
+            constexpr int H = R1 / 2;  // two batches: 4 registers per element in flight, not for all 32
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float xv[C1][H];
+                float xa[C1][H], xb[C1][H];
                 cx wv[C1][H];
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
 #pragma unroll
                     for (int c = 0; c < C1; ++c) {
                         const int n = M1 * (H * h + j) + lb + c;
-                        const unsigned nn = (unsigned)(n < L ? n : L - 1);  // unsigned: SGPR base + 32-bit offset
-                        xv[c][j] = ld_off(x, nn);
+                        const unsigned nn = (unsigned)(n < L ? n : L - 1);
+                        xa[c][j] = ld_off(x1, nn);
+                        xb[c][j] = ld_off(x2, nn);
                         wv[c][j] = ld_off(wl, nn);
                     }
                 }
@@ -147,8 +209,9 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                     for (int c = 0; c < C1; ++c) {
                         const int n = M1 * (H * h + j) + lb + c;
                         const int nn = n < L ? n : L - 1;
-                        const float t = n < L ? xv[c][j] * pre_l[nn] : 0.0f;
-                        r[c][H * h + j] = cx{t * wv[c][j].x, t * wv[c][j].y};
+                        const float pw = n < L ? pre_l[nn] : 0.0f;
+                        const cx z = cx{xa[c][j] * pw, has2 ? xb[c][j] * pw : 0.0f};
+                        r[c][H * h + j] = cx_mul(z, wv[c][j]);
                     }
                 }
                 THZ_SCHED_FENCE();
@@ -161,12 +224,12 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         f_core_pass1<P>(r, buf, t1, ad, lane);
         f_core_pass23<P>(buf, t2, ad, lane);  // buf = swap(c), nat layout
 
-        // ---- spectrum epilogue: X[k] = w[k] * c[k], k < nf; bins 256 g + 4 lane + c
+        // ---- spectrum epilogue: F[k] = w[k] c[k]; X1 = (F[k] + conj F[nt-k]) / 2, X2 = (F[k] - conj F[nt-k]) / 2i
         {
-            float carry = 0.0f, prev_tail = 0.0f, first = 0.0f;
+            FBUnwrap u1, u2;
             for (int g = 0; g < n_groups; ++g) {
                 const int k0 = 256 * g + lb4;
-                cx X[4];
+                cx X1[4], X2[4];
                 float m[4];
                 bool ok[4];
 #pragma unroll
@@ -174,64 +237,41 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                     const int k = k0 + c;
                     ok[c] = k < nf;
                     const int kc = ok[c] ? k : nf - 1;
-                    const cx s = buf[nat(kc)];
-                    X[c] = cx_mul(cx{s.y, s.x}, ld_off(wl, (unsigned)kc));
+                    const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
+                    const cx wk = ld_off(wl, (unsigned)kc);
+                    const cx s = buf[nat(kc)], sm = buf[nat(km)];
+                    const cx Fk = cx_mul(cx{s.y, s.x}, wk);
+                    const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
+                    const cx Fm = cx_mul(cx{sm.y, sm.x}, wm);
+                    // conj(Fm) = (Fm.x, -Fm.y)
+                    X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
+                    // (Fk - conj Fm) / 2i = (-i/2) (dx + i dy) = (dy/2, -dx/2)
+                    X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
                     m[c] = mask_l[kc];
-                    if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) X[c].y = 0.0f;  // real input
+                    if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {  // real input: DC / Nyquist bins are real
+                        X1[c].y = 0.0f;
+                        X2[c].y = 0.0f;
+                    }
                 }
-                float a[4], ph[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
-                    ph[c] = fast_atan2f(X[c].y, X[c].x);
-                }
-                // numpy_unwrap over ascending bins (same two-level scan as the F epilogue)
-                if (g == 0) first = wave_bcast<0>(ph[0]);
-                float prev = wave_shr1(ph[3]);
-                if (lane == 0) prev = prev_tail;
-                float s_[4], run = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float d = ph[c] - (c == 0 ? prev : ph[c - 1]);
-                    d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);
-                    if ((g == 0 && c == 0 && lane == 0) || !ok[c]) d = 0.0f;
-                    run += d;
-                    s_[c] = run;
-                }
-                const float incl = wave_scan_add(run);
-                const float excl = wave_shr1(incl);
-                const float base = carry + excl;
-                carry += wave_bcast<kWave - 1>(incl);
-                prev_tail = wave_bcast<kWave - 1>(ph[3]);
-                cx *f = A.fft_out + p * (size_t)nf + k0;
-                float *ao = A.amp_out + p * (size_t)nf + k0, *po = A.ph_out + p * (size_t)nf + k0;
-                if (ok[3]) {
-                    store_f4(reinterpret_cast<float *>(f), X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
-                    store_f4(reinterpret_cast<float *>(f) + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3],
-                             X[3].y * m[3]);
-                    store_f4(ao, a[0], a[1], a[2], a[3]);
-                    store_f4(po, first + (base + s_[0]), first + (base + s_[1]), first + (base + s_[2]),
-                             first + (base + s_[3]));
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (ok[c]) {
-                            f[c] = cx{X[c].x * m[c], X[c].y * m[c]};
-                            ao[c] = a[c];
-                            po[c] = first + (base + s_[c]);
-                        }
-                }
-                // the masked spectrum stays in the wave's slice (own slots) for the inverse
+                const size_t o1 = p * (size_t)nf + k0;
+                fb_finish_bins<true>(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                if (has2)
+                    fb_finish_bins<true>(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
+                                         A.ph_out + o1 + nf);
+                // masked spectra for the inverse: Y1[k] over c[k] — only its owner reads slot k or
+                // nt-k — and Y2[k] behind everything F uses
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (ok[c]) buf[256 * g + fb4[c]] = cx{X[c].x * m[c], X[c].y * m[c]};
+                    if (ok[c]) {
+                        buf[nat(k0 + c)] = cx{X1[c].x * m[c], X1[c].y * m[c]};
+                        buf[nat(y2_base + k0 + c)] = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                    }
             }
         }
         wave_sync();
 
-        // ---- inverse: a'[n] = conj(Yfull[n]) w[n];  Yfull[n] = Y[n] (n <= nt/2), conj(Y[nt-n]) above
+        // ---- inverse: a'[n] = conj(Y1full[n] + i Y2full[n]) w[n];  Yfull[n] = Y[n] (n <= nt/2), conj(Y[nt-n]) above
         {
-            const int half = L / 2;
             constexpr int H = R1 / 2;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -249,10 +289,14 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                     for (int c = 0; c < C1; ++c) {
                         const int n = M1 * (H * h + j) + lb + c;
                         const int nn = n < L ? n : L - 1;
-                        const int kk = nn <= half ? nn : L - nn;
-                        cx y = buf[nat(kk)];
-                        y.y = nn <= half ? -y.y : y.y;  // conj(Y[n]); above: conj(conj(Y[nt-n])) = Y[nt-n]
-                        const cx v = cx_mul(y, wv[c][j]);
+                        const bool low = nn <= half;
+                        const int kk = low ? nn : L - nn;
+                        cx y1 = buf[nat(kk)], y2 = buf[nat(y2_base + kk)];
+                        // Yfull = low ? Y : conj(Y);  G = Y1full + i Y2full;  conj(G) = conj(Y1full) - i conj(Y2full)
+                        // low : conj(Y1) - i conj(Y2) = (y1.x - y2.y, -y1.y - y2.x)
+                        // high: Y1 - i Y2             = (y1.x + y2.y,  y1.y - y2.x)
+                        const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
+                        const cx v = cx_mul(gc, wv[c][j]);
                         r[c][H * h + j] = n < L ? v : cx{0.0f, 0.0f};
                     }
                 }
@@ -267,23 +311,32 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         f_core_pass1<P>(r, buf, t1, ad, lane);
         f_core_pass23<P>(buf, t2, ad, lane);
 
-        // ---- y[n] = Re(w[n] * c'[n]) / nt * post[n]; image = sum y^2
+        // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
         {
-            float *o = A.data_out + p * (size_t)L;
-            float acc = 0.0f;
+            float *o1 = A.data_out + p * (size_t)L;
+            float acc1 = 0.0f, acc2 = 0.0f;
 #pragma unroll 4
             for (int n = lb1; n < L; n += kWave) {
                 const cx s = buf[nat(n)];
                 const cx wv = ld_off(wl, (unsigned)n);
-                // Re( swap(s) * w ) = s.y w.x - s.x w.y
-                float v = (s.y * wv.x - s.x * wv.y) / fnt;
-                v *= post_l[n];
-                o[n] = v;
-                acc += v * v;
+                const cx U = cx_mul(cx{s.y, s.x}, wv);
+                const float pw = post_l[n];
+                const float v1 = (U.x / fnt) * pw;
+                o1[n] = v1;
+                acc1 += v1 * v1;
+                if (has2) {
+                    const float v2 = (-U.y / fnt) * pw;
+                    o1[L + n] = v2;
+                    acc2 += v2 * v2;
+                }
             }
             if (A.img) {
-                acc = wave_reduce_add(acc);
-                if (lane == 0) A.img[p] = acc;
+                acc1 = wave_reduce_add(acc1);
+                acc2 = wave_reduce_add(acc2);
+                if (lane == 0) {
+                    A.img[p] = acc1;
+                    if (has2) A.img[p + 1] = acc2;
+                }
             }
         }
         wave_sync();

@@ -1103,7 +1103,8 @@ static void launch_fb(hipStream_t st, const PlanDev &P, const FBArgs &A)
     size_t per_cu = kLdsBytesPerCU / lds;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
-    size_t g = (A.npix + kWpb - 1) / kWpb;
+    const size_t n_pairs = (A.npix + 1) / 2;  // one wave per pair of traces
+    size_t g = (n_pairs + kWpb - 1) / kWpb;
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
     if (g < 1) g = 1;
     FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
