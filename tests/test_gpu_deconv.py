@@ -127,3 +127,27 @@ def test_band_parallel_partials_add_up(engine):
     assert np.abs(s - outs["all"]).max() / np.abs(outs["all"]).max() < 1e-5
     with pytest.raises(pkg.ThzError):
         engine.deconvolve(psf, pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5, 4, 2), nx, ny, 0.5, 0.5, 0, 0)
+
+
+def test_deconvolution_abort_and_progress(engine):
+    """abort flag (filters/filter.rs: Arc<AtomicBool>) polled between iteration batches: an aborted run
+    returns THZ_ERR_ABORTED with the input copied through; a completed run reports progress 1.0"""
+    import ctypes
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nx, ny, nt = 32, 32, 128
+    time, cube = _bar_target_cube(nx, ny, nt)
+    engine.set_time_axis(time)
+    cfg = pkg.DeconvCfg(80, 5, 0.3, 3.0, 0.5)     # > one graph batch of iterations
+    d_in = engine.to_device(cube); d_out = engine.empty((nx * ny, nt)).zero(); d_img = engine.empty((nx * ny,))
+    abort, progress = ctypes.c_int(1), ctypes.c_float(-1.0)
+    with pytest.raises(pkg.ThzError) as e:
+        engine.deconvolve(psf, cfg, nx, ny, 0.5, 0.5, d_in, d_out, d_img, abort=abort, progress=progress)
+    assert e.value.code == -5
+    assert np.array_equal(d_out.download((nx, ny, nt), np.float32), cube)
+    abort.value = 0
+    assert engine.deconvolve(psf, cfg, nx, ny, 0.5, 0.5, d_in, d_out, d_img, abort=abort, progress=progress) == 0
+    assert progress.value == 1.0
+    assert np.abs(d_out.download((nx, ny, nt), np.float32) - cube).max() > 0
+    for b in (d_in, d_out, d_img):
+        b.free()

@@ -584,10 +584,13 @@ class Engine:
         self._check(self.lib.thz_tilt_apply(self.ctx, npix, _dp(d_in), nt_in, _dp(d_taper), _dp(d_insert),
                                             nt_out, _dp(d_out)))
 
-    def deconvolve(self, psf: Psf, cfg: DeconvCfg, nx, ny, dx, dy, d_in, d_out, d_img=None, d_gains=None):
-        """-> status (0 applied, 1 skipped by one of the reference's guards)"""
+    def deconvolve(self, psf: Psf, cfg: DeconvCfg, nx, ny, dx, dy, d_in, d_out, d_img=None, d_gains=None,
+                   abort=None, progress=None):
+        """-> status (0 applied, 1 skipped by one of the reference's guards).  abort: ctypes.c_int polled
+        between iteration batches (the reference's AtomicBool); progress: ctypes.c_float written 0..1"""
         rc = self.lib.thz_deconvolve(self.ctx, C.byref(psf), C.byref(cfg), nx, ny, dx, dy, _dp(d_in), _dp(d_out),
-                                     _dp(d_img), _dp(d_gains), None, None)
+                                     _dp(d_img), _dp(d_gains), C.byref(abort) if abort is not None else None,
+                                     C.byref(progress) if progress is not None else None)
         if rc < 0:
             self._check(rc)
         return rc

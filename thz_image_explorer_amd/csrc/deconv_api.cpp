@@ -3,6 +3,7 @@
 #include "ctx.hpp"
 #include "deconv_host.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -176,7 +177,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     std::vector<RlBand> bands((size_t)nbs);
     std::vector<float> psf_pack;
     size_t ws_floats = 0;
-    unsigned blk = 0;
+    unsigned blk = 0, tblk = 0;
+    size_t tile_lds = 0;
     int max_iter = 0;
     std::vector<BandPsf> psfs((size_t)nbs);
     for (int b = 0; b < nbs; ++b) {
@@ -194,6 +196,10 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         if (B.n_iter > max_iter) max_iter = B.n_iter;
         B.blk0 = blk;
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
+        B.tblk0 = tblk;
+        B.tiles_w = (B.W + 15) / 16;
+        tblk += (unsigned)(B.tiles_w * ((B.H + 15) / 16));
+        tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;
         B.off_u = (unsigned)ws_floats; ws_floats += img;
@@ -222,19 +228,61 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     launch_dc_energy(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_energy);
     launch_rl_init(ctx->stream, d_bands, nbs, blk, npix, d_energy, d_ws);
     if (int rc = check_launch(ctx)) return rc;
-    for (int it = 0; it < max_iter; ++it) {
+    // Richardson-Lucy iterations: two dependent launches each, ~10 us of work per launch — the loop
+    // is launch-bound.  A batch of kRlBatch iterations is captured once into a hipGraph and replayed;
+    // the batch's first iteration number lives in device memory (d_it) so that one graph serves all
+    // batches.  Bands that have finished return at once (iteration >= n_iter), which also covers
+    // the tail of the last batch.  The abort flag is polled between batches.
+    constexpr int kRlBatch = 32;
+    const bool tiled = tile_lds <= (size_t)150 * 1024;  // image tile + halo + PSF fit in LDS
+    if (tiled) prepare_rl_step_tiled(tile_lds);
+    auto enqueue = [&](const int *it_base, int it) {
+        if (tiled) {
+            launch_rl_step_tiled(ctx->stream, d_bands, nbs, tblk, tile_lds, it_base, it, 0, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_bands, nbs, tblk, tile_lds, it_base, it, 1, d_ws);
+        } else {
+            launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 0, d_ws);
+            launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 1, d_ws);
+        }
+    };
+    int *d_it = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_it, sizeof(int)));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (max_iter > kRlBatch && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        for (int o = 0; o < kRlBatch; ++o) enqueue(d_it, o);
+        if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph
+            || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            graph = nullptr;
+            exec = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    struct GraphGuard {
+        hipGraph_t g;
+        hipGraphExec_t e;
+        ~GraphGuard()
+        {
+            if (e) (void)hipGraphExecDestroy(e);
+            if (g) (void)hipGraphDestroy(g);
+        }
+    } graph_guard{graph, exec};
+    for (int base = 0; base < max_iter; base += kRlBatch) {
         if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (int rc = copy_through(ctx, d_in, d_out, d_img, npix, nt)) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
         }
-        launch_rl_step(ctx->stream, d_bands, nbs, blk, it, 0, d_ws);
-        launch_rl_step(ctx->stream, d_bands, nbs, blk, it, 1, d_ws);
-        if ((it & 31) == 31) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
-            if (progress) *progress = (float)(it + 1) / (float)max_iter;
+        if (exec) {
+            HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_it), base, 1, ctx->stream));
+            HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
+        } else {
+            for (int it = base; it < base + kRlBatch && it < max_iter; ++it) enqueue(nullptr, it);
         }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
+        if (progress) *progress = (float)std::min(base + kRlBatch, max_iter) / (float)max_iter;
     }
     launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);
     launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);

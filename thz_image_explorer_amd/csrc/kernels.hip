@@ -857,10 +857,11 @@ __device__ __forceinline__ float rl_conv_at(const float *__restrict__ a, int H, 
 
 // step 1: t = d / (u (*) psf + eps)     step 2: u *= t (*) mirror(psf)
 __global__ __launch_bounds__(256) void k_rl_step(const RlBand *__restrict__ bands, int n_bands,
-                                                 int iteration, int step,
+                                                 const int *__restrict__ it_base, int iteration, int step,
                                                  float *__restrict__ ws)
 {
 #pragma clang fp contract(off)
+    if (it_base) iteration += *it_base;  // graph replay: the batch's first iteration lives in memory
     unsigned lb;
     const int b = rl_find_band(bands, n_bands, blockIdx.x, &lb);
     const RlBand B = bands[b];
@@ -875,6 +876,63 @@ __global__ __launch_bounds__(256) void k_rl_step(const RlBand *__restrict__ band
         const float c = rl_conv_at(ws + B.off_t, B.H, B.W, ws + B.off_mirror, B.pr, B.pc, B.mode, i, j);
         ws[B.off_u + idx] = ws[B.off_u + idx] * c;
     }
+}
+
+// The same step with the image tile and the PSF in LDS: a block owns a 16 x 16 tile of one band's
+// padded image, stages the tile plus its halo (zeros outside the image — the reference skips
+// those taps, and sum + 0*k leaves the sum as it was) and the kernel, then every thread runs the
+// reference's m-outer / n-inner loop out of LDS.  Values are those of k_rl_step bit for bit
+// (same operands, same order, no FMA); it only stops fetching every tap from L2.
+constexpr int kRlTile = 16;
+
+__global__ __launch_bounds__(256) void k_rl_step_tiled(const RlBand *__restrict__ bands, int n_bands,
+                                                       const int *__restrict__ it_base, int iteration, int step,
+                                                       float *__restrict__ ws)
+{
+#pragma clang fp contract(off)
+    THZ_DYN_LDS(smem);
+    if (it_base) iteration += *it_base;
+    int b = 0;
+    while (b + 1 < n_bands && blockIdx.x >= bands[b + 1].tblk0) ++b;
+    const RlBand B = bands[b];
+    if (iteration >= B.n_iter) return;  // block-uniform
+    const unsigned lt = blockIdx.x - B.tblk0;
+    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+    const int pr = B.pr, pc = B.pc;
+    const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;  // halo tile
+    float *a_s = reinterpret_cast<float *>(smem);
+    float *k_s = a_s + hs * wsz;
+    const float *a = ws + (step == 0 ? B.off_u : B.off_t);
+    const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
+    // first image row / column of the halo: mode 0 reads x = i + m - pr/2, mode 1 x = i + (pr-1)/2 - m
+    const int r0 = B.mode == 0 ? ti0 - pr / 2 : ti0 + (pr - 1) / 2 - (pr - 1);
+    const int c0 = B.mode == 0 ? tj0 - pc / 2 : tj0 + (pc - 1) / 2 - (pc - 1);
+    for (int e = (int)threadIdx.x; e < hs * wsz; e += (int)blockDim.x) {
+        const int x = r0 + e / wsz, y = c0 + e % wsz;
+        a_s[e] = (x >= 0 && x < B.H && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
+    }
+    for (int e = (int)threadIdx.x; e < pr * pc; e += (int)blockDim.x) k_s[e] = k[e];
+    __syncthreads();
+    const int ti = (int)threadIdx.x / kRlTile, tj = (int)threadIdx.x % kRlTile;
+    const int i = ti0 + ti, j = tj0 + tj;
+    if (i >= B.H || j >= B.W) return;
+    float sum = 0.0f;
+    if (B.mode == 0) {
+        for (int m = 0; m < pr; ++m) {
+            const float *row = a_s + (ti + m) * wsz + tj;
+            const float *kr = k_s + m * pc;
+            for (int n = 0; n < pc; ++n) sum += row[n] * kr[n];
+        }
+    } else {
+        for (int m = 0; m < pr; ++m) {
+            const float *row = a_s + (ti + pr - 1 - m) * wsz + tj + (pc - 1);
+            const float *kr = k_s + m * pc;
+            for (int n = 0; n < pc; ++n) sum += row[-n] * kr[n];
+        }
+    }
+    const int idx = i * B.W + j;
+    if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
+    else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
 }
 
 __global__ __launch_bounds__(256) void k_dc_gain(const RlBand *__restrict__ bands, int n_bands,
@@ -1283,9 +1341,22 @@ void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 }
 
 void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
-                    int iteration, int step, float *ws)
+                    const int *it_base, int iteration, int step, float *ws)
 {
-    THZ_LAUNCH(k_rl_step, total_blocks, 256, 0, st, d_bands, n_bands, iteration, step, ws);
+    THZ_LAUNCH(k_rl_step, total_blocks, 256, 0, st, d_bands, n_bands, it_base, iteration, step, ws);
+}
+
+size_t rl_tile_lds_bytes(int pr, int pc)
+{
+    return ((size_t)(kRlTile + pr - 1) * (kRlTile + pc - 1) + (size_t)pr * pc) * sizeof(float);
+}
+
+void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
+
+void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_tiles,
+                          size_t lds_bytes, const int *it_base, int iteration, int step, float *ws)
+{
+    THZ_LAUNCH(k_rl_step_tiled, total_tiles, 256, lds_bytes, st, d_bands, n_bands, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,

@@ -46,7 +46,9 @@ struct RlBand {
     int H, W;           // padded image
     int n_iter;
     int mode;           // 0: <= 256-element kernel (correlation-indexed), 1: true "same" convolution
-    unsigned blk0;      // first block of this band in the flattened grid
+    unsigned blk0;      // first block of this band in the flattened grid (256 pixels per block)
+    unsigned tblk0;     // first block of this band in the tiled grid (16 x 16 pixels per block)
+    int tiles_w;        // tiles per row of the padded image
     unsigned off_d, off_u, off_t, off_psf, off_mirror;
 };
 
@@ -57,8 +59,14 @@ void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, in
                        const c32 *spec, const c32 *H, const float *gain, float *out, float *img);
 void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
                     size_t npix, const float *energy, float *ws);
+// iteration = (it_base ? *it_base : 0) + iteration: a captured batch is replayed with a new base
 void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
-                    int iteration, int step, float *ws);
+                    const int *it_base, int iteration, int step, float *ws);
+// LDS-tiled form of the same step: total_tiles blocks, lds_bytes = rl_tile_lds_bytes of the largest band
+size_t rl_tile_lds_bytes(int pr, int pc);
+void prepare_rl_step_tiled(size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
+void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_tiles,
+                          size_t lds_bytes, const int *it_base, int iteration, int step, float *ws);
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
                     const float *energy, const float *ws, float *gain);
 
