@@ -508,3 +508,44 @@ def test_reference_spectrum_rejects_what_the_reference_panics_on(engine):
     with pytest.raises(pkg.ThzError):
         engine.reference_spectrum(scan_t, ref_t, ref_s, 3)
     engine.reference_spectrum(scan_t, ref_t, ref_s, 0)              # the adapted Blackman zips to the shorter one
+
+
+# ---- chirp-z fused chain (FB kernels) for lengths that are not a power of two -----------------
+@pytest.mark.parametrize("shape", [(3, 3, 1000), (5, 1, 513), (2, 2, 300), (7, 1, 77), (1, 1, 1023), (4, 5, 129)])
+def test_chirpz_fused_pipeline_lengths(engine, shape):
+    nx, ny, nt = shape
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()
+    engine.set_time_axis(time)
+    assert engine.kernel_variant().startswith("fb-bluestein")
+    chain = synth.default_chain(time)
+    got = synth.run_gpu_pipeline(engine, cube, chain)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"], ref["amplitudes"], scale) < TOL
+    assert rel(got["data"], ref["data"]) < TOL
+    assert rel(got["img"], ref["img"]) < TOL
+    st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(got["phases"], ref["phases"], st["amplitudes"])
+
+
+def test_chirpz_without_windows_matches_numpy(engine):
+    """no multipliers at all: X = rfft(x) and y = irfft(X) = x, against numpy fp64"""
+    nx, ny, nt = 3, 2, 1001
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) + 2, nt).reshape(nx, ny, nt)
+    engine.set_time_axis(time)
+    npix, nf = nx * ny, nt // 2 + 1
+    d_raw = engine.to_device(cube)
+    d_fft = engine.empty((npix, nf, 2)); d_amp = engine.empty((npix, nf)); d_ph = engine.empty((npix, nf))
+    d_out = engine.empty((npix, nt)); d_img = engine.empty((npix,))
+    engine.pipeline(npix, d_raw, None, None, None, d_fft, d_amp, d_ph, d_out, d_img)
+    X = np.fft.rfft(cube.astype(np.float64), axis=-1)
+    G = d_fft.download((nx, ny, nf, 2), np.float32)
+    assert np.abs((G[..., 0] + 1j * G[..., 1]) - X).max() / np.abs(X).max() < TOL
+    assert rel(d_amp.download((nx, ny, nf), np.float32), np.abs(X)) < TOL
+    assert rel(d_out.download((nx, ny, nt), np.float32), cube) < TOL
+    assert rel(d_img.download((nx, ny), np.float32), (cube.astype(np.float64) ** 2).sum(-1)) < TOL
+    for b in (d_raw, d_fft, d_amp, d_ph, d_out, d_img):
+        b.free()
