@@ -22,6 +22,8 @@ only = os.environ.get('THZ_ONLY')
 for name, fn, b in cases:
     if only and name != only:
         continue
+    if name == 'probe' and nt % 8:
+        continue
     fn(); eng.sync()
     ts = []
     for _ in range(7):

@@ -21,7 +21,8 @@ namespace thz {
 struct FBArgs {
     size_t npix;
     int nt, nf;
-    const float *in;        // (npix, nt)
+    const float *in;        // (npix, nt)            (forward / fused)
+    const cx *fft_in;       // (npix, nf)            (inverse only)
     const float *pre_win;   // nt or nullptr
     const float *mask;      // nf (never null: the plan's ones vector stands in)
     const float *post_win;  // nt or nullptr
@@ -83,7 +84,7 @@ struct FBUnwrap {
     float carry = 0.0f, prev_tail = 0.0f, first = 0.0f;
 };
 
-template <bool STORE>
+// f / ao / po may each be null (stage entry points that do not want that output)
 __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m)[4], const bool (&ok)[4], int g,
                                                int lane, FBUnwrap &u, cx *f, float *ao, float *po)
 {
@@ -111,20 +112,22 @@ __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m
     const float base = u.carry + excl;
     u.carry += wave_bcast<kWave - 1>(incl);
     u.prev_tail = wave_bcast<kWave - 1>(ph[3]);
-    if (!STORE) return;
     if (ok[3]) {
-        store_f4(reinterpret_cast<float *>(f), X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
-        store_f4(reinterpret_cast<float *>(f) + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
-        store_f4(ao, a[0], a[1], a[2], a[3]);
-        store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
-                 u.first + (base + s_[3]));
+        if (f) {
+            store_f4(reinterpret_cast<float *>(f), X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
+            store_f4(reinterpret_cast<float *>(f) + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+        }
+        if (ao) store_f4(ao, a[0], a[1], a[2], a[3]);
+        if (po)
+            store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
+                     u.first + (base + s_[3]));
     } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (ok[c]) {
-                f[c] = cx{X[c].x * m[c], X[c].y * m[c]};
-                ao[c] = a[c];
-                po[c] = u.first + (base + s_[c]);
+                if (f) f[c] = cx{X[c].x * m[c], X[c].y * m[c]};
+                if (ao) ao[c] = a[c];
+                if (po) po[c] = u.first + (base + s_[c]);
             }
     }
 }
@@ -133,7 +136,7 @@ __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m
 // F[k] = X1[k] + i X2[k] is split with F[nt-k] (w[nt-k] = (-1)^nt w[k], so no second table read),
 // and the inverse transforms conj(Y1full + i Y2full): y1 = Re U / nt, y2 = -Im U / nt.  Four
 // M-point FFTs per pair instead of per trace.
-template <class P>
+template <class P, int MODE>
 __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
 {
     THZ_DYN_LDS(lds);
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
         // address of the unrolled loops below is hoisted out of the trace loop and lives (spills) forever
         const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
 
+        if constexpr (MODE != kInv) {
         // ---- a[n] = (x1[n] + i x2[n]) pre[n] w[n] (zero from nt on), in the core's input layout.
         // Branch-free: indices are clamped and the value selected, so that the loads of a trace are
         // issued together instead of one exec-masked round trip each
@@ -254,21 +258,41 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                     }
                 }
                 const size_t o1 = p * (size_t)nf + k0;
-                fb_finish_bins<true>(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                               A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
                 if (has2)
-                    fb_finish_bins<true>(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
-                                         A.ph_out + o1 + nf);
+                    fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
+                                   A.amp_out ? A.amp_out + o1 + nf : nullptr, A.ph_out ? A.ph_out + o1 + nf : nullptr);
                 // masked spectra for the inverse: Y1[k] over c[k] — only its owner reads slot k or
                 // nt-k — and Y2[k] behind everything F uses
+                if constexpr (MODE == kPipe) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (ok[c]) {
-                        buf[nat(k0 + c)] = cx{X1[c].x * m[c], X1[c].y * m[c]};
-                        buf[nat(y2_base + k0 + c)] = cx{X2[c].x * m[c], X2[c].y * m[c]};
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (ok[c]) {
+                            buf[nat(k0 + c)] = cx{X1[c].x * m[c], X1[c].y * m[c]};
+                            buf[nat(y2_base + k0 + c)] = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                        }
+                }
             }
         }
         wave_sync();
+        } else {
+            // inverse only: the two spectra from memory into the slots the fused chain leaves them in;
+            // DC (and Nyquist for even nt) imaginary parts are ignored like realfft's C2R does
+            const cx *f1 = A.fft_in + p * (size_t)nf;
+            for (int k = lb1; k < nf; k += kWave) {
+                cx y1 = ld_off(f1, (unsigned)k);
+                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + k)) : cx{0.0f, 0.0f};
+                if (k == 0 || ((L & 1) == 0 && k == nf - 1)) {
+                    y1.y = 0.0f;
+                    y2.y = 0.0f;
+                }
+                buf[nat(k)] = y1;
+                buf[nat(y2_base + k)] = y2;
+            }
+            wave_sync();
+        }
+        if constexpr (MODE == kFwd) continue;
 
         // ---- inverse: a'[n] = conj(Y1full[n] + i Y2full[n]) w[n];  Yfull[n] = Y[n] (n <= nt/2), conj(Y[nt-n]) above
         {

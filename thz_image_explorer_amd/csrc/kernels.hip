@@ -1108,6 +1108,37 @@ static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool am
     else dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A);
 }
 
+template <class PL, int MODE>
+static void launch_fb(hipStream_t st, const PlanDev &P, const FBArgs &A)
+{
+    const unsigned kBlock = 512, kWpb = kBlock / kWave;
+    const size_t lds = FBLayout<PL>::lds_bytes((int)kWpb, P.nt, P.nf);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    const size_t n_pairs = (A.npix + 1) / 2;  // one wave per pair of traces
+    size_t g = (n_pairs + kWpb - 1) / kWpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (g < 1) g = 1;
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
+    allow_dynamic_lds(k_fb<PL, MODE>, lds);
+    THZ_LAUNCH((k_fb<PL, MODE>), (unsigned)g, kBlock, lds, st, A, T);
+}
+
+template <int MODE>
+static void dispatch_fb(hipStream_t st, const PlanDev &P, FBArgs &A)
+{
+    A.nt = P.nt;
+    A.nf = P.nf;
+    A.w = reinterpret_cast<const cx *>(P.chirp_conj);
+    A.bf = reinterpret_cast<const cx *>(P.bfft);
+    switch (1 << P.log2n) {
+    case 2048: launch_fb<FPlan4096, MODE>(st, P, A); break;
+    case 1024: launch_fb<FPlan2048, MODE>(st, P, A); break;
+    default: launch_fb<FPlan1024, MODE>(st, P, A); break;
+    }
+}
+
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
                     float *amp_out, float *ph_out, const float *mask)
@@ -1120,6 +1151,20 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
         launch_td_window(st, npix, P.nt, in, wa, data_out);
         if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
         launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        return;
+    }
+    // FB kernels (chirp-z lengths): same split — the windowed-trace output is its own launch
+    if (P.family == kFamilyFB && data_out && wa) {
+        launch_td_window(st, npix, P.nt, in, wa, data_out);
+        if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
+        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        return;
+    }
+    if (P.family == kFamilyFB && !wb && !data_out) {
+        FBArgs A{};
+        A.npix = npix; A.in = in; A.pre_win = wa; A.mask = mask ? mask : P.ones;
+        A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        dispatch_fb<kFwd>(st, P, A);
         return;
     }
     if (P.family == kFamilyF && !wb && !data_out && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
@@ -1146,28 +1191,18 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         dispatch_f<kInv>(st, P, A, false);
         return;
     }
+    if (P.family == kFamilyFB) {
+        FBArgs A{};
+        A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.mask = P.ones; A.post_win = win;
+        A.data_out = out; A.img = img;
+        dispatch_fb<kInv>(st, P, A);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
     allow_dynamic_lds(k_fft_inv, lds);
     THZ_LAUNCH(k_fft_inv, grid, block, lds, st, P, npix, fft_in, win, out, img);
-}
-
-template <class PL>
-static void launch_fb(hipStream_t st, const PlanDev &P, const FBArgs &A)
-{
-    const unsigned kBlock = 512, kWpb = kBlock / kWave;
-    const size_t lds = FBLayout<PL>::lds_bytes((int)kWpb, P.nt, P.nf);
-    size_t per_cu = kLdsBytesPerCU / lds;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    const size_t n_pairs = (A.npix + 1) / 2;  // one wave per pair of traces
-    size_t g = (n_pairs + kWpb - 1) / kWpb;
-    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
-    if (g < 1) g = 1;
-    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
-    allow_dynamic_lds(k_fb<PL>, lds);
-    THZ_LAUNCH((k_fb<PL>), (unsigned)g, kBlock, lds, st, A, T);
 }
 
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
@@ -1176,15 +1211,10 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
 {
     if (P.family == kFamilyFB && fft_out && amp_out && ph_out && data_out) {
         FBArgs A{};
-        A.npix = npix; A.nt = P.nt; A.nf = P.nf; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
         A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
         A.data_out = data_out; A.img = img;
-        A.w = reinterpret_cast<const cx *>(P.chirp_conj); A.bf = reinterpret_cast<const cx *>(P.bfft);
-        switch (1 << P.log2n) {
-        case 2048: launch_fb<FPlan4096>(st, P, A); break;
-        case 1024: launch_fb<FPlan2048>(st, P, A); break;
-        default: launch_fb<FPlan1024>(st, P, A); break;
-        }
+        dispatch_fb<kPipe>(st, P, A);
         return;
     }
     if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
