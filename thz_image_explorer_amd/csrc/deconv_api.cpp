@@ -4,6 +4,7 @@
 #include "deconv_host.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -249,7 +250,9 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, mem.alloc(&d_it, sizeof(int)));
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    if (max_iter > kRlBatch && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    const bool use_graph = !getenv("THZ_NO_GRAPH");  // developer knob: plain launches for A/B timing
+    if (use_graph && max_iter > kRlBatch
+        && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         for (int o = 0; o < kRlBatch; ++o) enqueue(d_it, o);
         if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph
             || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
