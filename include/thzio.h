@@ -2,7 +2,7 @@
  * that feeds the recompute path.
  *
  * Replaces, for the C++ host mirror and the tools of this repo, what the reference
- * reaches through the `dotthz` crate (0.3.x, Cargo.toml; absent from /root/reference —
+ * reaches through the `dotthz` crate (0.3.0, Cargo.toml:64 / Cargo.lock:2974; absent from /root/reference —
  * the published dotTHz layout is restated here: one HDF5 group per measurement with the
  * string attributes thzVer, dsDescription, mdDescription, md1..mdN, user, date, time,
  * mode, instrument and the datasets ds1..dsN):

@@ -1075,7 +1075,10 @@ static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
 {
     unsigned kBlock = 512;
 #ifndef THZ_EMU
-    if (const char *e = getenv("THZ_F_BLOCK")) kBlock = (unsigned)atoi(e);  // developer knob
+    if (const char *e = getenv("THZ_F_BLOCK")) {  // developer knob: waves per block
+        const int v = atoi(e);
+        if (v >= 64 && v <= 512 && v % 64 == 0) kBlock = (unsigned)v;
+    }
 #endif
     const unsigned kWpb = kBlock / kWave;
     const size_t lds = PL::lds_bytes(kWpb);
