@@ -453,18 +453,33 @@ __global__ __launch_bounds__(256) void k_fd_cmask(size_t npix, int nf, int nt,
     }
 }
 
+// out = in * win.  One wave per trace, 16-byte accesses when the rows allow it; no per-element
+// index division (the earlier flat grid-stride form spent its time in a 64-bit modulo).
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_td_window(size_t npix, int nt,
                                                    const float *__restrict__ in,
                                                    const float *__restrict__ win,
                                                    float *__restrict__ out)
 {
-    const size_t total = npix * (size_t)nt;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x)
-        out[i] = in[i] * win[i % nt];
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    for (size_t p = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = in + p * (size_t)nt;
+        float *y = out + p * (size_t)nt;
+        if constexpr (VEC) {
+#pragma unroll 4
+            for (int e = 4 * lane; e < nt; e += 4 * kWave) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + e);
+                const float4 w = *reinterpret_cast<const float4 *>(win + e);
+                *reinterpret_cast<float4 *>(y + e) = make_float4(v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
+            }
+        } else {
+            for (int e = lane; e < nt; e += kWave) y[e] = x[e] * win[e];
+        }
+    }
 }
 
-// one wave per trace; optional bias subtraction first (io.rs:578-596)
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_intensity(size_t npix, int nt, float *__restrict__ data,
                                                    float *__restrict__ img, int subtract_bias)
 {
@@ -472,14 +487,28 @@ __global__ __launch_bounds__(256) void k_intensity(size_t npix, int nt, float *_
     const int wib = (int)(threadIdx.x >> 6);
     const int wpb = (int)(blockDim.x >> 6);
     for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
-        float *x = data + p * nt;
+        float *x = data + p * (size_t)nt;
         const float off = subtract_bias ? x[0] : 0.0f;
-        wave_sync();
+        wave_sync();  // every lane has read x[0] before lane 0 overwrites it
         float acc = 0.0f;
-        for (int i = lane; i < nt; i += kWave) {
-            float v = x[i];
-            if (subtract_bias) { v = v - off; x[i] = v; }
-            acc += v * v;
+        if constexpr (VEC) {
+            for (int e = 4 * lane; e < nt; e += 4 * kWave) {
+                float4 v = *reinterpret_cast<const float4 *>(x + e);
+                if (subtract_bias) {
+                    v = make_float4(v.x - off, v.y - off, v.z - off, v.w - off);
+                    *reinterpret_cast<float4 *>(x + e) = v;
+                }
+                acc += v.x * v.x;
+                acc += v.y * v.y;
+                acc += v.z * v.z;
+                acc += v.w * v.w;
+            }
+        } else {
+            for (int i = lane; i < nt; i += kWave) {
+                float v = x[i];
+                if (subtract_bias) { v = v - off; x[i] = v; }
+                acc += v * v;
+            }
         }
         if (img) {
             acc = wave_reduce_add(acc);
@@ -600,62 +629,83 @@ __global__ __launch_bounds__(256) void k_roi_mask(const uint64_t *__restrict__ p
 }
 
 // out[z] = sum over listed pixels (in list order) of arr[pix*len + z]
-__global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ arr, size_t len,
-                                                    const uint32_t *__restrict__ list,
-                                                    uint32_t count, float div,
-                                                    float *__restrict__ out)
+// Sum over a list of pixels, one thread per sample index z, in the list's order — the
+// reference's sequential f32 accumulation (math_tools.rs:640-659), so the result is bit-exact.
+// The order is a property of the adds only: the loads of kGatherBatch pixels are issued together
+// (kGatherBatch rows of 256 B per wave in flight) and then added one after the other.  One wave
+// per block so that the nt (or nf) independent chains spread over as many CUs as possible.
+constexpr int kGatherBatch = 64;
+
+__global__ __launch_bounds__(64) void k_gather_sum(const float *__restrict__ arr, size_t len,
+                                                   const uint32_t *__restrict__ list,
+                                                   uint32_t count, float div,
+                                                   float *__restrict__ out)
 {
-    for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < len;
-         z += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (uint32_t c = 0; c < count; ++c) s += arr[(size_t)list[c] * len + z];
-        out[z] = (div > 0.0f) ? s / div : s;
+    const size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= len) return;
+    const float *col = arr + z;
+    float s = 0.0f;
+    uint32_t c = 0;
+    for (; c + kGatherBatch <= count; c += kGatherBatch) {
+        float v[kGatherBatch];
+#pragma unroll
+        for (int i = 0; i < kGatherBatch; ++i) v[i] = col[(size_t)list[c + i] * len];
+#pragma unroll
+        for (int i = 0; i < kGatherBatch; ++i) s += v[i];
     }
+    for (; c < count; ++c) s += col[(size_t)list[c] * len];
+    out[z] = (div > 0.0f) ? s / div : s;
 }
 
-// TiltCompensation per-pixel copy, tilt_compensation.rs:171-201: front fill with
-// trace[0], tapered trace at insert_index, zeros behind.
+// One wave per pixel: the trace is copied to its insert position on the extended axis, the front
+// is filled with its first sample, the rest with zeros (tilt_compensation.rs:171-201).
 __global__ __launch_bounds__(256) void k_tilt(size_t npix, int nt_in, int nt_out,
                                               const float *__restrict__ in,
                                               const float *__restrict__ taper,
                                               const int *__restrict__ insert_index,
                                               float *__restrict__ out)
 {
-    const size_t total = npix * (size_t)nt_out;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t p = idx / nt_out;
-        const int e = (int)(idx % nt_out);
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    for (size_t p = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); p < npix; p += (size_t)gridDim.x * wpb) {
         const int ins = insert_index[p];
         const int end = (ins + nt_in < nt_out) ? ins + nt_in : nt_out;
-        const float *raw = in + p * nt_in;
-        float v = 0.0f;
-        if (e < ins) v = raw[0];
-        else if (e < end) v = raw[e - ins] * taper[e - ins];
-        out[idx] = v;
+        const float *raw = in + p * (size_t)nt_in;
+        float *o = out + p * (size_t)nt_out;
+        const float first = raw[0];
+#pragma unroll 8
+        for (int e = lane; e < nt_out; e += kWave) {
+            float v = 0.0f;
+            if (e < ins) v = first;
+            else if (e < end) v = raw[e - ins] * taper[e - ins];
+            o[e] = v;
+        }
     }
 }
 
-// scale_3d, math_tools.rs:273-301
+// Block mean over s x s pixels (math_tools.rs:273-301): one wave per output pixel, sample axis
+// across the lanes, the s*s inputs added in the reference's i-outer / j-inner order.
 __global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, size_t nx,
                                                  size_t ny, size_t L, size_t s,
                                                  float *__restrict__ out)
 {
     const size_t nw = nx / s, nh = ny / s;
-    const size_t total = nw * nh * L;
     const float sf = (float)(s * s);
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t z = idx % L;
-        const size_t ay = (idx / L) % nh;
-        const size_t ax = idx / (L * nh);
-        float sum = 0.0f;
-        for (size_t i = 0; i < s; ++i)
-            for (size_t j = 0; j < s; ++j) {
-                const size_t ox = ax * s + i, oy = ay * s + j;
-                if (ox < nx && oy < ny) sum += arr[(ox * ny + oy) * L + z];
-            }
-        out[idx] = sum / sf;
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    for (size_t q = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); q < nw * nh; q += (size_t)gridDim.x * wpb) {
+        const size_t ax = q / nh, ay = q % nh;
+        float *o = out + q * L;
+#pragma unroll 4
+        for (size_t z = (size_t)lane; z < L; z += kWave) {
+            float sum = 0.0f;
+            for (size_t i = 0; i < s; ++i)
+                for (size_t j = 0; j < s; ++j) {
+                    const size_t ox = ax * s + i, oy = ay * s + j;
+                    if (ox < nx && oy < ny) sum += arr[(ox * ny + oy) * L + z];
+                }
+            o[z] = sum / sf;
+        }
     }
 }
 
@@ -1252,15 +1302,20 @@ void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, floa
 void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
                       float *out)
 {
-    THZ_LAUNCH(k_td_window, grid_1d(npix * nt, 256, kNumCU * 8), 256, 0, st, npix, nt, in, win,
-               out);
+    const bool vec = nt % 4 == 0 && ((uintptr_t)in | (uintptr_t)win | (uintptr_t)out) % 16 == 0;
+    const unsigned grid = grid_1d(npix * kWave, 256, kNumCU * 8);
+    if (vec) THZ_LAUNCH(k_td_window<true>, grid, 256, 0, st, npix, nt, in, win, out);
+    else THZ_LAUNCH(k_td_window<false>, grid, 256, 0, st, npix, nt, in, win, out);
 }
 
 void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *img,
                       int subtract_bias)
 {
-    THZ_LAUNCH(k_intensity, grid_1d(npix * kWave, 256, kNumCU * 8), 256, 0, st, npix, nt, data, img,
-               subtract_bias);
+    const unsigned grid = grid_1d(npix * kWave, 256, kNumCU * 8);
+    if (nt % 4 == 0 && (uintptr_t)data % 16 == 0)
+        THZ_LAUNCH(k_intensity<true>, grid, 256, 0, st, npix, nt, data, img, subtract_bias);
+    else
+        THZ_LAUNCH(k_intensity<false>, grid, 256, 0, st, npix, nt, data, img, subtract_bias);
 }
 
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
@@ -1301,22 +1356,21 @@ void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_m
 void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list,
                        uint32_t count, float div, float *out)
 {
-    THZ_LAUNCH(k_gather_sum, grid_1d(len, 256, kNumCU * 8), 256, 0, st, arr, len, d_list, count,
-               div, out);
+    THZ_LAUNCH(k_gather_sum, (unsigned)((len + 63) / 64), 64, 0, st, arr, len, d_list, count, div, out);
 }
 
 void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,
                     float *out)
 {
-    const size_t total = (nx / s) * (ny / s) * L;
-    THZ_LAUNCH(k_scale3d, grid_1d(total, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+    const size_t pixels = (nx / s) * (ny / s);
+    THZ_LAUNCH(k_scale3d, grid_1d(pixels * kWave, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
 }
 
 void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float *in,
                  const float *taper, const int *insert_index, float *out)
 {
-    THZ_LAUNCH(k_tilt, grid_1d(npix * nt_out, 256, kNumCU * 8), 256, 0, st, npix, nt_in, nt_out, in,
-               taper, insert_index, out);
+    THZ_LAUNCH(k_tilt, grid_1d(npix * kWave, 256, kNumCU * 8), 256, 0, st, npix, nt_in, nt_out, in, taper,
+               insert_index, out);
 }
 
 // ---- deconvolution launchers
