@@ -525,8 +525,19 @@ __global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
          i += (size_t)gridDim.x * blockDim.x) {
+        // sequential f32 sum over axis 0 (ndarray's order); only the adds are ordered, so the
+        // loads of 16 rows go out together
         float s = 0.0f;
-        for (size_t a = 0; a < n0; ++a) s += arr[a * inner + i];
+        size_t a = 0;
+        const float *col = arr + i;
+        for (; a + 16 <= n0; a += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = col[(a + u) * inner];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; a < n0; ++a) s += col[a * inner];
         out[i] = (div > 0.0f) ? s / div : s;
     }
 }
