@@ -154,6 +154,7 @@ template <class T>
 inline const T *launder_uniform(const T *p) { return p; }
 inline int launder_v(int x) { return x; }
 inline float launder_f(float x) { return x; }
+inline int launder_after(int x, float) { return x; }
 }  // namespace thz
 #define THZ_UNIFORM(x) (x)
 #define THZ_SCHED_FENCE() ((void)0)

@@ -367,4 +367,295 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FB2: chirp-z lengths 1024 < nt < 2048.  The convolution length M = 4096 is twice the largest
+// complex size of the F core, so each M-point transform is two N = 2048 core runs plus one radix-2
+// stage, arranged so that no reordering pass is needed:
+//   forward  : decimation in frequency — the first stage needs a[k + N], which is zero (nt <= N):
+//              b_0[k] = a[k], b_1[k] = a[k] W_M^k; two core runs leave A[2j + s] in region s
+//   multiply : by FFT_M(b)[2j + s] / M, in place, swapped (inverse through the forward passes)
+//   inverse  : decimation in time — two core runs on the regions as they are, and the last stage
+//              c[k] = swap(D_0[k] + W_M^k D_1[k]) is evaluated where c is consumed (only k < nt
+//              is ever needed, i.e. only the first of its two outputs).
+// Two traces per convolution as in k_fb.  A wave owns two regions of N + 2 entries (32.8 KB):
+// four waves per block.  The masked spectra of the pair are kept in registers until every lane has
+// finished reading the regions, then parked in region 1 for the inverse.
+template <class P>
+struct FB2Layout {
+    static constexpr int kWaves = 4;
+    static constexpr int pad4(int v) { return (v + 3) & ~3; }
+    static size_t lds_bytes(int nf)
+    {
+        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * 2 * P::WAVE_ENTRIES) * sizeof(cx)
+               + (size_t)pad4(nf) * sizeof(float);
+    }
+};
+
+struct FB2Args {
+    FBArgs a;       // same fields as the single-core kernel (w: nt, bf: M)
+    const cx *tw;   // W_M^m, m < M
+};
+
+// r[c][j1] <- swap(region[nat(n)] * bf[2 n + s]), n in the core's input layout
+template <class P>
+__device__ __forceinline__ void fb2_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
+                                                     cx (&r)[P::C1][P::R1])
+{
+    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    int fbase[2][C1];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
+    const unsigned bl = (unsigned)launder_v(2 * C1 * lane + s);
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) {
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            const cx a = region[fbase[j1 & 1][c] + M1 * j1];
+            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(2 * (M1 * j1 + c))));
+            r[c][j1] = cx{t.y, t.x};
+        }
+        if ((j1 & 3) == 3) THZ_SCHED_FENCE();
+    }
+}
+
+// c[m] = swap(D_0[m] + W_M^m D_1[m]) for one index (the radix-2 stage of the inverse, on demand)
+__device__ __forceinline__ cx fb2_c(const cx *r0, const cx *r1, const cx *tw, int m)
+{
+    const cx d0 = r0[nat(m)], d1 = r1[nat(m)];
+    const cx z = d0 + cx_mul(ld_off(tw, (unsigned)m), d1);
+    return cx{z.y, z.x};
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    static_assert(P::N == 2048, "two regions of 2048: convolution length 4096");
+    constexpr int NG = 4;  // epilogue groups of 256 bins: nf <= 1024
+    const FBArgs &A = B.a;
+    const int L = A.nt, nf = A.nf;
+    const int lane = lane_id();
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + P::T1_ENTRIES;
+    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * 2 * P::WAVE_ENTRIES;
+    cx *reg1 = reg0 + P::WAVE_ENTRIES;
+    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * 2 * P::WAVE_ENTRIES);
+    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    __syncthreads();
+
+    FAddr<P> ad;
+    ad.init(lane);
+    const float fnt = (float)L;
+    const int half = L / 2;
+    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
+    const size_t n_pairs = (A.npix + 1) / 2;
+    const size_t stride = (size_t)gridDim.x * wpb;
+
+    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
+        const size_t p = 2 * q;
+        const bool has2 = p + 1 < A.npix;  // wave-uniform
+        cx r[C1][R1];
+        ad.refresh();
+        const cx *wl = launder_uniform(A.w);
+        const cx *bf = launder_uniform(A.bf);
+        const cx *tw = launder_uniform(B.tw);
+        const float *mask_l = launder_uniform((const float *)mask_s);
+        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
+        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
+        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
+
+        // ---- forward, first stage: b_s[n] = a[n] W_M^(s n), a[n] = (x1 + i x2)[n] pre[n] w[n]
+        {
+            const float *x1 = A.in + p * (size_t)L;
+            const float *x2 = has2 ? x1 + L : x1;
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) {
+                constexpr int H = R1 / 4;  // quarter batches: 8 registers per element in flight
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    float xa[C1][H], xb[C1][H], pw[C1][H];
+                    cx wv[C1][H], tv[C1][H];
+                    const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
+#pragma unroll
+                    for (int j = 0; j < H; ++j) {
+#pragma unroll
+                        for (int c = 0; c < C1; ++c) {
+                            const int n = M1 * (H * h + j) + lbh + c;
+                            const unsigned nn = (unsigned)(n < L ? n : L - 1);
+                            xa[c][j] = ld_off(x1, nn);
+                            xb[c][j] = ld_off(x2, nn);
+                            wv[c][j] = ld_off(wl, nn);
+                            pw[c][j] = pre_g ? ld_off(pre_g, nn) : 1.0f;
+                            tv[c][j] = s ? ld_off(tw, nn) : cx{1.0f, 0.0f};
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < H; ++j) {
+#pragma unroll
+                        for (int c = 0; c < C1; ++c) {
+                            const int n = M1 * (H * h + j) + lbh + c;
+                            const float pwv = n < L ? pw[c][j] : 0.0f;
+                            const cx z = cx{xa[c][j] * pwv, has2 ? xb[c][j] * pwv : 0.0f};
+                            cx v = cx_mul(z, wv[c][j]);
+                            if (s) v = cx_mul(v, tv[c][j]);
+                            r[c][H * h + j] = v;
+                        }
+                    }
+                    THZ_SCHED_FENCE();
+                }
+                cx *reg = s ? reg1 : reg0;
+                f_core_pass1<P>(r, reg, t1, ad, lane);
+                f_core_pass23<P>(reg, t2, ad, lane);
+            }
+        }
+        // ---- multiply by FFT_M(b)/M and inverse core runs, region by region
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            cx *reg = s ? reg1 : reg0;
+            fb2_multiply_swapped<P>(reg, bf, s, lane, r);
+            wave_sync();
+            f_core_pass1<P>(r, reg, t1, ad, lane);
+            f_core_pass23<P>(reg, t2, ad, lane);
+        }
+
+        // ---- spectrum epilogue; the pair's masked spectra wait in registers
+        cx Y1[NG][4], Y2[NG][4];
+        {
+            FBUnwrap u1, u2;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (256 * g < nf) {  // wave-uniform
+                    const int k0 = 256 * g + lb4;
+                    cx X1[4], X2[4];
+                    float m[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = k0 + c;
+                        ok[c] = k < nf;
+                        const int kc = ok[c] ? k : nf - 1;
+                        const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
+                        const cx wk = ld_off(wl, (unsigned)kc);
+                        const cx Fk = cx_mul(fb2_c(reg0, reg1, tw, kc), wk);
+                        const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
+                        const cx Fm = cx_mul(fb2_c(reg0, reg1, tw, km), wm);
+                        X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
+                        X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
+                        m[c] = mask_l[kc];
+                        if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
+                            X1[c].y = 0.0f;
+                            X2[c].y = 0.0f;
+                        }
+                        Y1[g][c] = cx{X1[c].x * m[c], X1[c].y * m[c]};
+                        Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                    }
+                    const size_t o1 = p * (size_t)nf + k0;
+                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                    if (has2)
+                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
+                                       A.ph_out + o1 + nf);
+                }
+            }
+        }
+        wave_sync();  // every lane is done with D_0, D_1
+        // park them in region 1: Y1[k] at k, Y2[k] at nf + k (2 nf <= N + 2)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (256 * g < nf) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = 256 * g + lb4 + c;
+                    if (k < nf) {
+                        reg1[k] = Y1[g][c];
+                        reg1[nf + k] = Y2[g][c];
+                    }
+                }
+            }
+        wave_sync();
+
+        // ---- inverse, first stage: b'_s[n] = u[n] W_M^(s n), u[n] = conj(Y1full + i Y2full)[n] w[n]
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            constexpr int H = R1 / 4;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                cx wv[C1][H], tv[C1][H];
+                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;
+#pragma unroll
+                for (int j = 0; j < H; ++j)
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lbh + c;
+                        const unsigned nn = (unsigned)(n < L ? n : L - 1);
+                        wv[c][j] = ld_off(wl, nn);
+                        tv[c][j] = s ? ld_off(tw, nn) : cx{1.0f, 0.0f};
+                    }
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int n = M1 * (H * h + j) + lbh + c;
+                        const int nn = n < L ? n : L - 1;
+                        const bool low = nn <= half;
+                        const int kk = low ? nn : L - nn;
+                        const cx y1 = reg1[kk], y2 = reg1[nf + kk];
+                        const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
+                        cx v = cx_mul(gc, wv[c][j]);
+                        if (s) v = cx_mul(v, tv[c][j]);
+                        r[c][H * h + j] = n < L ? v : cx{0.0f, 0.0f};
+                    }
+                }
+                THZ_SCHED_FENCE();
+            }
+            cx *reg = s ? reg1 : reg0;
+            wave_sync();  // s = 1: every lane has read the parked spectra before region 1 is rewritten
+            f_core_pass1<P>(r, reg, t1, ad, lane);
+            f_core_pass23<P>(reg, t2, ad, lane);
+        }
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            cx *reg = s ? reg1 : reg0;
+            fb2_multiply_swapped<P>(reg, bf, s, lane, r);
+            wave_sync();
+            f_core_pass1<P>(r, reg, t1, ad, lane);
+            f_core_pass23<P>(reg, t2, ad, lane);
+        }
+
+        // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
+        {
+            float *o1 = A.data_out + p * (size_t)L;
+            float acc1 = 0.0f, acc2 = 0.0f;
+#pragma unroll 4
+            for (int n = lb1; n < L; n += kWave) {
+                const cx U = cx_mul(fb2_c(reg0, reg1, tw, n), ld_off(wl, (unsigned)n));
+                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
+                const float v1 = (U.x / fnt) * pw;
+                o1[n] = v1;
+                acc1 += v1 * v1;
+                if (has2) {
+                    const float v2 = (-U.y / fnt) * pw;
+                    o1[L + n] = v2;
+                    acc2 += v2 * v2;
+                }
+            }
+            if (A.img) {
+                acc1 = wave_reduce_add(acc1);
+                acc2 = wave_reduce_add(acc2);
+                if (lane == 0) {
+                    A.img[p] = acc1;
+                    if (has2) A.img[p + 1] = acc2;
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 }  // namespace thz

@@ -101,6 +101,14 @@ __device__ __forceinline__ int launder_v(int x)
     return x;
 }
 
+// x, but not computable before `dep` is: serialises batches of independent loads that the
+// scheduler would otherwise all issue up front (and spill their destinations)
+__device__ __forceinline__ int launder_after(int x, float dep)
+{
+    asm volatile("" : "+v"(x) : "v"(dep));
+    return x;
+}
+
 // a float the optimiser must have in a register here (forces pending loads of it to complete)
 __device__ __forceinline__ float launder_f(float x)
 {
