@@ -512,13 +512,14 @@ def test_reference_spectrum_rejects_what_the_reference_panics_on(engine):
 
 # ---- chirp-z fused chain (FB kernels) for lengths that are not a power of two -----------------
 @pytest.mark.parametrize("shape", [(3, 3, 1000), (5, 1, 513), (2, 2, 300), (7, 1, 77), (1, 1, 1023), (4, 5, 129),
-                                   (3, 1, 2000), (2, 2, 1500), (1, 1, 2047), (5, 1, 1025)])
+                                   (3, 1, 2000), (2, 2, 1500), (1, 1, 2047), (5, 1, 1025),
+                                   (3, 1, 4000), (2, 1, 3000), (1, 1, 4095), (3, 1, 2049)])
 def test_chirpz_fused_pipeline_lengths(engine, shape):
     nx, ny, nt = shape
     time = synth.make_time(nt)
     cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()
     engine.set_time_axis(time)
-    assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else "fb2-bluestein")
+    assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else ("fb2-" if nt < 2048 else "fb4-"))
     chain = synth.default_chain(time)
     got = synth.run_gpu_pipeline(engine, cube, chain)
     ref = ob.run_pipeline(cube, time, chain)

@@ -658,4 +658,283 @@ __global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FB4: chirp-z lengths 2048 < nt < 4096: convolution length M = 8192 = four N = 2048 core runs
+// per transform and one radix-4 stage, same arrangement as FB2 (decimation in frequency forward —
+// a[k + 2N], a[k + 3N] are zero since nt <= 2N — decimation in time inverse, last stage on
+// demand).  A wave owns four regions (65.6 KB): two waves per block, one per SIMD pair, so the
+// wave may use the whole register file: the pair's masked spectra (up to 128 values per lane)
+// wait in registers, and the last two inputs of the inverse's first stage are both built before
+// their regions are overwritten.
+template <class P>
+struct FB4Layout {
+    static constexpr int kWaves = 2;
+    static constexpr int pad4(int v) { return (v + 3) & ~3; }
+    static size_t lds_bytes(int nf)
+    {
+        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * 4 * P::WAVE_ENTRIES) * sizeof(cx)
+               + (size_t)pad4(nf) * sizeof(float);
+    }
+};
+
+// z * (-i)^s
+__device__ __forceinline__ cx fb4_rot(cx z, int s)
+{
+    switch (s & 3) {
+    case 1: return cx{z.y, -z.x};
+    case 2: return cx{-z.x, -z.y};
+    case 3: return cx{-z.y, z.x};
+    default: return z;
+    }
+}
+
+// r[c][j1] <- swap(region[nat(n)] * bf[4 n + s])
+template <class P>
+__device__ __forceinline__ void fb4_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
+                                                     cx (&r)[P::C1][P::R1])
+{
+    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    int fbase[2][C1];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
+    const unsigned bl = (unsigned)launder_v(4 * C1 * lane + s);
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) {
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            const cx a = region[fbase[j1 & 1][c] + M1 * j1];
+            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(4 * (M1 * j1 + c))));
+            r[c][j1] = cx{t.y, t.x};
+        }
+        if ((j1 & 3) == 3) THZ_SCHED_FENCE();
+    }
+}
+
+// c[m], m = k + N q (q = 0, 1): swap(sum_s (-i)^(s q) W_M^(s k) D_s[k])
+template <int N>
+__device__ __forceinline__ cx fb4_c(const cx *reg0, int region_stride, const cx *tw, int m)
+{
+    const int k = m & (N - 1), q = m >> 11;
+    const int slot = nat(k);
+    const cx d0 = reg0[slot], d1 = reg0[region_stride + slot], d2 = reg0[2 * region_stride + slot],
+             d3 = reg0[3 * region_stride + slot];
+    const cx t1 = cx_mul(ld_off(tw, (unsigned)k), d1), t2 = cx_mul(ld_off(tw, (unsigned)(2 * k)), d2),
+             t3 = cx_mul(ld_off(tw, (unsigned)(3 * k)), d3);
+    const cx z = q ? d0 + fb4_rot(t1, 1) - t2 + fb4_rot(t3, 3) : d0 + t1 + t2 + t3;
+    return cx{z.y, z.x};
+}
+
+template <class P>
+__global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    static_assert(N == 2048, "four regions of 2048: convolution length 8192");
+    constexpr int NG = 8;  // epilogue groups of 256 bins: nf <= 2048
+    constexpr int RS = P::WAVE_ENTRIES;
+    const FBArgs &A = B.a;
+    const int L = A.nt, nf = A.nf;
+    const int lane = lane_id();
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + P::T1_ENTRIES;
+    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * 4 * RS;
+    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * 4 * RS);
+    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    __syncthreads();
+
+    FAddr<P> ad;
+    ad.init(lane);
+    const float fnt = (float)L;
+    const int half = L / 2;
+    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
+    const size_t n_pairs = (A.npix + 1) / 2;
+    const size_t stride = (size_t)gridDim.x * wpb;
+
+    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
+        const size_t p = 2 * q;
+        const bool has2 = p + 1 < A.npix;  // wave-uniform
+        ad.refresh();
+        const cx *wl = launder_uniform(A.w);
+        const cx *bf = launder_uniform(A.bf);
+        const cx *tw = launder_uniform(B.tw);
+        const float *mask_l = launder_uniform((const float *)mask_s);
+        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
+        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
+        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
+        const float *x1 = A.in + p * (size_t)L;
+        const float *x2 = has2 ? x1 + L : x1;
+
+        // a[m] = (x1 + i x2)[m] pre[m] w[m], zero from nt on
+        auto a_at = [&](int m) -> cx {
+            const unsigned mm = (unsigned)(m < L ? m : L - 1);
+            const float pw = pre_g ? ld_off(pre_g, mm) : 1.0f;
+            const float xa = ld_off(x1, mm), xb = ld_off(x2, mm);
+            const float pwv = m < L ? pw : 0.0f;
+            return cx_mul(cx{xa * pwv, has2 ? xb * pwv : 0.0f}, ld_off(wl, mm));
+        };
+        // u[m] = conj(Y1full + i Y2full)[m] w[m] from the parked spectra (Y1 in region 2, Y2 in region 3)
+        auto u_at = [&](int m) -> cx {
+            const int mm = m < L ? m : L - 1;
+            const bool low = mm <= half;
+            const int kk = low ? mm : L - mm;
+            const cx y1 = reg0[2 * RS + kk], y2 = reg0[3 * RS + kk];
+            const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
+            const cx v = cx_mul(gc, ld_off(wl, (unsigned)mm));
+            return m < L ? v : cx{0.0f, 0.0f};
+        };
+        // first stage of either direction for sub-transform s: (f[k] + (-i)^s f[k + N]) W_M^(s k)
+        auto first_stage = [&](auto f, int s, cx(&r)[C1][R1]) {
+            constexpr int H = R1 / 4;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int k = M1 * (H * h + j) + lbh + c;
+                        cx v = f(k) + fb4_rot(f(k + N), s);
+                        if (s) v = cx_mul(v, ld_off(tw, (unsigned)(s * k)));
+                        r[c][H * h + j] = v;
+                    }
+                }
+                THZ_SCHED_FENCE();
+            }
+        };
+
+        // ---- forward: four sub-transforms, multiply, four inverse sub-transforms
+        {
+            cx r[C1][R1];
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                first_stage(a_at, s, r);
+                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+            }
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                fb4_multiply_swapped<P>(reg0 + s * RS, bf, s, lane, r);
+                wave_sync();
+                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+            }
+        }
+
+        // ---- spectrum epilogue; the pair's masked spectra wait in registers
+        cx Y1[NG][4], Y2[NG][4];
+        {
+            FBUnwrap u1, u2;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (256 * g < nf) {  // wave-uniform
+                    const int k0 = 256 * g + lb4;
+                    cx X1[4], X2[4];
+                    float m[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = k0 + c;
+                        ok[c] = k < nf;
+                        const int kc = ok[c] ? k : nf - 1;
+                        const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
+                        const cx wk = ld_off(wl, (unsigned)kc);
+                        const cx Fk = cx_mul(fb4_c<N>(reg0, RS, tw, kc), wk);
+                        const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
+                        const cx Fm = cx_mul(fb4_c<N>(reg0, RS, tw, km), wm);
+                        X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
+                        X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
+                        m[c] = mask_l[kc];
+                        if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
+                            X1[c].y = 0.0f;
+                            X2[c].y = 0.0f;
+                        }
+                        Y1[g][c] = cx{X1[c].x * m[c], X1[c].y * m[c]};
+                        Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                    }
+                    const size_t o1 = p * (size_t)nf + k0;
+                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                    if (has2)
+                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
+                                       A.ph_out + o1 + nf);
+                    THZ_SCHED_FENCE();
+                }
+            }
+        }
+        wave_sync();  // every lane is done with D_0 .. D_3
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (256 * g < nf) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = 256 * g + lb4 + c;
+                    if (k < nf) {
+                        reg0[2 * RS + k] = Y1[g][c];
+                        reg0[3 * RS + k] = Y2[g][c];
+                    }
+                }
+            }
+        wave_sync();
+
+        // ---- inverse: sub-transforms 0 and 1 go to regions 0 and 1; 2 and 3 are both built before
+        // their regions (which hold the parked spectra) are overwritten
+        {
+            cx r[C1][R1], r3[C1][R1];
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) {
+                first_stage(u_at, s, r);
+                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+            }
+            first_stage(u_at, 2, r);
+            first_stage(u_at, 3, r3);
+            wave_sync();
+            f_core_pass1<P>(r, reg0 + 2 * RS, t1, ad, lane);
+            f_core_pass23<P>(reg0 + 2 * RS, t2, ad, lane);
+            f_core_pass1<P>(r3, reg0 + 3 * RS, t1, ad, lane);
+            f_core_pass23<P>(reg0 + 3 * RS, t2, ad, lane);
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                fb4_multiply_swapped<P>(reg0 + s * RS, bf, s, lane, r);
+                wave_sync();
+                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+            }
+        }
+
+        // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
+        {
+            float *o1 = A.data_out + p * (size_t)L;
+            float acc1 = 0.0f, acc2 = 0.0f;
+#pragma unroll 2
+            for (int n = lb1; n < L; n += kWave) {
+                const cx U = cx_mul(fb4_c<N>(reg0, RS, tw, n), ld_off(wl, (unsigned)n));
+                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
+                const float v1 = (U.x / fnt) * pw;
+                o1[n] = v1;
+                acc1 += v1 * v1;
+                if (has2) {
+                    const float v2 = (-U.y / fnt) * pw;
+                    o1[L + n] = v2;
+                    acc2 += v2 * v2;
+                }
+            }
+            if (A.img) {
+                acc1 = wave_reduce_add(acc1);
+                acc2 = wave_reduce_add(acc2);
+                if (lane == 0) {
+                    A.img[p] = acc1;
+                    if (has2) A.img[p + 1] = acc2;
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 }  // namespace thz

@@ -1273,7 +1273,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img)
 {
-    if (P.family == kFamilyFB2 && fft_out && amp_out && ph_out && data_out) {
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4) && fft_out && amp_out && ph_out && data_out) {
         FB2Args B{};
         FBArgs &A = B.a;
         A.npix = npix; A.nt = P.nt; A.nf = P.nf; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
@@ -1282,15 +1282,21 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.w = reinterpret_cast<const cx *>(P.chirp_conj); A.bf = reinterpret_cast<const cx *>(P.bfft);
         B.tw = reinterpret_cast<const cx *>(P.tw);
         using PL = FPlan4096;
-        const size_t lds = FB2Layout<PL>::lds_bytes(P.nf);
-        const unsigned wpb = FB2Layout<PL>::kWaves;
+        const bool four = P.family == kFamilyFB4;
+        const size_t lds = four ? FB4Layout<PL>::lds_bytes(P.nf) : FB2Layout<PL>::lds_bytes(P.nf);
+        const unsigned wpb = four ? FB4Layout<PL>::kWaves : FB2Layout<PL>::kWaves;
         const size_t n_pairs = (npix + 1) / 2;
         size_t g = (n_pairs + wpb - 1) / wpb;
         if (g > (size_t)kNumCU) g = kNumCU;
         if (g < 1) g = 1;
         FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
-        allow_dynamic_lds(k_fb2<PL>, lds);
-        THZ_LAUNCH((k_fb2<PL>), (unsigned)g, wpb * kWave, lds, st, B, T);
+        if (four) {
+            allow_dynamic_lds(k_fb4<PL>, lds);
+            THZ_LAUNCH((k_fb4<PL>), (unsigned)g, wpb * kWave, lds, st, B, T);
+        } else {
+            allow_dynamic_lds(k_fb2<PL>, lds);
+            THZ_LAUNCH((k_fb2<PL>), (unsigned)g, wpb * kWave, lds, st, B, T);
+        }
         return;
     }
     if (P.family == kFamilyFB && fft_out && amp_out && ph_out && data_out) {

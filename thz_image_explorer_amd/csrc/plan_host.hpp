@@ -131,12 +131,13 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
     // F core of complex length Nc: the half-length transform of a power-of-two trace (family F), or
     // the length-M convolution transform of a chirp-z length with M <= 2048 (family FB)
     // ... or two core runs per length-4096 convolution (family FB2, 1024 < nt < 2048)
+    const bool fb4 = allow_f && P.mode == kModeBluestein && N == 8192 && f_factors(N / 2, r1, r2, r3);
     const bool fb2 = allow_f && P.mode == kModeBluestein && N == 4096 && f_factors(N, r1, r2, r3);
     const bool fb = !fb2 && allow_f && P.mode == kModeBluestein && f_factors(2 * N, r1, r2, r3);
-    if (fb || fb2 || (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3))) {
-        P.family = fb2 ? kFamilyFB2 : (fb ? kFamilyFB : kFamilyF);
-        P.variant = fb2 ? "fb2-bluestein-regs-3pass-lds-xor" : (fb ? "fb-bluestein-regs-3pass-lds-xor" : "f-regs-3pass-lds-xor");
-        const size_t Nc = fb2 ? N / 2 : (fb ? N : nt / 2), m1 = (size_t)r2 * r3;
+    if (fb || fb2 || fb4 || (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3))) {
+        P.family = fb4 ? kFamilyFB4 : fb2 ? kFamilyFB2 : (fb ? kFamilyFB : kFamilyF);
+        P.variant = fb4 ? "fb4-bluestein-regs-3pass-lds-xor" : fb2 ? "fb2-bluestein-regs-3pass-lds-xor" : (fb ? "fb-bluestein-regs-3pass-lds-xor" : "f-regs-3pass-lds-xor");
+        const size_t Nc = fb4 ? N / 4 : fb2 ? N / 2 : (fb ? N : nt / 2), m1 = (size_t)r2 * r3;
         P.f_t1.resize((size_t)r1 * m1);
         for (int k1 = 0; k1 < r1; ++k1)
             for (size_t m = 0; m < m1; ++m) {
@@ -177,7 +178,8 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     D.bfft = bfft;
     D.family = kFamilyG;
     if (H.family == kFamilyF && f_t1 && f_t2 && f_w2n && ones) D.family = kFamilyF;
-    if ((H.family == kFamilyFB || H.family == kFamilyFB2) && f_t1 && f_t2 && ones && chirp_conj && bfft)
+    if ((H.family == kFamilyFB || H.family == kFamilyFB2 || H.family == kFamilyFB4) && f_t1 && f_t2 && ones
+        && chirp_conj && bfft)
         D.family = H.family;
     D.ones = ones;
     D.f_t1 = f_t1;
