@@ -43,16 +43,16 @@ def _fwd(emu, x, wa, mask, nt):
 
 
 @pytest.mark.parametrize("family", ["auto", "g"])
-@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 30])
+@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 30, 1500, 3000])
 def test_forward_inverse_vs_oracle(emu, nt, family):
     emu.emu_allow_f(1 if family == "auto" else 0)
     if family == "g" and nt not in (1024, 2048, 4096):
         pytest.skip("only one family exists for this length")
-    # auto: F for 1024/2048/4096, FB (chirp-z over the F core; fused chain only) for other lengths
-    # that are not a power of two; the stage entry points used here still run the G kernels there
+    # auto: F for 1024/2048/4096, FB / FB2 / FB4 (chirp-z over the F core) for the other lengths
+    # below 4096 that are not a power of two
     want = 0
     if family == "auto":
-        want = 1 if nt in (1024, 2048, 4096) else (2 if nt & (nt - 1) else 0)
+        want = 1 if nt in (1024, 2048, 4096) else ((2 if nt < 1024 else 3 if nt < 2048 else 4) if nt & (nt - 1) else 0)
     assert emu.emu_family(nt) == want
     npix = 11  # > waves per block: exercises the grid-stride loop and a ragged last block
     rng = np.random.default_rng(nt)

@@ -428,7 +428,7 @@ __device__ __forceinline__ cx fb2_c(const cx *r0, const cx *r1, const cx *tw, in
     return cx{z.y, z.x};
 }
 
-template <class P>
+template <class P, int MODE>
 __global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
 {
     THZ_DYN_LDS(lds);
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
         const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
         const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
 
+        if constexpr (MODE != kInv) {
         // ---- forward, first stage: b_s[n] = a[n] W_M^(s n), a[n] = (x1 + i x2)[n] pre[n] w[n]
         {
             const float *x1 = A.in + p * (size_t)L;
@@ -557,14 +558,17 @@ __global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
                         Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
                     }
                     const size_t o1 = p * (size_t)nf + k0;
-                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                                   A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
                     if (has2)
-                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
-                                       A.ph_out + o1 + nf);
+                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
+                                       A.amp_out ? A.amp_out + o1 + nf : nullptr,
+                                       A.ph_out ? A.ph_out + o1 + nf : nullptr);
                 }
             }
         }
         wave_sync();  // every lane is done with D_0, D_1
+        if constexpr (MODE == kFwd) continue;
         // park them in region 1: Y1[k] at k, Y2[k] at nf + k (2 nf <= N + 2)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -579,6 +583,21 @@ __global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
                 }
             }
         wave_sync();
+        } else {
+            // inverse only: the two spectra from memory to where the fused chain parks them
+            const cx *f1 = A.fft_in + p * (size_t)nf;
+            for (int k = lb1; k < nf; k += kWave) {
+                cx y1 = ld_off(f1, (unsigned)k);
+                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + k)) : cx{0.0f, 0.0f};
+                if (k == 0 || ((L & 1) == 0 && k == nf - 1)) {
+                    y1.y = 0.0f;
+                    y2.y = 0.0f;
+                }
+                reg1[k] = y1;
+                reg1[nf + k] = y2;
+            }
+            wave_sync();
+        }
 
         // ---- inverse, first stage: b'_s[n] = u[n] W_M^(s n), u[n] = conj(Y1full + i Y2full)[n] w[n]
 #pragma unroll 1
@@ -726,7 +745,7 @@ __device__ __forceinline__ cx fb4_c(const cx *reg0, int region_stride, const cx 
     return cx{z.y, z.x};
 }
 
-template <class P>
+template <class P, int MODE>
 __global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
 {
     THZ_DYN_LDS(lds);
@@ -808,6 +827,7 @@ __global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
             }
         };
 
+        if constexpr (MODE != kInv) {
         // ---- forward: four sub-transforms, multiply, four inverse sub-transforms
         {
             cx r[C1][R1];
@@ -858,15 +878,18 @@ __global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
                         Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
                     }
                     const size_t o1 = p * (size_t)nf + k0;
-                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out + o1, A.amp_out + o1, A.ph_out + o1);
+                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                                   A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
                     if (has2)
-                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out + o1 + nf, A.amp_out + o1 + nf,
-                                       A.ph_out + o1 + nf);
+                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
+                                       A.amp_out ? A.amp_out + o1 + nf : nullptr,
+                                       A.ph_out ? A.ph_out + o1 + nf : nullptr);
                     THZ_SCHED_FENCE();
                 }
             }
         }
         wave_sync();  // every lane is done with D_0 .. D_3
+        if constexpr (MODE == kFwd) continue;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             if (256 * g < nf) {
@@ -880,6 +903,20 @@ __global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
                 }
             }
         wave_sync();
+        } else {
+            const cx *f1 = A.fft_in + p * (size_t)nf;
+            for (int k = lb1; k < nf; k += kWave) {
+                cx y1 = ld_off(f1, (unsigned)k);
+                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + k)) : cx{0.0f, 0.0f};
+                if (k == 0 || ((L & 1) == 0 && k == nf - 1)) {
+                    y1.y = 0.0f;
+                    y2.y = 0.0f;
+                }
+                reg0[2 * RS + k] = y1;
+                reg0[3 * RS + k] = y2;
+            }
+            wave_sync();
+        }
 
         // ---- inverse: sub-transforms 0 and 1 go to regions 0 and 1; 2 and 3 are both built before
         // their regions (which hold the parked spectra) are overwritten
