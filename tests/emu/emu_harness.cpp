@@ -50,7 +50,7 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 {
     PlanHost H;
     if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
-    if (H.mode != kModePow2 && H.family != kFamilyFB && H.family != kFamilyFB2 && H.family != kFamilyFB4) return -2;
+    if (H.mode != kModePow2 && H.family < kFamilyFB) return -2;
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img);
     return 0;

@@ -102,12 +102,12 @@ def test_fused_pipeline_vs_oracle(emu, nt):
     assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / ref["img"].max() < 1e-5
 
 
-@pytest.mark.parametrize("nt", [1001, 1000, 1024 - 1, 513, 512 - 1, 300, 257, 129, 40, 1025, 1500, 2000, 2047, 2049, 3000, 4000, 4095])
+@pytest.mark.parametrize("nt", [1001, 1000, 1024 - 1, 513, 512 - 1, 300, 257, 129, 40, 1025, 1500, 2000, 2047, 2049, 3000, 4000, 4095, 4097, 6000, 8191])
 def test_chirpz_pipeline_vs_oracle(emu, nt):
     """FB / FB2 kernels (fft_fb.hpp): non-power-of-two trace lengths, chirp-z over the F core
-    (one core run per transform up to nt = 1023, two up to 2047, four up to 4095)"""
+    (one core run per transform up to nt = 1023, two up to 2047, four up to 4095, eight up to 8191)"""
     emu.emu_allow_f(1)
-    assert emu.emu_family(nt) == (2 if nt < 1024 else (3 if nt < 2048 else 4))
+    assert emu.emu_family(nt) == (2 if nt < 1024 else 3 if nt < 2048 else 4 if nt < 4096 else 5)
     nx, ny = (5, 1) if nt % 2 else (2, 3)   # odd trace count: the last pair has one member
     time = synth.make_time(nt)
     cube = synth.make_traces(np.arange(nx * ny) + 11, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()

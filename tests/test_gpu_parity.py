@@ -337,7 +337,7 @@ def test_device_synth_matches_host(engine):
 def test_edge_cases(engine):
     e = engine
     with pytest.raises(pkg.ThzError) as ei:
-        e.set_time_axis(np.arange(5000, dtype=np.float32))  # non-pow2 > 4096
+        e.set_time_axis(np.arange(9000, dtype=np.float32))  # not a power of two and > 8191
     assert ei.value.code == -2
     with pytest.raises(pkg.ThzError):
         e.set_time_axis(np.zeros(1, np.float32))
@@ -513,13 +513,14 @@ def test_reference_spectrum_rejects_what_the_reference_panics_on(engine):
 # ---- chirp-z fused chain (FB kernels) for lengths that are not a power of two -----------------
 @pytest.mark.parametrize("shape", [(3, 3, 1000), (5, 1, 513), (2, 2, 300), (7, 1, 77), (1, 1, 1023), (4, 5, 129),
                                    (3, 1, 2000), (2, 2, 1500), (1, 1, 2047), (5, 1, 1025),
-                                   (3, 1, 4000), (2, 1, 3000), (1, 1, 4095), (3, 1, 2049)])
+                                   (3, 1, 4000), (2, 1, 3000), (1, 1, 4095), (3, 1, 2049),
+                                   (3, 1, 5000), (1, 1, 8191), (2, 1, 4097)])
 def test_chirpz_fused_pipeline_lengths(engine, shape):
     nx, ny, nt = shape
     time = synth.make_time(nt)
     cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()
     engine.set_time_axis(time)
-    assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else ("fb2-" if nt < 2048 else "fb4-"))
+    assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else ("fb2-" if nt < 2048 else "fb4-" if nt < 4096 else "fb8-"))
     chain = synth.default_chain(time)
     got = synth.run_gpu_pipeline(engine, cube, chain)
     ref = ob.run_pipeline(cube, time, chain)

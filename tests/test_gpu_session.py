@@ -136,6 +136,24 @@ def test_session_plot_copy_out(engine):
             sess.close()
 
 
+def test_session_tilted_4096_scan(engine):
+    """a tilted 4096-sample scan leaves the power-of-two lengths: nt_out = 4096 + 2 * steps goes
+    through the eight-run chirp-z kernels"""
+    nx, ny, nt = 2, 3, 4096
+    time, cube = synth.make_cube(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time, dx=2.0, dy=2.0)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        cfg = pkg.chain_cfg_default(time)
+        cfg.tilt_x_deg, cfg.tilt_y_deg = 3.0, 1.0
+        sess.recompute(cfg)
+        assert 4096 < sess.nt_out < 8192
+        assert engine.kernel_variant().startswith("fb8-")
+        check(sess, oracle_chain(cube, time, cfg, 2.0, 2.0), nx, ny)
+    finally:
+        sess.close()
+
+
 def test_session_download_bounds_and_missing_means(engine):
     time, cube = synth.make_cube(2, 2, 256)
     sess = pkg.Session(engine, 2, 2, time)

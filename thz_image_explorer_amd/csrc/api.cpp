@@ -130,7 +130,7 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     if (!build_plan(nt, H, ctx->allow_f))
         return fail(ctx, THZ_ERR_UNSUPPORTED,
                     "unsupported trace length " + std::to_string(nt) +
-                        " (powers of two 4..16384, or any length 2..4096)");
+                        " (powers of two 4..16384, or any length 2..8191)");
     const size_t n_tw = H.tw.size(), n_sp = H.tw_split.size(), n_ch = H.chirp_conj.size(),
                  n_bf = H.bfft.size();
     const size_t n_f1 = H.f_t1.size(), n_f2 = H.f_t2.size(), n_fw = H.f_w2n.size();
@@ -364,7 +364,8 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
     if (npix == 0) return THZ_OK;
     StageTimer t(ctx, THZ_STAGE_PIPELINE);
     if (ctx->plan_d.mode == kModePow2
-        || ((ctx->plan_d.family == kFamilyFB || ctx->plan_d.family == kFamilyFB2 || ctx->plan_d.family == kFamilyFB4)
+        || ((ctx->plan_d.family == kFamilyFB || ctx->plan_d.family == kFamilyFB2 || ctx->plan_d.family == kFamilyFB4
+             || ctx->plan_d.family == kFamilyFB8)
             && d_fft && d_amp && d_phase)) {  // chirp-z over the F core: one launch
         launch_pipeline(ctx->stream, ctx->plan_d, npix, d_raw, d_pre_win, d_fd_mask, d_post_win,
                         reinterpret_cast<c32 *>(d_fft), d_amp, d_phase, d_data_out, d_img);

@@ -974,4 +974,241 @@ __global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FBS: the same scheme for S core runs per transform (convolution length M = S * 2048), written
+// for S = 4 or 8 and used for S = 8 (4096 < nt < 8192; for S = 4 the hand-arranged k_fb4 above is
+// 20 % faster), as separate forward and inverse kernels: with that many
+// regions per wave there is no room to carry the pair's spectra from the one to the other, and the
+// inverse can read them where the forward kernel stored them (the masked spectrum rows in memory).
+//   first stage (decimation in frequency):  b_s[k] = (sum_{q < S/2} f[k + N q] W_S^(q s)) W_M^(s k)
+//                                           (f[m] = 0 for m >= nt, and nt <= N S / 2)
+//   last stage (decimation in time), where c is consumed:
+//                                           c[k + N q] = swap(sum_s W_S^(s q) W_M^(s k) D_s[k])
+// S = 4: two waves per block; S = 8: one (8 x 16.4 KB of LDS per wave), mask read from memory.
+template <class P, int S>
+struct FBSLayout {
+    static constexpr int kWaves = S == 4 ? 2 : 1;
+    static constexpr bool kMaskInLds = S == 4;
+    static constexpr int pad4(int v) { return (v + 3) & ~3; }
+    static size_t lds_bytes(int nf)
+    {
+        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * S * P::WAVE_ENTRIES) * sizeof(cx)
+               + (kMaskInLds ? (size_t)pad4(nf) * sizeof(float) : 0);
+    }
+};
+
+template <class P, int S>
+__device__ __forceinline__ void fbs_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
+                                                     cx (&r)[P::C1][P::R1])
+{
+    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
+    int fbase[2][C1];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
+    const unsigned bl = (unsigned)launder_v(S * C1 * lane + s);
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) {
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            const cx a = region[fbase[j1 & 1][c] + M1 * j1];
+            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(S * (M1 * j1 + c))));
+            r[c][j1] = cx{t.y, t.x};
+        }
+        if ((j1 & 3) == 3) THZ_SCHED_FENCE();
+    }
+}
+
+// c[m], m = k + N q, q < S/2
+template <class P, int S>
+__device__ __forceinline__ cx fbs_c(const cx *reg0, const cx *tw, int m)
+{
+    constexpr int N = P::N, RS = P::WAVE_ENTRIES;
+    const int k = m & (N - 1), q = m >> 11;
+    const int slot = nat(k);
+    cx z = reg0[slot];
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+        cx t = cx_mul(ld_off(tw, (unsigned)(s * k)), reg0[s * RS + slot]);
+        // W_S^(s q) = W_M^(N * ((s q) mod S)): a wave-uniform table entry
+        if (q) t = cx_mul(t, ld_off(tw, (unsigned)(N * ((s * q) & (S - 1)))));
+        z = z + t;
+    }
+    return cx{z.y, z.x};
+}
+
+template <class P, int S, int MODE>
+__global__ __launch_bounds__(S == 4 ? 128 : 64) void k_fbs(FB2Args B, FTables T)
+{
+    static_assert(MODE == kFwd || MODE == kInv, "forward and inverse are separate launches");
+    THZ_DYN_LDS(lds);
+    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1, RS = P::WAVE_ENTRIES;
+    static_assert(N == 2048, "regions of 2048");
+    constexpr bool kMaskInLds = FBSLayout<P, S>::kMaskInLds;
+    const FBArgs &A = B.a;
+    const int L = A.nt, nf = A.nf;
+    const int lane = lane_id();
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + P::T1_ENTRIES;
+    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * S * RS;
+    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * S * RS);
+    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    if (MODE == kFwd && kMaskInLds)
+        for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    __syncthreads();
+
+    FAddr<P> ad;
+    ad.init(lane);
+    const float fnt = (float)L;
+    const int half = L / 2;
+    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
+    const size_t n_pairs = (A.npix + 1) / 2;
+    const size_t stride = (size_t)gridDim.x * wpb;
+
+    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
+        const size_t p = 2 * q;
+        const bool has2 = p + 1 < A.npix;  // wave-uniform
+        ad.refresh();
+        const cx *wl = launder_uniform(A.w);
+        const cx *bf = launder_uniform(A.bf);
+        const cx *tw = launder_uniform(B.tw);
+        const float *mask_l = kMaskInLds ? launder_uniform((const float *)mask_s) : launder_uniform(A.mask);
+        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
+        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
+        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
+
+        // the sequence that is transformed: a[m] = (x1 + i x2)[m] pre[m] w[m] going forward,
+        // u[m] = conj(Y1full + i Y2full)[m] w[m] going back (spectra read from memory); 0 from nt on
+        auto f_at = [&](int m) -> cx {
+            const int mm = m < L ? m : L - 1;
+            cx v;
+            if constexpr (MODE == kFwd) {
+                const float *x1 = A.in + p * (size_t)L;
+                const float pw = pre_g ? ld_off(pre_g, (unsigned)mm) : 1.0f;
+                const float xa = ld_off(x1, (unsigned)mm);
+                const float xb = has2 ? ld_off(x1, (unsigned)(L + mm)) : 0.0f;
+                v = cx_mul(cx{xa * pw, xb * pw}, ld_off(wl, (unsigned)mm));
+            } else {
+                const cx *f1 = A.fft_in + p * (size_t)nf;
+                const bool low = mm <= half;
+                const int kk = low ? mm : L - mm;
+                cx y1 = ld_off(f1, (unsigned)kk);
+                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + kk)) : cx{0.0f, 0.0f};
+                if (kk == 0 || ((L & 1) == 0 && kk == nf - 1)) {  // realfft's C2R ignores these
+                    y1.y = 0.0f;
+                    y2.y = 0.0f;
+                }
+                const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
+                v = cx_mul(gc, ld_off(wl, (unsigned)mm));
+            }
+            return m < L ? v : cx{0.0f, 0.0f};
+        };
+
+        cx r[C1][R1];
+        // ---- first stage + S core runs
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            constexpr int H = R1 / 4;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int k = M1 * (H * h + j) + lbh + c;
+                        cx v = f_at(k);
+#pragma unroll
+                        for (int qq = 1; qq < S / 2; ++qq) {
+                            cx t = f_at(k + N * qq);
+                            if (s) t = cx_mul(t, ld_off(tw, (unsigned)(N * ((qq * s) & (S - 1)))));
+                            v = v + t;
+                        }
+                        if (s) v = cx_mul(v, ld_off(tw, (unsigned)(s * k)));
+                        r[c][H * h + j] = v;
+                    }
+                }
+                THZ_SCHED_FENCE();
+            }
+            f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+            f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+        }
+        // ---- multiply by FFT_M(b)/M and S inverse core runs, region by region
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            fbs_multiply_swapped<P, S>(reg0 + s * RS, bf, s, lane, r);
+            wave_sync();
+            f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
+            f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
+        }
+
+        if constexpr (MODE == kFwd) {
+            // ---- spectrum epilogue
+            FBUnwrap u1, u2;
+            const int n_groups = (nf + 255) / 256;
+#pragma unroll 1
+            for (int g = 0; g < n_groups; ++g) {
+                const int k0 = 256 * g + lb4;
+                cx X1[4], X2[4];
+                float m[4];
+                bool ok[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k0 + c;
+                    ok[c] = k < nf;
+                    const int kc = ok[c] ? k : nf - 1;
+                    const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
+                    const cx wk = ld_off(wl, (unsigned)kc);
+                    const cx Fk = cx_mul(fbs_c<P, S>(reg0, tw, kc), wk);
+                    const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
+                    const cx Fm = cx_mul(fbs_c<P, S>(reg0, tw, km), wm);
+                    X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
+                    X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
+                    m[c] = kMaskInLds ? mask_l[kc] : ld_off(mask_l, (unsigned)kc);
+                    if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
+                        X1[c].y = 0.0f;
+                        X2[c].y = 0.0f;
+                    }
+                }
+                const size_t o1 = p * (size_t)nf + k0;
+                fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                               A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
+                if (has2)
+                    fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
+                                   A.amp_out ? A.amp_out + o1 + nf : nullptr, A.ph_out ? A.ph_out + o1 + nf : nullptr);
+            }
+        } else {
+            // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
+            float *o1 = A.data_out + p * (size_t)L;
+            float acc1 = 0.0f, acc2 = 0.0f;
+#pragma unroll 2
+            for (int n = lb1; n < L; n += kWave) {
+                const cx U = cx_mul(fbs_c<P, S>(reg0, tw, n), ld_off(wl, (unsigned)n));
+                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
+                const float v1 = (U.x / fnt) * pw;
+                o1[n] = v1;
+                acc1 += v1 * v1;
+                if (has2) {
+                    const float v2 = (-U.y / fnt) * pw;
+                    o1[L + n] = v2;
+                    acc2 += v2 * v2;
+                }
+            }
+            if (A.img) {
+                acc1 = wave_reduce_add(acc1);
+                acc2 = wave_reduce_add(acc2);
+                if (lane == 0) {
+                    A.img[p] = acc1;
+                    if (has2) A.img[p + 1] = acc2;
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 }  // namespace thz

@@ -36,7 +36,7 @@ struct PlanDev {
     const float *ones; // nf floats of 1.0 (stand-in mask)
 };
 
-enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)
+enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4, kFamilyFB8 = 5 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)
 
 // one band of the batched Richardson–Lucy solve (offsets in floats into one workspace)
 struct RlBand {

@@ -72,7 +72,9 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
         N = nt / 2;
         P.variant = "g-stockham-lds-r4r2";
     } else {
-        if (nt > 4096) return false;
+        // chirp-z: the G kernels hold 2 M entries per wave in LDS (nt <= 4096); above that only the
+        // FBS kernels (eight F-core runs per transform) exist, up to nt = 8191
+        if (nt > (allow_f ? 8191u : 4096u)) return false;
         P.mode = kModeBluestein;
         N = 1;
         while (N < 2 * nt - 1) N <<= 1;
@@ -85,7 +87,10 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
     P.buf_entries = (int)(((N > (size_t)P.nf ? N : (size_t)P.nf) + 1) & ~(size_t)1);
     P.lds_per_wave = 2 * P.buf_entries * (int)sizeof(c32);
     int wpb = (int)(kLdsBytesPerCU / (size_t)P.lds_per_wave);
-    if (wpb < 1) return false;
+    if (wpb < 1) {
+        if (!(allow_f && P.mode == kModeBluestein && N == 16384)) return false;
+        wpb = 1;  // no G kernel can run this plan; every entry point goes through k_fbs<8>
+    }
     if (wpb > 4) wpb = 4;
     P.waves_per_block = wpb;
 
@@ -131,13 +136,14 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
     // F core of complex length Nc: the half-length transform of a power-of-two trace (family F), or
     // the length-M convolution transform of a chirp-z length with M <= 2048 (family FB)
     // ... or two core runs per length-4096 convolution (family FB2, 1024 < nt < 2048)
+    const bool fb8 = allow_f && P.mode == kModeBluestein && N == 16384 && f_factors(N / 4, r1, r2, r3);
     const bool fb4 = allow_f && P.mode == kModeBluestein && N == 8192 && f_factors(N / 2, r1, r2, r3);
     const bool fb2 = allow_f && P.mode == kModeBluestein && N == 4096 && f_factors(N, r1, r2, r3);
     const bool fb = !fb2 && allow_f && P.mode == kModeBluestein && f_factors(2 * N, r1, r2, r3);
-    if (fb || fb2 || fb4 || (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3))) {
-        P.family = fb4 ? kFamilyFB4 : fb2 ? kFamilyFB2 : (fb ? kFamilyFB : kFamilyF);
-        P.variant = fb4 ? "fb4-bluestein-regs-3pass-lds-xor" : fb2 ? "fb2-bluestein-regs-3pass-lds-xor" : (fb ? "fb-bluestein-regs-3pass-lds-xor" : "f-regs-3pass-lds-xor");
-        const size_t Nc = fb4 ? N / 4 : fb2 ? N / 2 : (fb ? N : nt / 2), m1 = (size_t)r2 * r3;
+    if (fb || fb2 || fb4 || fb8 || (allow_f && P.mode == kModePow2 && f_factors(nt, r1, r2, r3))) {
+        P.family = fb8 ? kFamilyFB8 : fb4 ? kFamilyFB4 : fb2 ? kFamilyFB2 : (fb ? kFamilyFB : kFamilyF);
+        P.variant = fb8 ? "fb8-bluestein-regs-3pass-lds-xor" : fb4 ? "fb4-bluestein-regs-3pass-lds-xor" : fb2 ? "fb2-bluestein-regs-3pass-lds-xor" : (fb ? "fb-bluestein-regs-3pass-lds-xor" : "f-regs-3pass-lds-xor");
+        const size_t Nc = fb8 ? N / 8 : fb4 ? N / 4 : fb2 ? N / 2 : (fb ? N : nt / 2), m1 = (size_t)r2 * r3;
         P.f_t1.resize((size_t)r1 * m1);
         for (int k1 = 0; k1 < r1; ++k1)
             for (size_t m = 0; m < m1; ++m) {
@@ -178,7 +184,7 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     D.bfft = bfft;
     D.family = kFamilyG;
     if (H.family == kFamilyF && f_t1 && f_t2 && f_w2n && ones) D.family = kFamilyF;
-    if ((H.family == kFamilyFB || H.family == kFamilyFB2 || H.family == kFamilyFB4) && f_t1 && f_t2 && ones
+    if ((H.family == kFamilyFB || H.family == kFamilyFB2 || H.family == kFamilyFB4 || H.family == kFamilyFB8) && f_t1 && f_t2 && ones
         && chirp_conj && bfft)
         D.family = H.family;
     D.ones = ones;
