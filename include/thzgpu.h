@@ -94,12 +94,14 @@ int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes);
  * Replaces RealFftPlanner::plan_fft_forward/inverse + the frequency-axis rule
  * at io.rs:614-621, data_thread.rs:1194-1207, tilt_compensation.rs:206-217:
  * frequency[i] = i / (time[nt-1] - time[0]), i = 0..nt/2.
- * Supported nt: powers of two 4..8192 (Stockham path) and any other
- * 2 <= nt <= 4096 (Bluestein path over the same kernels). */
+ * Supported nt: powers of two 4..16384 and any other length 2..8191 (chirp-z;
+ * with the G kernels forced — thz_set_kernel_family(1) — any other 2..4096). */
 int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
 /* Kernel family selection: 0 = automatic (register-resident three-pass "F"
- * kernels for nt = 1024/2048/4096, LDS Stockham / Bluestein "G" kernels
- * otherwise), 1 = G kernels for every length (A/B measurements, tests).
+ * kernels for nt = 1024/2048/4096, chirp-z over the same core — "FB" kernels —
+ * for the lengths that are not a power of two, LDS Stockham "G" kernels for the
+ * remaining powers of two), 1 = G kernels (Stockham / Bluestein in LDS) for
+ * every length (A/B measurements, tests).
  * Re-plans if a time axis is already set. */
 int thz_set_kernel_family(thz_ctx *ctx, int family);
 size_t thz_nt(const thz_ctx *ctx);
