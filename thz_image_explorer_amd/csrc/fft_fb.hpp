@@ -1211,4 +1211,294 @@ __global__ __launch_bounds__(S == 4 ? 128 : 64) void k_fbs(FB2Args B, FTables T)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FBC: the S-region scheme with S waves per pair of traces.  In k_fb2 / k_fb4 / k_fbs one wave
+// owns all S regions of its pair, so LDS (8 regions per CU) caps a CU at 8 / S waves.  The S
+// sub-transforms of a stage are independent, though: here wave s of a pair runs sub-transform s in
+// region s, and the block (8 waves = 8 / S pairs) meets at a barrier where the stages meet — after
+// the inverse core runs, before the on-demand last stage reads all S regions.  The epilogue is
+// split by bin groups (two groups per wave); the unwrap's running sum crosses waves as per-group
+// totals published in LDS and re-added in group order, so every value is the one the single-wave
+// kernels produce.  Forward and inverse are separate kernels (the inverse reads the masked spectra
+// from memory), mask read from memory.
+template <class P, int S>
+struct FBCLayout {
+    static constexpr int kWaves = 8, kPairs = 8 / S;
+    static constexpr int kXch = 2 * kPairs * (2 * 16 + 2 * S);  // floats: group totals [pair][spectrum][16], image partials
+    static size_t lds_bytes()
+    {
+        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * P::WAVE_ENTRIES) * sizeof(cx) + (size_t)kXch * sizeof(float);
+    }
+};
+
+template <class P, int S, int MODE>
+__global__ __launch_bounds__(512) void k_fbc(FB2Args B, FTables T)
+{
+    static_assert(MODE == kFwd || MODE == kInv, "forward and inverse are separate launches");
+    THZ_DYN_LDS(lds);
+    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1, RS = P::WAVE_ENTRIES;
+    static_assert(N == 2048, "regions of 2048");
+    constexpr int PAIRS = FBCLayout<P, S>::kPairs;
+    const FBArgs &A = B.a;
+    const int L = A.nt, nf = A.nf;
+    const int lane = lane_id();
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    const int pi = wib / S, s = wib % S;  // pair slot in the block, sub-transform of this wave
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + P::T1_ENTRIES;
+    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)pi * S * RS;  // the pair's regions
+    cx *my_reg = reg0 + s * RS;
+    float *xch = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)8 * RS);
+    float *tot = xch + pi * 32;                               // [spectrum][group] totals of the pair
+    float *imgp = xch + PAIRS * 32 + pi * 2 * S;              // [spectrum][wave] image partial sums
+    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    __syncthreads();
+
+    FAddr<P> ad;
+    ad.init(lane);
+    const float fnt = (float)L;
+    const int half = L / 2;
+    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
+    const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
+    const size_t n_pairs = (A.npix + 1) / 2;
+    const size_t per_round = (size_t)gridDim.x * PAIRS;
+    const size_t rounds = (n_pairs + per_round - 1) / per_round;  // block-uniform trip count: barriers inside
+
+    for (size_t it = 0; it < rounds; ++it) {
+        const size_t q = (it * gridDim.x + blockIdx.x) * PAIRS + pi;
+        const bool valid = q < n_pairs;  // wave-uniform
+        const size_t p = 2 * q;
+        const bool has2 = valid && p + 1 < A.npix;
+        ad.refresh();
+        const cx *wl = launder_uniform(A.w);
+        const cx *bf = launder_uniform(A.bf);
+        const cx *tw = launder_uniform(B.tw);
+        const float *mask_g = launder_uniform(A.mask);
+        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
+        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
+        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
+
+        auto f_at = [&](int m) -> cx {
+            const int mm = m < L ? m : L - 1;
+            cx v;
+            if constexpr (MODE == kFwd) {
+                const float *x1 = A.in + p * (size_t)L;
+                const float pw = pre_g ? ld_off(pre_g, (unsigned)mm) : 1.0f;
+                const float xa = ld_off(x1, (unsigned)mm);
+                const float xb = has2 ? ld_off(x1, (unsigned)(L + mm)) : 0.0f;
+                v = cx_mul(cx{xa * pw, xb * pw}, ld_off(wl, (unsigned)mm));
+            } else {
+                const cx *f1 = A.fft_in + p * (size_t)nf;
+                const bool low = mm <= half;
+                const int kk = low ? mm : L - mm;
+                cx y1 = ld_off(f1, (unsigned)kk);
+                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + kk)) : cx{0.0f, 0.0f};
+                if (kk == 0 || ((L & 1) == 0 && kk == nf - 1)) {  // realfft's C2R ignores these
+                    y1.y = 0.0f;
+                    y2.y = 0.0f;
+                }
+                const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
+                v = cx_mul(gc, ld_off(wl, (unsigned)mm));
+            }
+            return m < L ? v : cx{0.0f, 0.0f};
+        };
+
+        if (valid) {
+            cx r[C1][R1];
+            // ---- first stage of sub-transform s, its core run, the multiply, the inverse core run:
+            // all inside region s, no other wave involved
+            constexpr int H = R1 / 4;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) {
+                        const int k = M1 * (H * h + j) + lbh + c;
+                        cx v = f_at(k);
+#pragma unroll
+                        for (int qq = 1; qq < S / 2; ++qq) {
+                            cx t = f_at(k + N * qq);
+                            if (s) t = cx_mul(t, ld_off(tw, (unsigned)(N * ((qq * s) & (S - 1)))));
+                            v = v + t;
+                        }
+                        if (s) v = cx_mul(v, ld_off(tw, (unsigned)(s * k)));
+                        r[c][H * h + j] = v;
+                    }
+                }
+                THZ_SCHED_FENCE();
+            }
+            f_core_pass1<P>(r, my_reg, t1, ad, lane);
+            f_core_pass23<P>(my_reg, t2, ad, lane);
+            fbs_multiply_swapped<P, S>(my_reg, bf, s, lane, r);
+            wave_sync();
+            f_core_pass1<P>(r, my_reg, t1, ad, lane);
+            f_core_pass23<P>(my_reg, t2, ad, lane);
+        }
+        __syncthreads();  // D_0 .. D_{S-1} of every pair are complete
+
+        if constexpr (MODE == kFwd) {
+            // ---- spectrum epilogue, two groups of 256 bins per wave: groups 2 s and 2 s + 1
+            const int n_groups = (nf + 255) / 256;
+            cx X1[2][4], X2[2][4];
+            float mk[2][4], sr1[2][4], sr2[2][4], ex1[2], ex2[2];
+            float first1 = 0.0f, first2 = 0.0f;
+            auto spectra_at = [&](int kc, cx &x1v, cx &x2v) {
+                const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
+                const cx wk = ld_off(wl, (unsigned)kc);
+                const cx Fk = cx_mul(fbs_c<P, S>(reg0, tw, kc), wk);
+                const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
+                const cx Fm = cx_mul(fbs_c<P, S>(reg0, tw, km), wm);
+                x1v = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
+                x2v = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
+                if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
+                    x1v.y = 0.0f;
+                    x2v.y = 0.0f;
+                }
+            };
+            if (valid) {
+                {   // raw phase of bin 0 (every wave needs it; cheaper to evaluate than to pass around)
+                    cx a0, b0;
+                    spectra_at(0, a0, b0);
+                    first1 = fast_atan2f(a0.y, a0.x);
+                    first2 = fast_atan2f(b0.y, b0.x);
+                }
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * s + gg;
+                    if (g < n_groups) {
+                        const int k0 = 256 * g + lb4;
+                        float ph1[4], ph2[4];
+                        bool ok[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int k = k0 + c;
+                            ok[c] = k < nf;
+                            const int kc = ok[c] ? k : nf - 1;
+                            spectra_at(kc, X1[gg][c], X2[gg][c]);
+                            mk[gg][c] = ld_off(mask_g, (unsigned)kc);
+                            ph1[c] = fast_atan2f(X1[gg][c].y, X1[gg][c].x);
+                            ph2[c] = fast_atan2f(X2[gg][c].y, X2[gg][c].x);
+                        }
+                        // raw phase of the bin before this group (lane 0 only uses it): the last bin of
+                        // the previous group, evaluated here so that the differences need no other wave
+                        float pt1 = 0.0f, pt2 = 0.0f;
+                        if (g > 0) {
+                            cx a0, b0;
+                            spectra_at(256 * g - 1, a0, b0);
+                            pt1 = fast_atan2f(a0.y, a0.x);
+                            pt2 = fast_atan2f(b0.y, b0.x);
+                        }
+                        float prev1 = wave_shr1(ph1[3]), prev2 = wave_shr1(ph2[3]);
+                        if (lane == 0) { prev1 = pt1; prev2 = pt2; }
+                        float run1 = 0.0f, run2 = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float d1 = ph1[c] - (c == 0 ? prev1 : ph1[c - 1]);
+                            float d2 = ph2[c] - (c == 0 ? prev2 : ph2[c - 1]);
+                            d1 += (d1 > kPi) ? -kTwoPi : ((d1 < -kPi) ? kTwoPi : 0.0f);
+                            d2 += (d2 > kPi) ? -kTwoPi : ((d2 < -kPi) ? kTwoPi : 0.0f);
+                            if ((g == 0 && c == 0 && lane == 0) || !ok[c]) { d1 = 0.0f; d2 = 0.0f; }
+                            run1 += d1; run2 += d2;
+                            sr1[gg][c] = run1; sr2[gg][c] = run2;
+                        }
+                        const float incl1 = wave_scan_add(run1), incl2 = wave_scan_add(run2);
+                        ex1[gg] = wave_shr1(incl1);
+                        ex2[gg] = wave_shr1(incl2);
+                        if (lane == kWave - 1) {
+                            tot[g] = incl1;
+                            tot[16 + g] = incl2;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // the pair's group totals are published
+            if (valid) {
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * s + gg;
+                    if (g < n_groups) {
+                        float carry1 = 0.0f, carry2 = 0.0f;  // the single-wave kernels' carry += total, group by group
+                        for (int gp = 0; gp < g; ++gp) {
+                            carry1 += tot[gp];
+                            carry2 += tot[16 + gp];
+                        }
+                        const int k0 = 256 * g + lb4;
+                        const size_t o1 = p * (size_t)nf + k0;
+                        const float base1 = carry1 + ex1[gg], base2 = carry2 + ex2[gg];
+                        auto put = [&](const cx(&X)[4], const float(&sr)[4], float first, float base, size_t o) {
+                            const float(&m)[4] = mk[gg];
+                            float am[4], py[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                am[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+                                py[c] = first + (base + sr[c]);
+                            }
+                            if (k0 + 3 < nf) {
+                                if (A.fft_out) {
+                                    float *f = reinterpret_cast<float *>(A.fft_out + o);
+                                    store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
+                                    store_f4(f + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+                                }
+                                if (A.amp_out) store_f4(A.amp_out + o, am[0], am[1], am[2], am[3]);
+                                if (A.ph_out) store_f4(A.ph_out + o, py[0], py[1], py[2], py[3]);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (k0 + c < nf) {
+                                        if (A.fft_out) A.fft_out[o + c] = cx{X[c].x * m[c], X[c].y * m[c]};
+                                        if (A.amp_out) A.amp_out[o + c] = am[c];
+                                        if (A.ph_out) A.ph_out[o + c] = py[c];
+                                    }
+                            }
+                        };
+                        put(X1[gg], sr1[gg], first1, base1, o1);
+                        if (has2) put(X2[gg], sr2[gg], first2, base2, o1 + nf);
+                    }
+                }
+            }
+        } else {
+            // ---- U[n] = w[n] c'[n] over this wave's share of the samples; image partial sums meet in LDS
+            float acc1 = 0.0f, acc2 = 0.0f;
+            if (valid) {
+                const int chunk = (((L + S - 1) / S + kWave - 1) / kWave) * kWave;
+                const int n_end = (s + 1) * chunk < L ? (s + 1) * chunk : L;
+                float *o1 = A.data_out + p * (size_t)L;
+#pragma unroll 2
+                for (int n = s * chunk + lb1; n < n_end; n += kWave) {
+                    const cx U = cx_mul(fbs_c<P, S>(reg0, tw, n), ld_off(wl, (unsigned)n));
+                    const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
+                    const float v1 = (U.x / fnt) * pw;
+                    o1[n] = v1;
+                    acc1 += v1 * v1;
+                    if (has2) {
+                        const float v2 = (-U.y / fnt) * pw;
+                        o1[L + n] = v2;
+                        acc2 += v2 * v2;
+                    }
+                }
+                acc1 = wave_reduce_add(acc1);
+                acc2 = wave_reduce_add(acc2);
+                if (lane == 0) {
+                    imgp[s] = acc1;
+                    imgp[S + s] = acc2;
+                }
+            }
+            __syncthreads();
+            if (valid && A.img && s == 0 && lane == 0) {
+                float a1 = 0.0f, a2 = 0.0f;
+                for (int w = 0; w < S; ++w) {
+                    a1 += imgp[w];
+                    a2 += imgp[S + w];
+                }
+                A.img[p] = a1;
+                if (has2) A.img[p + 1] = a2;
+            }
+        }
+        __syncthreads();  // regions and exchange slots are reused by the next round
+    }
+}
+
 }  // namespace thz

@@ -1231,6 +1231,46 @@ static void dispatch_fbx(hipStream_t st, const PlanDev &P, FB2Args &B)
     }
 }
 
+// FBC: S waves per pair (fft_fb.hpp), forward and inverse as separate kernels; the default for
+// 1024 < nt < 8192 lengths that are not a power of two.  THZ_FB_SOLO=1 (developer knob) selects the
+// one-wave-per-pair kernels instead.
+static bool fb_solo()
+{
+    static const bool solo = getenv("THZ_FB_SOLO") != nullptr;
+    return solo;
+}
+
+template <int S, int MODE>
+static void launch_fbc(hipStream_t st, const PlanDev &P, FB2Args &B)
+{
+    FBArgs &A = B.a;
+    A.nt = P.nt;
+    A.nf = P.nf;
+    A.w = reinterpret_cast<const cx *>(P.chirp_conj);
+    A.bf = reinterpret_cast<const cx *>(P.bfft);
+    B.tw = reinterpret_cast<const cx *>(P.tw);
+    using PL = FPlan4096;
+    using LY = FBCLayout<PL, S>;
+    const size_t lds = LY::lds_bytes();
+    const size_t n_pairs = (A.npix + 1) / 2;
+    size_t g = (n_pairs + LY::kPairs - 1) / LY::kPairs;
+    if (g > (size_t)kNumCU) g = kNumCU;
+    if (g < 1) g = 1;
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
+    allow_dynamic_lds(k_fbc<PL, S, MODE>, lds);
+    THZ_LAUNCH((k_fbc<PL, S, MODE>), (unsigned)g, 512, lds, st, B, T);
+}
+
+template <int MODE>
+static void dispatch_fbc(hipStream_t st, const PlanDev &P, FB2Args &B)
+{
+    switch (P.family) {
+    case kFamilyFB2: launch_fbc<2, MODE>(st, P, B); break;
+    case kFamilyFB4: launch_fbc<4, MODE>(st, P, B); break;
+    default: launch_fbc<8, MODE>(st, P, B); break;
+    }
+}
+
 // FBS: S = 4 / 8 core runs per transform, forward and inverse as separate kernels
 template <int S, int MODE>
 static void launch_fbs(hipStream_t st, const PlanDev &P, FB2Args &B)
@@ -1268,6 +1308,21 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
         return;
     }
     // FB kernels (chirp-z lengths): same split — the windowed-trace output is its own launch
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && !fb_solo()) {
+        if (data_out && wa) {
+            launch_td_window(st, npix, P.nt, in, wa, data_out);
+            if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
+            launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+            return;
+        }
+        if (!wb && !data_out) {
+            FB2Args B{};
+            B.a.npix = npix; B.a.in = in; B.a.pre_win = wa; B.a.mask = mask ? mask : P.ones;
+            B.a.fft_out = reinterpret_cast<cx *>(fft_out); B.a.amp_out = amp_out; B.a.ph_out = ph_out;
+            dispatch_fbc<kFwd>(st, P, B);
+            return;
+        }
+    }
     if (P.family == kFamilyFB8) {  // the only kernels that exist for 4096 < nt < 8192
         if (data_out && wa) {
             launch_td_window(st, npix, P.nt, in, wa, data_out);
@@ -1339,6 +1394,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         dispatch_fb<kInv>(st, P, A);
         return;
     }
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && !fb_solo()) {
+        FB2Args B{};
+        B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
+        B.a.data_out = out; B.a.img = img;
+        dispatch_fbc<kInv>(st, P, B);
+        return;
+    }
     if (P.family == kFamilyFB8) {
         FB2Args B{};
         B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
@@ -1364,7 +1426,8 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img)
 {
-    if ((P.family == kFamilyFB4 || P.family == kFamilyFB8) && fft_out && data_out) {
+    if ((P.family == kFamilyFB4 || P.family == kFamilyFB8 || (P.family == kFamilyFB2 && !fb_solo())) && fft_out
+        && data_out) {
         // four regions per wave leave no room to carry the pair's spectra through one kernel without
         // spilling: forward and inverse as two launches are faster here (6.4 + 8.1 ms vs 17.7 ms fused
         // for 65 536 traces of 4000 samples); the spectrum round trip through HBM is noise next to
