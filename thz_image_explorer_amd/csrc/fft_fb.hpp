@@ -368,635 +368,24 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
 }
 
 // ---------------------------------------------------------------------------------------------
-// FB2: chirp-z lengths 1024 < nt < 2048.  The convolution length M = 4096 is twice the largest
-// complex size of the F core, so each M-point transform is two N = 2048 core runs plus one radix-2
-// stage, arranged so that no reordering pass is needed:
-//   forward  : decimation in frequency — the first stage needs a[k + N], which is zero (nt <= N):
-//              b_0[k] = a[k], b_1[k] = a[k] W_M^k; two core runs leave A[2j + s] in region s
-//   multiply : by FFT_M(b)[2j + s] / M, in place, swapped (inverse through the forward passes)
-//   inverse  : decimation in time — two core runs on the regions as they are, and the last stage
-//              c[k] = swap(D_0[k] + W_M^k D_1[k]) is evaluated where c is consumed (only k < nt
-//              is ever needed, i.e. only the first of its two outputs).
-// Two traces per convolution as in k_fb.  A wave owns two regions of N + 2 entries (32.8 KB):
-// four waves per block.  The masked spectra of the pair are kept in registers until every lane has
-// finished reading the regions, then parked in region 1 for the inverse.
-template <class P>
-struct FB2Layout {
-    static constexpr int kWaves = 4;
-    static constexpr int pad4(int v) { return (v + 3) & ~3; }
-    static size_t lds_bytes(int nf)
-    {
-        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * 2 * P::WAVE_ENTRIES) * sizeof(cx)
-               + (size_t)pad4(nf) * sizeof(float);
-    }
-};
-
+// Lengths 1024 < nt < 8192 that are not a power of two: the convolution length M = S * 2048 is
+// S = 2, 4 or 8 times the largest complex size of the F core, so each M-point transform is S core
+// runs plus one radix-S stage, arranged so that no reordering pass is needed:
+//   forward  : decimation in frequency.  First stage, straight from the loads:
+//                b_s[k] = (sum_{q < S/2} f[k + N q] W_S^(q s)) W_M^(s k)
+//              (f[m] = 0 for m >= nt and nt <= N S / 2: for S = 2 simply b_0 = f, b_1 = f W_M^k);
+//              S core runs leave A[S j + s] in region s
+//   multiply : by FFT_M(b)[S j + s] / M, in place, swapped (inverse through the forward passes)
+//   inverse  : decimation in time: S core runs on the regions as they are; the last stage
+//                c[k + N q] = swap(sum_s W_S^(s q) W_M^(s k) D_s[k])
+//              is evaluated where c is consumed (only indices < nt are ever needed).
+// Two traces per convolution as in k_fb.
 struct FB2Args {
     FBArgs a;       // same fields as the single-core kernel (w: nt, bf: M)
     const cx *tw;   // W_M^m, m < M
 };
 
-// r[c][j1] <- swap(region[nat(n)] * bf[2 n + s]), n in the core's input layout
-template <class P>
-__device__ __forceinline__ void fb2_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
-                                                     cx (&r)[P::C1][P::R1])
-{
-    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    int fbase[2][C1];
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-#pragma unroll
-        for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
-    const unsigned bl = (unsigned)launder_v(2 * C1 * lane + s);
-#pragma unroll
-    for (int j1 = 0; j1 < R1; ++j1) {
-#pragma unroll
-        for (int c = 0; c < C1; ++c) {
-            const cx a = region[fbase[j1 & 1][c] + M1 * j1];
-            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(2 * (M1 * j1 + c))));
-            r[c][j1] = cx{t.y, t.x};
-        }
-        if ((j1 & 3) == 3) THZ_SCHED_FENCE();
-    }
-}
-
-// c[m] = swap(D_0[m] + W_M^m D_1[m]) for one index (the radix-2 stage of the inverse, on demand)
-__device__ __forceinline__ cx fb2_c(const cx *r0, const cx *r1, const cx *tw, int m)
-{
-    const cx d0 = r0[nat(m)], d1 = r1[nat(m)];
-    const cx z = d0 + cx_mul(ld_off(tw, (unsigned)m), d1);
-    return cx{z.y, z.x};
-}
-
-template <class P, int MODE>
-__global__ __launch_bounds__(256) void k_fb2(FB2Args B, FTables T)
-{
-    THZ_DYN_LDS(lds);
-    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    static_assert(P::N == 2048, "two regions of 2048: convolution length 4096");
-    constexpr int NG = 4;  // epilogue groups of 256 bins: nf <= 1024
-    const FBArgs &A = B.a;
-    const int L = A.nt, nf = A.nf;
-    const int lane = lane_id();
-    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
-    const int wpb = (int)(blockDim.x >> 6);
-    cx *t1 = reinterpret_cast<cx *>(lds);
-    cx *t2 = t1 + P::T1_ENTRIES;
-    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * 2 * P::WAVE_ENTRIES;
-    cx *reg1 = reg0 + P::WAVE_ENTRIES;
-    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * 2 * P::WAVE_ENTRIES);
-    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
-    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
-    for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
-    __syncthreads();
-
-    FAddr<P> ad;
-    ad.init(lane);
-    const float fnt = (float)L;
-    const int half = L / 2;
-    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
-    const size_t n_pairs = (A.npix + 1) / 2;
-    const size_t stride = (size_t)gridDim.x * wpb;
-
-    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
-        const size_t p = 2 * q;
-        const bool has2 = p + 1 < A.npix;  // wave-uniform
-        cx r[C1][R1];
-        ad.refresh();
-        const cx *wl = launder_uniform(A.w);
-        const cx *bf = launder_uniform(A.bf);
-        const cx *tw = launder_uniform(B.tw);
-        const float *mask_l = launder_uniform((const float *)mask_s);
-        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
-        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
-        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
-
-        if constexpr (MODE != kInv) {
-        // ---- forward, first stage: b_s[n] = a[n] W_M^(s n), a[n] = (x1 + i x2)[n] pre[n] w[n]
-        {
-            const float *x1 = A.in + p * (size_t)L;
-            const float *x2 = has2 ? x1 + L : x1;
-#pragma unroll 1
-            for (int s = 0; s < 2; ++s) {
-                constexpr int H = R1 / 4;  // quarter batches: 8 registers per element in flight
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    float xa[C1][H], xb[C1][H], pw[C1][H];
-                    cx wv[C1][H], tv[C1][H];
-                    const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
-#pragma unroll
-                    for (int j = 0; j < H; ++j) {
-#pragma unroll
-                        for (int c = 0; c < C1; ++c) {
-                            const int n = M1 * (H * h + j) + lbh + c;
-                            const unsigned nn = (unsigned)(n < L ? n : L - 1);
-                            xa[c][j] = ld_off(x1, nn);
-                            xb[c][j] = ld_off(x2, nn);
-                            wv[c][j] = ld_off(wl, nn);
-                            pw[c][j] = pre_g ? ld_off(pre_g, nn) : 1.0f;
-                            tv[c][j] = s ? ld_off(tw, nn) : cx{1.0f, 0.0f};
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < H; ++j) {
-#pragma unroll
-                        for (int c = 0; c < C1; ++c) {
-                            const int n = M1 * (H * h + j) + lbh + c;
-                            const float pwv = n < L ? pw[c][j] : 0.0f;
-                            const cx z = cx{xa[c][j] * pwv, has2 ? xb[c][j] * pwv : 0.0f};
-                            cx v = cx_mul(z, wv[c][j]);
-                            if (s) v = cx_mul(v, tv[c][j]);
-                            r[c][H * h + j] = v;
-                        }
-                    }
-                    THZ_SCHED_FENCE();
-                }
-                cx *reg = s ? reg1 : reg0;
-                f_core_pass1<P>(r, reg, t1, ad, lane);
-                f_core_pass23<P>(reg, t2, ad, lane);
-            }
-        }
-        // ---- multiply by FFT_M(b)/M and inverse core runs, region by region
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            cx *reg = s ? reg1 : reg0;
-            fb2_multiply_swapped<P>(reg, bf, s, lane, r);
-            wave_sync();
-            f_core_pass1<P>(r, reg, t1, ad, lane);
-            f_core_pass23<P>(reg, t2, ad, lane);
-        }
-
-        // ---- spectrum epilogue; the pair's masked spectra wait in registers
-        cx Y1[NG][4], Y2[NG][4];
-        {
-            FBUnwrap u1, u2;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (256 * g < nf) {  // wave-uniform
-                    const int k0 = 256 * g + lb4;
-                    cx X1[4], X2[4];
-                    float m[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int k = k0 + c;
-                        ok[c] = k < nf;
-                        const int kc = ok[c] ? k : nf - 1;
-                        const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
-                        const cx wk = ld_off(wl, (unsigned)kc);
-                        const cx Fk = cx_mul(fb2_c(reg0, reg1, tw, kc), wk);
-                        const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
-                        const cx Fm = cx_mul(fb2_c(reg0, reg1, tw, km), wm);
-                        X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
-                        X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
-                        m[c] = mask_l[kc];
-                        if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
-                            X1[c].y = 0.0f;
-                            X2[c].y = 0.0f;
-                        }
-                        Y1[g][c] = cx{X1[c].x * m[c], X1[c].y * m[c]};
-                        Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
-                    }
-                    const size_t o1 = p * (size_t)nf + k0;
-                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
-                                   A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
-                    if (has2)
-                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
-                                       A.amp_out ? A.amp_out + o1 + nf : nullptr,
-                                       A.ph_out ? A.ph_out + o1 + nf : nullptr);
-                }
-            }
-        }
-        wave_sync();  // every lane is done with D_0, D_1
-        if constexpr (MODE == kFwd) continue;
-        // park them in region 1: Y1[k] at k, Y2[k] at nf + k (2 nf <= N + 2)
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            if (256 * g < nf) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int k = 256 * g + lb4 + c;
-                    if (k < nf) {
-                        reg1[k] = Y1[g][c];
-                        reg1[nf + k] = Y2[g][c];
-                    }
-                }
-            }
-        wave_sync();
-        } else {
-            // inverse only: the two spectra from memory to where the fused chain parks them
-            const cx *f1 = A.fft_in + p * (size_t)nf;
-            for (int k = lb1; k < nf; k += kWave) {
-                cx y1 = ld_off(f1, (unsigned)k);
-                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + k)) : cx{0.0f, 0.0f};
-                if (k == 0 || ((L & 1) == 0 && k == nf - 1)) {
-                    y1.y = 0.0f;
-                    y2.y = 0.0f;
-                }
-                reg1[k] = y1;
-                reg1[nf + k] = y2;
-            }
-            wave_sync();
-        }
-
-        // ---- inverse, first stage: b'_s[n] = u[n] W_M^(s n), u[n] = conj(Y1full + i Y2full)[n] w[n]
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            constexpr int H = R1 / 4;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                cx wv[C1][H], tv[C1][H];
-                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;
-#pragma unroll
-                for (int j = 0; j < H; ++j)
-#pragma unroll
-                    for (int c = 0; c < C1; ++c) {
-                        const int n = M1 * (H * h + j) + lbh + c;
-                        const unsigned nn = (unsigned)(n < L ? n : L - 1);
-                        wv[c][j] = ld_off(wl, nn);
-                        tv[c][j] = s ? ld_off(tw, nn) : cx{1.0f, 0.0f};
-                    }
-#pragma unroll
-                for (int j = 0; j < H; ++j) {
-#pragma unroll
-                    for (int c = 0; c < C1; ++c) {
-                        const int n = M1 * (H * h + j) + lbh + c;
-                        const int nn = n < L ? n : L - 1;
-                        const bool low = nn <= half;
-                        const int kk = low ? nn : L - nn;
-                        const cx y1 = reg1[kk], y2 = reg1[nf + kk];
-                        const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
-                        cx v = cx_mul(gc, wv[c][j]);
-                        if (s) v = cx_mul(v, tv[c][j]);
-                        r[c][H * h + j] = n < L ? v : cx{0.0f, 0.0f};
-                    }
-                }
-                THZ_SCHED_FENCE();
-            }
-            cx *reg = s ? reg1 : reg0;
-            wave_sync();  // s = 1: every lane has read the parked spectra before region 1 is rewritten
-            f_core_pass1<P>(r, reg, t1, ad, lane);
-            f_core_pass23<P>(reg, t2, ad, lane);
-        }
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            cx *reg = s ? reg1 : reg0;
-            fb2_multiply_swapped<P>(reg, bf, s, lane, r);
-            wave_sync();
-            f_core_pass1<P>(r, reg, t1, ad, lane);
-            f_core_pass23<P>(reg, t2, ad, lane);
-        }
-
-        // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
-        {
-            float *o1 = A.data_out + p * (size_t)L;
-            float acc1 = 0.0f, acc2 = 0.0f;
-#pragma unroll 4
-            for (int n = lb1; n < L; n += kWave) {
-                const cx U = cx_mul(fb2_c(reg0, reg1, tw, n), ld_off(wl, (unsigned)n));
-                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
-                const float v1 = (U.x / fnt) * pw;
-                o1[n] = v1;
-                acc1 += v1 * v1;
-                if (has2) {
-                    const float v2 = (-U.y / fnt) * pw;
-                    o1[L + n] = v2;
-                    acc2 += v2 * v2;
-                }
-            }
-            if (A.img) {
-                acc1 = wave_reduce_add(acc1);
-                acc2 = wave_reduce_add(acc2);
-                if (lane == 0) {
-                    A.img[p] = acc1;
-                    if (has2) A.img[p + 1] = acc2;
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// FB4: chirp-z lengths 2048 < nt < 4096: convolution length M = 8192 = four N = 2048 core runs
-// per transform and one radix-4 stage, same arrangement as FB2 (decimation in frequency forward —
-// a[k + 2N], a[k + 3N] are zero since nt <= 2N — decimation in time inverse, last stage on
-// demand).  A wave owns four regions (65.6 KB): two waves per block, one per SIMD pair, so the
-// wave may use the whole register file: the pair's masked spectra (up to 128 values per lane)
-// wait in registers, and the last two inputs of the inverse's first stage are both built before
-// their regions are overwritten.
-template <class P>
-struct FB4Layout {
-    static constexpr int kWaves = 2;
-    static constexpr int pad4(int v) { return (v + 3) & ~3; }
-    static size_t lds_bytes(int nf)
-    {
-        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * 4 * P::WAVE_ENTRIES) * sizeof(cx)
-               + (size_t)pad4(nf) * sizeof(float);
-    }
-};
-
-// z * (-i)^s
-__device__ __forceinline__ cx fb4_rot(cx z, int s)
-{
-    switch (s & 3) {
-    case 1: return cx{z.y, -z.x};
-    case 2: return cx{-z.x, -z.y};
-    case 3: return cx{-z.y, z.x};
-    default: return z;
-    }
-}
-
-// r[c][j1] <- swap(region[nat(n)] * bf[4 n + s])
-template <class P>
-__device__ __forceinline__ void fb4_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
-                                                     cx (&r)[P::C1][P::R1])
-{
-    constexpr int R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    int fbase[2][C1];
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-#pragma unroll
-        for (int c = 0; c < C1; ++c) fbase[v][c] = launder_v(nat(M1 * v + C1 * lane + c) - M1 * v);
-    const unsigned bl = (unsigned)launder_v(4 * C1 * lane + s);
-#pragma unroll
-    for (int j1 = 0; j1 < R1; ++j1) {
-#pragma unroll
-        for (int c = 0; c < C1; ++c) {
-            const cx a = region[fbase[j1 & 1][c] + M1 * j1];
-            const cx t = cx_mul(a, ld_off(bf, bl + (unsigned)(4 * (M1 * j1 + c))));
-            r[c][j1] = cx{t.y, t.x};
-        }
-        if ((j1 & 3) == 3) THZ_SCHED_FENCE();
-    }
-}
-
-// c[m], m = k + N q (q = 0, 1): swap(sum_s (-i)^(s q) W_M^(s k) D_s[k])
-template <int N>
-__device__ __forceinline__ cx fb4_c(const cx *reg0, int region_stride, const cx *tw, int m)
-{
-    const int k = m & (N - 1), q = m >> 11;
-    const int slot = nat(k);
-    const cx d0 = reg0[slot], d1 = reg0[region_stride + slot], d2 = reg0[2 * region_stride + slot],
-             d3 = reg0[3 * region_stride + slot];
-    const cx t1 = cx_mul(ld_off(tw, (unsigned)k), d1), t2 = cx_mul(ld_off(tw, (unsigned)(2 * k)), d2),
-             t3 = cx_mul(ld_off(tw, (unsigned)(3 * k)), d3);
-    const cx z = q ? d0 + fb4_rot(t1, 1) - t2 + fb4_rot(t3, 3) : d0 + t1 + t2 + t3;
-    return cx{z.y, z.x};
-}
-
-template <class P, int MODE>
-__global__ __launch_bounds__(128) void k_fb4(FB2Args B, FTables T)
-{
-    THZ_DYN_LDS(lds);
-    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    static_assert(N == 2048, "four regions of 2048: convolution length 8192");
-    constexpr int NG = 8;  // epilogue groups of 256 bins: nf <= 2048
-    constexpr int RS = P::WAVE_ENTRIES;
-    const FBArgs &A = B.a;
-    const int L = A.nt, nf = A.nf;
-    const int lane = lane_id();
-    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
-    const int wpb = (int)(blockDim.x >> 6);
-    cx *t1 = reinterpret_cast<cx *>(lds);
-    cx *t2 = t1 + P::T1_ENTRIES;
-    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * 4 * RS;
-    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * 4 * RS);
-    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
-    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
-    for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
-    __syncthreads();
-
-    FAddr<P> ad;
-    ad.init(lane);
-    const float fnt = (float)L;
-    const int half = L / 2;
-    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
-    const size_t n_pairs = (A.npix + 1) / 2;
-    const size_t stride = (size_t)gridDim.x * wpb;
-
-    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
-        const size_t p = 2 * q;
-        const bool has2 = p + 1 < A.npix;  // wave-uniform
-        ad.refresh();
-        const cx *wl = launder_uniform(A.w);
-        const cx *bf = launder_uniform(A.bf);
-        const cx *tw = launder_uniform(B.tw);
-        const float *mask_l = launder_uniform((const float *)mask_s);
-        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
-        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
-        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
-        const float *x1 = A.in + p * (size_t)L;
-        const float *x2 = has2 ? x1 + L : x1;
-
-        // a[m] = (x1 + i x2)[m] pre[m] w[m], zero from nt on
-        auto a_at = [&](int m) -> cx {
-            const unsigned mm = (unsigned)(m < L ? m : L - 1);
-            const float pw = pre_g ? ld_off(pre_g, mm) : 1.0f;
-            const float xa = ld_off(x1, mm), xb = ld_off(x2, mm);
-            const float pwv = m < L ? pw : 0.0f;
-            return cx_mul(cx{xa * pwv, has2 ? xb * pwv : 0.0f}, ld_off(wl, mm));
-        };
-        // u[m] = conj(Y1full + i Y2full)[m] w[m] from the parked spectra (Y1 in region 2, Y2 in region 3)
-        auto u_at = [&](int m) -> cx {
-            const int mm = m < L ? m : L - 1;
-            const bool low = mm <= half;
-            const int kk = low ? mm : L - mm;
-            const cx y1 = reg0[2 * RS + kk], y2 = reg0[3 * RS + kk];
-            const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
-            const cx v = cx_mul(gc, ld_off(wl, (unsigned)mm));
-            return m < L ? v : cx{0.0f, 0.0f};
-        };
-        // first stage of either direction for sub-transform s: (f[k] + (-i)^s f[k + N]) W_M^(s k)
-        auto first_stage = [&](auto f, int s, cx(&r)[C1][R1]) {
-            constexpr int H = R1 / 4;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
-#pragma unroll
-                for (int j = 0; j < H; ++j) {
-#pragma unroll
-                    for (int c = 0; c < C1; ++c) {
-                        const int k = M1 * (H * h + j) + lbh + c;
-                        cx v = f(k) + fb4_rot(f(k + N), s);
-                        if (s) v = cx_mul(v, ld_off(tw, (unsigned)(s * k)));
-                        r[c][H * h + j] = v;
-                    }
-                }
-                THZ_SCHED_FENCE();
-            }
-        };
-
-        if constexpr (MODE != kInv) {
-        // ---- forward: four sub-transforms, multiply, four inverse sub-transforms
-        {
-            cx r[C1][R1];
-#pragma unroll 1
-            for (int s = 0; s < 4; ++s) {
-                first_stage(a_at, s, r);
-                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-            }
-#pragma unroll 1
-            for (int s = 0; s < 4; ++s) {
-                fb4_multiply_swapped<P>(reg0 + s * RS, bf, s, lane, r);
-                wave_sync();
-                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-            }
-        }
-
-        // ---- spectrum epilogue; the pair's masked spectra wait in registers
-        cx Y1[NG][4], Y2[NG][4];
-        {
-            FBUnwrap u1, u2;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (256 * g < nf) {  // wave-uniform
-                    const int k0 = 256 * g + lb4;
-                    cx X1[4], X2[4];
-                    float m[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int k = k0 + c;
-                        ok[c] = k < nf;
-                        const int kc = ok[c] ? k : nf - 1;
-                        const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
-                        const cx wk = ld_off(wl, (unsigned)kc);
-                        const cx Fk = cx_mul(fb4_c<N>(reg0, RS, tw, kc), wk);
-                        const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
-                        const cx Fm = cx_mul(fb4_c<N>(reg0, RS, tw, km), wm);
-                        X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
-                        X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
-                        m[c] = mask_l[kc];
-                        if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
-                            X1[c].y = 0.0f;
-                            X2[c].y = 0.0f;
-                        }
-                        Y1[g][c] = cx{X1[c].x * m[c], X1[c].y * m[c]};
-                        Y2[g][c] = cx{X2[c].x * m[c], X2[c].y * m[c]};
-                    }
-                    const size_t o1 = p * (size_t)nf + k0;
-                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
-                                   A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
-                    if (has2)
-                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
-                                       A.amp_out ? A.amp_out + o1 + nf : nullptr,
-                                       A.ph_out ? A.ph_out + o1 + nf : nullptr);
-                    THZ_SCHED_FENCE();
-                }
-            }
-        }
-        wave_sync();  // every lane is done with D_0 .. D_3
-        if constexpr (MODE == kFwd) continue;
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            if (256 * g < nf) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int k = 256 * g + lb4 + c;
-                    if (k < nf) {
-                        reg0[2 * RS + k] = Y1[g][c];
-                        reg0[3 * RS + k] = Y2[g][c];
-                    }
-                }
-            }
-        wave_sync();
-        } else {
-            const cx *f1 = A.fft_in + p * (size_t)nf;
-            for (int k = lb1; k < nf; k += kWave) {
-                cx y1 = ld_off(f1, (unsigned)k);
-                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + k)) : cx{0.0f, 0.0f};
-                if (k == 0 || ((L & 1) == 0 && k == nf - 1)) {
-                    y1.y = 0.0f;
-                    y2.y = 0.0f;
-                }
-                reg0[2 * RS + k] = y1;
-                reg0[3 * RS + k] = y2;
-            }
-            wave_sync();
-        }
-
-        // ---- inverse: sub-transforms 0 and 1 go to regions 0 and 1; 2 and 3 are both built before
-        // their regions (which hold the parked spectra) are overwritten
-        {
-            cx r[C1][R1], r3[C1][R1];
-#pragma unroll 1
-            for (int s = 0; s < 2; ++s) {
-                first_stage(u_at, s, r);
-                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-            }
-            first_stage(u_at, 2, r);
-            first_stage(u_at, 3, r3);
-            wave_sync();
-            f_core_pass1<P>(r, reg0 + 2 * RS, t1, ad, lane);
-            f_core_pass23<P>(reg0 + 2 * RS, t2, ad, lane);
-            f_core_pass1<P>(r3, reg0 + 3 * RS, t1, ad, lane);
-            f_core_pass23<P>(reg0 + 3 * RS, t2, ad, lane);
-#pragma unroll 1
-            for (int s = 0; s < 4; ++s) {
-                fb4_multiply_swapped<P>(reg0 + s * RS, bf, s, lane, r);
-                wave_sync();
-                f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-                f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-            }
-        }
-
-        // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
-        {
-            float *o1 = A.data_out + p * (size_t)L;
-            float acc1 = 0.0f, acc2 = 0.0f;
-#pragma unroll 2
-            for (int n = lb1; n < L; n += kWave) {
-                const cx U = cx_mul(fb4_c<N>(reg0, RS, tw, n), ld_off(wl, (unsigned)n));
-                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
-                const float v1 = (U.x / fnt) * pw;
-                o1[n] = v1;
-                acc1 += v1 * v1;
-                if (has2) {
-                    const float v2 = (-U.y / fnt) * pw;
-                    o1[L + n] = v2;
-                    acc2 += v2 * v2;
-                }
-            }
-            if (A.img) {
-                acc1 = wave_reduce_add(acc1);
-                acc2 = wave_reduce_add(acc2);
-                if (lane == 0) {
-                    A.img[p] = acc1;
-                    if (has2) A.img[p + 1] = acc2;
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// FBS: the same scheme for S core runs per transform (convolution length M = S * 2048), written
-// for S = 4 or 8 and used for S = 8 (4096 < nt < 8192; for S = 4 the hand-arranged k_fb4 above is
-// 20 % faster), as separate forward and inverse kernels: with that many
-// regions per wave there is no room to carry the pair's spectra from the one to the other, and the
-// inverse can read them where the forward kernel stored them (the masked spectrum rows in memory).
-//   first stage (decimation in frequency):  b_s[k] = (sum_{q < S/2} f[k + N q] W_S^(q s)) W_M^(s k)
-//                                           (f[m] = 0 for m >= nt, and nt <= N S / 2)
-//   last stage (decimation in time), where c is consumed:
-//                                           c[k + N q] = swap(sum_s W_S^(s q) W_M^(s k) D_s[k])
-// S = 4: two waves per block; S = 8: one (8 x 16.4 KB of LDS per wave), mask read from memory.
-template <class P, int S>
-struct FBSLayout {
-    static constexpr int kWaves = S == 4 ? 2 : 1;
-    static constexpr bool kMaskInLds = S == 4;
-    static constexpr int pad4(int v) { return (v + 3) & ~3; }
-    static size_t lds_bytes(int nf)
-    {
-        return (size_t)(P::T1_ENTRIES + P::T2_ENTRIES + kWaves * S * P::WAVE_ENTRIES) * sizeof(cx)
-               + (kMaskInLds ? (size_t)pad4(nf) * sizeof(float) : 0);
-    }
-};
-
+// r[c][j1] <- swap(region[nat(n)] * bf[S n + s]), n in the core's input layout
 template <class P, int S>
 __device__ __forceinline__ void fbs_multiply_swapped(const cx *region, const cx *__restrict__ bf, int s, int lane,
                                                      cx (&r)[P::C1][P::R1])
@@ -1038,183 +427,11 @@ __device__ __forceinline__ cx fbs_c(const cx *reg0, const cx *tw, int m)
     return cx{z.y, z.x};
 }
 
-template <class P, int S, int MODE>
-__global__ __launch_bounds__(S == 4 ? 128 : 64) void k_fbs(FB2Args B, FTables T)
-{
-    static_assert(MODE == kFwd || MODE == kInv, "forward and inverse are separate launches");
-    THZ_DYN_LDS(lds);
-    constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1, RS = P::WAVE_ENTRIES;
-    static_assert(N == 2048, "regions of 2048");
-    constexpr bool kMaskInLds = FBSLayout<P, S>::kMaskInLds;
-    const FBArgs &A = B.a;
-    const int L = A.nt, nf = A.nf;
-    const int lane = lane_id();
-    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
-    const int wpb = (int)(blockDim.x >> 6);
-    cx *t1 = reinterpret_cast<cx *>(lds);
-    cx *t2 = t1 + P::T1_ENTRIES;
-    cx *reg0 = t2 + P::T2_ENTRIES + (size_t)wib * S * RS;
-    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * S * RS);
-    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
-    for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
-    if (MODE == kFwd && kMaskInLds)
-        for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
-    __syncthreads();
-
-    FAddr<P> ad;
-    ad.init(lane);
-    const float fnt = (float)L;
-    const int half = L / 2;
-    const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
-    const size_t n_pairs = (A.npix + 1) / 2;
-    const size_t stride = (size_t)gridDim.x * wpb;
-
-    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
-        const size_t p = 2 * q;
-        const bool has2 = p + 1 < A.npix;  // wave-uniform
-        ad.refresh();
-        const cx *wl = launder_uniform(A.w);
-        const cx *bf = launder_uniform(A.bf);
-        const cx *tw = launder_uniform(B.tw);
-        const float *mask_l = kMaskInLds ? launder_uniform((const float *)mask_s) : launder_uniform(A.mask);
-        const float *pre_g = A.pre_win ? launder_uniform(A.pre_win) : nullptr;
-        const float *post_g = A.post_win ? launder_uniform(A.post_win) : nullptr;
-        const int lb = launder_v(C1 * lane), lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
-
-        // the sequence that is transformed: a[m] = (x1 + i x2)[m] pre[m] w[m] going forward,
-        // u[m] = conj(Y1full + i Y2full)[m] w[m] going back (spectra read from memory); 0 from nt on
-        auto f_at = [&](int m) -> cx {
-            const int mm = m < L ? m : L - 1;
-            cx v;
-            if constexpr (MODE == kFwd) {
-                const float *x1 = A.in + p * (size_t)L;
-                const float pw = pre_g ? ld_off(pre_g, (unsigned)mm) : 1.0f;
-                const float xa = ld_off(x1, (unsigned)mm);
-                const float xb = has2 ? ld_off(x1, (unsigned)(L + mm)) : 0.0f;
-                v = cx_mul(cx{xa * pw, xb * pw}, ld_off(wl, (unsigned)mm));
-            } else {
-                const cx *f1 = A.fft_in + p * (size_t)nf;
-                const bool low = mm <= half;
-                const int kk = low ? mm : L - mm;
-                cx y1 = ld_off(f1, (unsigned)kk);
-                cx y2 = has2 ? ld_off(f1, (unsigned)(nf + kk)) : cx{0.0f, 0.0f};
-                if (kk == 0 || ((L & 1) == 0 && kk == nf - 1)) {  // realfft's C2R ignores these
-                    y1.y = 0.0f;
-                    y2.y = 0.0f;
-                }
-                const cx gc = low ? cx{y1.x - y2.y, -y1.y - y2.x} : cx{y1.x + y2.y, y1.y - y2.x};
-                v = cx_mul(gc, ld_off(wl, (unsigned)mm));
-            }
-            return m < L ? v : cx{0.0f, 0.0f};
-        };
-
-        cx r[C1][R1];
-        // ---- first stage + S core runs
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) {
-            constexpr int H = R1 / 4;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int lbh = h ? launder_after(lb, r[C1 - 1][H * h - 1].x) : lb;  // batch after batch
-#pragma unroll
-                for (int j = 0; j < H; ++j) {
-#pragma unroll
-                    for (int c = 0; c < C1; ++c) {
-                        const int k = M1 * (H * h + j) + lbh + c;
-                        cx v = f_at(k);
-#pragma unroll
-                        for (int qq = 1; qq < S / 2; ++qq) {
-                            cx t = f_at(k + N * qq);
-                            if (s) t = cx_mul(t, ld_off(tw, (unsigned)(N * ((qq * s) & (S - 1)))));
-                            v = v + t;
-                        }
-                        if (s) v = cx_mul(v, ld_off(tw, (unsigned)(s * k)));
-                        r[c][H * h + j] = v;
-                    }
-                }
-                THZ_SCHED_FENCE();
-            }
-            f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-            f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-        }
-        // ---- multiply by FFT_M(b)/M and S inverse core runs, region by region
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) {
-            fbs_multiply_swapped<P, S>(reg0 + s * RS, bf, s, lane, r);
-            wave_sync();
-            f_core_pass1<P>(r, reg0 + s * RS, t1, ad, lane);
-            f_core_pass23<P>(reg0 + s * RS, t2, ad, lane);
-        }
-
-        if constexpr (MODE == kFwd) {
-            // ---- spectrum epilogue
-            FBUnwrap u1, u2;
-            const int n_groups = (nf + 255) / 256;
-#pragma unroll 1
-            for (int g = 0; g < n_groups; ++g) {
-                const int k0 = 256 * g + lb4;
-                cx X1[4], X2[4];
-                float m[4];
-                bool ok[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int k = k0 + c;
-                    ok[c] = k < nf;
-                    const int kc = ok[c] ? k : nf - 1;
-                    const int km = kc == 0 ? 0 : L - kc;  // F[nt] = F[0]
-                    const cx wk = ld_off(wl, (unsigned)kc);
-                    const cx Fk = cx_mul(fbs_c<P, S>(reg0, tw, kc), wk);
-                    const cx wm = kc == 0 ? wk : cx{sgn * wk.x, sgn * wk.y};
-                    const cx Fm = cx_mul(fbs_c<P, S>(reg0, tw, km), wm);
-                    X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
-                    X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
-                    m[c] = kMaskInLds ? mask_l[kc] : ld_off(mask_l, (unsigned)kc);
-                    if (kc == 0 || ((L & 1) == 0 && kc == nf - 1)) {
-                        X1[c].y = 0.0f;
-                        X2[c].y = 0.0f;
-                    }
-                }
-                const size_t o1 = p * (size_t)nf + k0;
-                fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
-                               A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
-                if (has2)
-                    fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + nf : nullptr,
-                                   A.amp_out ? A.amp_out + o1 + nf : nullptr, A.ph_out ? A.ph_out + o1 + nf : nullptr);
-            }
-        } else {
-            // ---- U[n] = w[n] c'[n]:  y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
-            float *o1 = A.data_out + p * (size_t)L;
-            float acc1 = 0.0f, acc2 = 0.0f;
-#pragma unroll 2
-            for (int n = lb1; n < L; n += kWave) {
-                const cx U = cx_mul(fbs_c<P, S>(reg0, tw, n), ld_off(wl, (unsigned)n));
-                const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
-                const float v1 = (U.x / fnt) * pw;
-                o1[n] = v1;
-                acc1 += v1 * v1;
-                if (has2) {
-                    const float v2 = (-U.y / fnt) * pw;
-                    o1[L + n] = v2;
-                    acc2 += v2 * v2;
-                }
-            }
-            if (A.img) {
-                acc1 = wave_reduce_add(acc1);
-                acc2 = wave_reduce_add(acc2);
-                if (lane == 0) {
-                    A.img[p] = acc1;
-                    if (has2) A.img[p + 1] = acc2;
-                }
-            }
-        }
-        wave_sync();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// FBC: the S-region scheme with S waves per pair of traces.  In k_fb2 / k_fb4 / k_fbs one wave
-// owns all S regions of its pair, so LDS (8 regions per CU) caps a CU at 8 / S waves.  The S
-// sub-transforms of a stage are independent, though: here wave s of a pair runs sub-transform s in
+// FBC: S waves per pair of traces.  If one wave owned all S regions of its pair, LDS (8 regions per
+// CU) would cap a CU at 8 / S waves (measured: 2.7 / 14.5 / 25 ms against 2.5 / 7.3 / 5.7 ms at
+// nt = 2000 / 4000 / 5000 for the three S).  The S sub-transforms of a stage are independent, so
+// wave s of a pair runs sub-transform s in
 // region s, and the block (8 waves = 8 / S pairs) meets at a barrier where the stages meet — after
 // the inverse core runs, before the on-demand last stage reads all S regions.  The epilogue is
 // split by bin groups (two groups per wave); the unwrap's running sum crosses waves as per-group

@@ -1203,42 +1203,8 @@ static void dispatch_fb(hipStream_t st, const PlanDev &P, FBArgs &A)
     }
 }
 
-// FB2 / FB4: two or four core runs per convolution transform (1024 < nt < 4096)
-template <int MODE>
-static void dispatch_fbx(hipStream_t st, const PlanDev &P, FB2Args &B)
-{
-    FBArgs &A = B.a;
-    A.nt = P.nt;
-    A.nf = P.nf;
-    A.w = reinterpret_cast<const cx *>(P.chirp_conj);
-    A.bf = reinterpret_cast<const cx *>(P.bfft);
-    B.tw = reinterpret_cast<const cx *>(P.tw);
-    using PL = FPlan4096;
-    const bool four = P.family == kFamilyFB4;
-    const size_t lds = four ? FB4Layout<PL>::lds_bytes(P.nf) : FB2Layout<PL>::lds_bytes(P.nf);
-    const unsigned wpb = four ? FB4Layout<PL>::kWaves : FB2Layout<PL>::kWaves;
-    const size_t n_pairs = (A.npix + 1) / 2;
-    size_t g = (n_pairs + wpb - 1) / wpb;
-    if (g > (size_t)kNumCU) g = kNumCU;
-    if (g < 1) g = 1;
-    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
-    if (four) {
-        allow_dynamic_lds(k_fb4<PL, MODE>, lds);
-        THZ_LAUNCH((k_fb4<PL, MODE>), (unsigned)g, wpb * kWave, lds, st, B, T);
-    } else {
-        allow_dynamic_lds(k_fb2<PL, MODE>, lds);
-        THZ_LAUNCH((k_fb2<PL, MODE>), (unsigned)g, wpb * kWave, lds, st, B, T);
-    }
-}
-
-// FBC: S waves per pair (fft_fb.hpp), forward and inverse as separate kernels; the default for
-// 1024 < nt < 8192 lengths that are not a power of two.  THZ_FB_SOLO=1 (developer knob) selects the
-// one-wave-per-pair kernels instead.
-static bool fb_solo()
-{
-    static const bool solo = getenv("THZ_FB_SOLO") != nullptr;
-    return solo;
-}
+// FBC: S waves per pair (fft_fb.hpp), forward and inverse as separate kernels, for the lengths
+// 1024 < nt < 8192 that are not a power of two
 
 template <int S, int MODE>
 static void launch_fbc(hipStream_t st, const PlanDev &P, FB2Args &B)
@@ -1271,28 +1237,6 @@ static void dispatch_fbc(hipStream_t st, const PlanDev &P, FB2Args &B)
     }
 }
 
-// FBS: S = 4 / 8 core runs per transform, forward and inverse as separate kernels
-template <int S, int MODE>
-static void launch_fbs(hipStream_t st, const PlanDev &P, FB2Args &B)
-{
-    FBArgs &A = B.a;
-    A.nt = P.nt;
-    A.nf = P.nf;
-    A.w = reinterpret_cast<const cx *>(P.chirp_conj);
-    A.bf = reinterpret_cast<const cx *>(P.bfft);
-    B.tw = reinterpret_cast<const cx *>(P.tw);
-    using PL = FPlan4096;
-    using LY = FBSLayout<PL, S>;
-    const size_t lds = LY::lds_bytes(P.nf);
-    const size_t n_pairs = (A.npix + 1) / 2;
-    size_t g = (n_pairs + LY::kWaves - 1) / LY::kWaves;
-    if (g > (size_t)kNumCU) g = kNumCU;
-    if (g < 1) g = 1;
-    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2), nullptr};
-    allow_dynamic_lds(k_fbs<PL, S, MODE>, lds);
-    THZ_LAUNCH((k_fbs<PL, S, MODE>), (unsigned)g, LY::kWaves * kWave, lds, st, B, T);
-}
-
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
                     float *amp_out, float *ph_out, const float *mask)
@@ -1308,7 +1252,7 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
         return;
     }
     // FB kernels (chirp-z lengths): same split — the windowed-trace output is its own launch
-    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && !fb_solo()) {
+    if (P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) {
         if (data_out && wa) {
             launch_td_window(st, npix, P.nt, in, wa, data_out);
             if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
@@ -1322,33 +1266,6 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
             dispatch_fbc<kFwd>(st, P, B);
             return;
         }
-    }
-    if (P.family == kFamilyFB8) {  // the only kernels that exist for 4096 < nt < 8192
-        if (data_out && wa) {
-            launch_td_window(st, npix, P.nt, in, wa, data_out);
-            if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
-            launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
-            return;
-        }
-        FB2Args B{};
-        B.a.npix = npix; B.a.in = in; B.a.pre_win = wa; B.a.mask = mask ? mask : P.ones;
-        B.a.fft_out = reinterpret_cast<cx *>(fft_out); B.a.amp_out = amp_out; B.a.ph_out = ph_out;
-        launch_fbs<8, kFwd>(st, P, B);  // (a second multiplier without a data output is not a stage the chain has)
-        return;
-    }
-    const bool fbx = P.family == kFamilyFB2 || P.family == kFamilyFB4;
-    if (fbx && data_out && wa) {
-        launch_td_window(st, npix, P.nt, in, wa, data_out);
-        if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
-        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
-        return;
-    }
-    if (fbx && !wb && !data_out) {
-        FB2Args B{};
-        B.a.npix = npix; B.a.in = in; B.a.pre_win = wa; B.a.mask = mask ? mask : P.ones;
-        B.a.fft_out = reinterpret_cast<cx *>(fft_out); B.a.amp_out = amp_out; B.a.ph_out = ph_out;
-        dispatch_fbx<kFwd>(st, P, B);
-        return;
     }
     if (P.family == kFamilyFB && data_out && wa) {
         launch_td_window(st, npix, P.nt, in, wa, data_out);
@@ -1394,25 +1311,11 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         dispatch_fb<kInv>(st, P, A);
         return;
     }
-    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && !fb_solo()) {
+    if (P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) {
         FB2Args B{};
         B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
         B.a.data_out = out; B.a.img = img;
         dispatch_fbc<kInv>(st, P, B);
-        return;
-    }
-    if (P.family == kFamilyFB8) {
-        FB2Args B{};
-        B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
-        B.a.data_out = out; B.a.img = img;
-        launch_fbs<8, kInv>(st, P, B);
-        return;
-    }
-    if (P.family == kFamilyFB2 || P.family == kFamilyFB4) {
-        FB2Args B{};
-        B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
-        B.a.data_out = out; B.a.img = img;
-        dispatch_fbx<kInv>(st, P, B);
         return;
     }
     unsigned grid, block;
@@ -1426,23 +1329,12 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img)
 {
-    if ((P.family == kFamilyFB4 || P.family == kFamilyFB8 || (P.family == kFamilyFB2 && !fb_solo())) && fft_out
-        && data_out) {
-        // four regions per wave leave no room to carry the pair's spectra through one kernel without
-        // spilling: forward and inverse as two launches are faster here (6.4 + 8.1 ms vs 17.7 ms fused
-        // for 65 536 traces of 4000 samples); the spectrum round trip through HBM is noise next to
-        // sixteen core runs per pair
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && fft_out && data_out) {
+        // S regions per pair leave no room to carry the pair's spectra from the forward to the inverse
+        // transform inside one kernel: two launches, the inverse reads the masked spectra back (the
+        // round trip through HBM is noise next to 4 S core runs per pair)
         launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
         launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
-        return;
-    }
-    if (P.family == kFamilyFB2 && fft_out && amp_out && ph_out && data_out) {
-        FB2Args B{};
-        FBArgs &A = B.a;
-        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
-        A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
-        A.data_out = data_out; A.img = img;
-        dispatch_fbx<kPipe>(st, P, B);
         return;
     }
     if (P.family == kFamilyFB && fft_out && amp_out && ph_out && data_out) {
