@@ -389,7 +389,8 @@ enum {
     THZ_BUF_IMG = 5,        /* (nx, ny) */
     THZ_BUF_AVG_FFT = 6,    /* (nf) complex   — needs want_means */
     THZ_BUF_AVG_AMPLITUDES = 7, /* (nf) */
-    THZ_BUF_AVG_PHASES = 8  /* (nf) */
+    THZ_BUF_AVG_PHASES = 8, /* (nf) */
+    THZ_BUF_OPACITY = 9     /* (nx, ny, nt_out) after thz_session_voxels */
 };
 
 int thz_session_create(thz_ctx *ctx, size_t nx, size_t ny, size_t nt, const float *time, float dx,
@@ -507,6 +508,15 @@ int thz_voxel_instances(thz_ctx *ctx, const float *d_opacity, size_t gw, size_t 
                         size_t gw_total, float threshold, float time_span, int scaling, size_t orig_w,
                         size_t orig_h, size_t orig_d, thz_voxel_instance *d_out, uint64_t capacity,
                         uint64_t *count, float *cube_dims);
+
+/* update_intensity_image's 3-D part for a session (data_thread.rs:82-101): opacity cube of the
+ * session's final trace cube, effective threshold, instance list — downloaded to `host_out`
+ * (capacity records; NULL with capacity 0 to only count).  time_span = last - first sample of the
+ * final time axis; scaling / orig_* as in thz_voxel_instances.  The opacity cube stays resident in
+ * the session (THZ_BUF_OPACITY) until the next call. */
+int thz_session_voxels(thz_session *s, const thz_voxel_cfg *cfg, uint64_t max_instances, int scaling,
+                       size_t orig_w, size_t orig_h, size_t orig_d, thz_voxel_instance *host_out,
+                       uint64_t capacity, uint64_t *count, float *threshold, float *cube_dims);
 
 /* Per-stage device time of the most recent call of each kind, the value the
  * reference shows next to each filter (filter.rs:607-621).  `stage` is one

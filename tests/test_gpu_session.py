@@ -154,6 +154,35 @@ def test_session_tilted_4096_scan(engine):
         sess.close()
 
 
+def test_session_voxels(engine):
+    """update_intensity_image's 3-D part on the session's final cube (data_thread.rs:82-101)"""
+    nx, ny, nt = 10, 9, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    cube = (cube * np.float32(4.0)).astype(np.float32)     # envelope maxima above the opacity threshold
+    sess = pkg.Session(engine, nx, ny, time)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        vcfg = pkg.voxel_cfg_default()
+        with pytest.raises(pkg.ThzError):
+            sess.voxels(vcfg)                               # nothing computed yet
+        cfg = pkg.chain_cfg_default(time)
+        sess.recompute(cfg)
+        inst, thr, dims = sess.voxels(vcfg, max_instances=3000)
+        final = sess.download(pkg.BUF_DATA).reshape(nx, ny, nt)
+        op_gpu = sess.download(pkg.BUF_OPACITY).reshape(nx, ny, nt)
+        assert np.abs(op_gpu - ob.voxel_opacity(final)).max() < 1e-5
+        assert thr == ob.voxel_threshold(op_gpu, 3000)
+        ref, rdims = ob.voxel_instances(op_gpu, thr, float(time[-1] - time[0]), 1, (nx, ny, nt))
+        assert dims == rdims and len(inst) == len(ref) >= 3000
+        assert np.array_equal(inst["position"], ref["position"])
+        assert np.array_equal(inst["color"][:, 3], ref["color"][:, 3])
+        # a buffer smaller than the count: complete count is still reported by the first (sizing) call
+        few, _, _ = sess.voxels(vcfg, max_instances=3000, capacity=10)
+        assert len(few) == 10 and np.array_equal(few["position"], ref["position"][:10])
+    finally:
+        sess.close()
+
+
 def test_session_download_bounds_and_missing_means(engine):
     time, cube = synth.make_cube(2, 2, 256)
     sess = pkg.Session(engine, 2, 2, time)

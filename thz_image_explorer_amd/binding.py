@@ -98,7 +98,7 @@ class PlotOut(C.Structure):
 
 
 BUF_RAW, BUF_FFT, BUF_AMPLITUDES, BUF_PHASES, BUF_DATA, BUF_IMG, BUF_AVG_FFT, BUF_AVG_AMPLITUDES, \
-    BUF_AVG_PHASES = range(9)
+    BUF_AVG_PHASES, BUF_OPACITY = range(10)
 
 
 class ThzError(RuntimeError):
@@ -169,6 +169,8 @@ SYMBOLS = [
     ("thz_session_buffer", _P, [_P, C.c_int]),
     ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
+    ("thz_session_voxels", C.c_int, [_P, C.POINTER(VoxelCfg), C.c_uint64, C.c_int, _SZ, _SZ, _SZ, _P, C.c_uint64,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_float), _P]),
     ("thz_host_align_reference", C.c_int, [_P, _SZ, _P, _P, _SZ, _P]),
     ("thz_reference_spectrum", C.c_int, [_P, _P, _SZ, _P, _P, _SZ, C.POINTER(WindowCfg), _P, _P, _P]),
     ("thz_host_optical_properties", C.c_int, [_P, _P, _P, _P, _P, _SZ, C.c_float, _P, _P, _P]),
@@ -397,6 +399,22 @@ class Session:
         self.eng._check(self.eng.lib.thz_session_time_out(self.h, t.ctypes.data))
         return t
 
+    def voxels(self, cfg: "VoxelCfg", max_instances=VOXEL_MAX_INSTANCES, scaling=1, orig_dims=None, capacity=None):
+        """update_intensity_image's 3-D part -> (instances, threshold, (cube_width, cube_height, cube_depth))"""
+        orig = orig_dims or (self.nx, self.ny, self.nt_out)
+        n, thr = C.c_uint64(), C.c_float()
+        dims = np.zeros(3, np.float32)
+        if capacity is None:   # count first
+            self.eng._check(self.eng.lib.thz_session_voxels(self.h, C.byref(cfg), max_instances, scaling, orig[0],
+                                                            orig[1], orig[2], None, 0, C.byref(n), C.byref(thr),
+                                                            dims.ctypes.data))
+            capacity = n.value
+        out = np.zeros(capacity, VOXEL_INSTANCE)
+        self.eng._check(self.eng.lib.thz_session_voxels(self.h, C.byref(cfg), max_instances, scaling, orig[0], orig[1],
+                                                        orig[2], out.ctypes.data if capacity else None, capacity,
+                                                        C.byref(n), C.byref(thr), dims.ctypes.data))
+        return out[:min(n.value, capacity)], thr.value, tuple(float(x) for x in dims)
+
     def plot(self, px, py, want=None):
         """UpdateType::Plot copy-out for pixel (px, py) -> dict of host vectors"""
         nto = self.nt_out
@@ -413,7 +431,7 @@ class Session:
         nto = self.nt_out
         nf = nto // 2 + 1
         per = {BUF_RAW: (self.nt,), BUF_FFT: (nf, 2), BUF_AMPLITUDES: (nf,), BUF_PHASES: (nf,), BUF_DATA: (nto,),
-               BUF_IMG: ()}
+               BUF_IMG: (), BUF_OPACITY: (nto,)}
         if which in per:
             npix = self.nx * self.ny - pix0 if npix is None else npix
             out = np.empty((npix,) + per[which], np.float32)

@@ -17,6 +17,8 @@ struct thz_session {
           *d_img = nullptr, *d_avg = nullptr;  // d_avg: [2 nf | nf | nf]
     float *d_vec = nullptr;                    // pre | mask | post multipliers (+ tilt scratch)
     float *d_tilt = nullptr;                   // extended cube when tilt != 0
+    float *d_opacity = nullptr;                // voxel opacities of the final cube (thz_session_voxels)
+    size_t opacity_floats = 0;
     int32_t *d_ins = nullptr;
     bool have_means = false;
     bool have_outputs = false;   // a recompute has run
@@ -97,7 +99,8 @@ void thz_session_destroy(thz_session *s)
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
-                    (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins})
+                    (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins,
+                    (void *)s->d_opacity})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -223,6 +226,7 @@ void *thz_session_buffer(thz_session *s, int which)
     case THZ_BUF_AVG_FFT: return s->have_means ? s->d_avg : nullptr;
     case THZ_BUF_AVG_AMPLITUDES: return s->have_means ? s->d_avg + 2 * nf : nullptr;
     case THZ_BUF_AVG_PHASES: return s->have_means ? s->d_avg + 3 * nf : nullptr;
+    case THZ_BUF_OPACITY: return s->opacity_floats == s->nx * s->ny * s->nt_out ? s->d_opacity : nullptr;
     default: return nullptr;
     }
 }
@@ -239,7 +243,7 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     case THZ_BUF_RAW: per = s->nt; break;
     case THZ_BUF_FFT: per = 2 * s->nf_out; break;
     case THZ_BUF_AMPLITUDES: case THZ_BUF_PHASES: per = s->nf_out; break;
-    case THZ_BUF_DATA: per = s->nt_out; break;
+    case THZ_BUF_DATA: case THZ_BUF_OPACITY: per = s->nt_out; break;
     case THZ_BUF_IMG: per = 1; break;
     case THZ_BUF_AVG_FFT: return thz_memcpy_d2h(ctx, dst, base, 2 * s->nf_out * sizeof(float));
     case THZ_BUF_AVG_AMPLITUDES: case THZ_BUF_AVG_PHASES: return thz_memcpy_d2h(ctx, dst, base, s->nf_out * sizeof(float));
@@ -247,6 +251,41 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     }
     if (pix0 + npix > total_pix) return fail(ctx, THZ_ERR_INVALID, "thz_session_download: pixel range out of bounds");
     return thz_memcpy_d2h(ctx, dst, base + pix0 * per, npix * per * sizeof(float));
+}
+
+int thz_session_voxels(thz_session *s, const thz_voxel_cfg *cfg, uint64_t max_instances, int scaling,
+                       size_t orig_w, size_t orig_h, size_t orig_d, thz_voxel_instance *host_out,
+                       uint64_t capacity, uint64_t *count, float *threshold, float *cube_dims)
+{
+    if (!s || !cfg || !count) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_voxels: no recompute has run");
+    if (capacity && !host_out) return fail(ctx, THZ_ERR_INVALID, "thz_session_voxels: capacity without a buffer");
+    if (int rc = use_device(ctx)) return rc;
+    const size_t npix = s->nx * s->ny, nt = s->nt_out, n = npix * nt;
+    if (s->opacity_floats != n) {
+        s->opacity_floats = 0;
+        if (int rc = dev_alloc(ctx, &s->d_opacity, n)) return rc;
+        s->opacity_floats = n;
+    }
+    if (int rc = thz_voxel_opacity(ctx, npix, nt, s->d_data, cfg, s->d_opacity)) return rc;
+    float thr = 0.0f;
+    if (int rc = thz_voxel_threshold(ctx, s->d_opacity, n, max_instances, &thr)) return rc;
+    if (threshold) *threshold = thr;
+    const float time_span = s->time_out.back() - s->time_out.front();
+    thz_voxel_instance *d_inst = nullptr;
+    if (capacity) HIP_TRY(ctx, hipMalloc((void **)&d_inst, capacity * sizeof(thz_voxel_instance)));
+    int rc = thz_voxel_instances(ctx, s->d_opacity, s->nx, s->ny, nt, 0, s->nx, thr, time_span, scaling, orig_w, orig_h,
+                                 orig_d, d_inst, capacity, count, cube_dims);
+    if (!rc && capacity) {
+        const uint64_t n_copy = *count < capacity ? *count : capacity;
+        if (n_copy) rc = thz_memcpy_d2h(ctx, host_out, d_inst, n_copy * sizeof(thz_voxel_instance));
+    }
+    if (d_inst) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_inst);
+    }
+    return rc;
 }
 
 int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *out)
