@@ -183,6 +183,27 @@ def test_session_voxels(engine):
         sess.close()
 
 
+def test_real_thz_file_through_session(engine):
+    """a real sample file of the reference (single-pulse .thz, nt = 1001), opened by the dotTHz reader,
+    through OpenFile's preprocessing and the default chain — against the oracle on the same trace"""
+    import os
+    from thz_image_explorer_amd import io_binding as tio
+    if not tio.available():
+        pytest.skip("libthzio.so not built")
+    path = os.path.join(os.path.dirname(__file__), "golden", "knife_edge_2groups.thz")
+    with tio.ScanFile(path) as f:
+        time, raw, g = f.time(), f.cube(), f.geometry()
+    assert raw.shape == (1, 1, 1001) and g.has_dx
+    sess = pkg.Session(engine, 1, 1, time, g.dx, g.dy)
+    try:
+        sess.upload(raw, subtract_bias=True)
+        cfg = pkg.chain_cfg_default(time)
+        sess.recompute(cfg)
+        check(sess, oracle_chain(ob.subtract_bias(raw), time, cfg, g.dx, g.dy), 1, 1)
+    finally:
+        sess.close()
+
+
 def test_session_download_bounds_and_missing_means(engine):
     time, cube = synth.make_cube(2, 2, 256)
     sess = pkg.Session(engine, 2, 2, time)
