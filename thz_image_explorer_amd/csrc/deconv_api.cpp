@@ -214,6 +214,12 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.off_mirror = (unsigned)(ws_floats + psf_pack.size());
         for (size_t i = bp.v.size(); i-- > 0;) psf_pack.push_back(bp.v[i]);  // psf[::-1, ::-1]
     }
+    if (getenv("THZ_DEBUG_BANDS"))  // developer knob: the band table on stderr
+        for (int b = 0; b < nbs; ++b)
+            fprintf(stderr, "band %2d  f=%.3f THz  psf %3d x %3d  n_iter %4d  tiles %u\n", b, centers[(size_t)b],
+                    bands[(size_t)b].pr, bands[(size_t)b].pc, bands[(size_t)b].n_iter,
+                    (b + 1 < nbs ? bands[(size_t)b + 1].tblk0 : tblk) - bands[(size_t)b].tblk0);
+    psf_pack.insert(psf_pack.end(), 32, 0.0f);  // the tiled step reads taps a whole chunk at a time
     HIP_TRY(ctx, mem.alloc(&d_ws, (ws_floats + psf_pack.size()) * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
                                 hipMemcpyHostToDevice, ctx->stream));

@@ -946,51 +946,241 @@ __global__ __launch_bounds__(256) void k_rl_step(const RlBand *__restrict__ band
 // (same operands, same order, no FMA); it only stops fetching every tap from L2.
 constexpr int kRlTile = 16;
 
-__global__ __launch_bounds__(256) void k_rl_step_tiled(const RlBand *__restrict__ bands, int n_bands,
-                                                       const int *__restrict__ it_base, int iteration, int step,
-                                                       float *__restrict__ ws)
+// One pixel's sum over the pr x pc taps in the reference's order (m outer, n inner, one add per tap,
+// no FMA), out of LDS.  The sum is a single dependent chain.  Most iterations only the two or three
+// widest bands are still running (n_iter falls with frequency), which is about one wave per SIMD:
+// nothing else hides a wait, and a launch lasts exactly as long as one such wave's chain.  What made
+// that slow was never the adds but the operand latency in front of each group of them — taps
+// fetched through the scalar cache (cold at every launch: an L2 round trip per 64 bytes) or LDS
+// reads waited for in full before the first multiply, per 16 taps and per TAP in a row's remainder.
+// Here a row is cut into chunks of kRlChunk taps, the chunks of all rows form one sequence, the
+// taps are staged into LDS IN THAT SEQUENCE (one coalesced pass per block), and chunk t+1's
+// operands are requested before chunk t's arithmetic starts; LDS returns in order, so the wait in
+// front of a chunk leaves the next chunk's reads in flight.  Every fetch is a full chunk: a row's
+// last chunk is the row's LAST kRlChunk taps (it overlaps the chunk before it, or starts in front
+// of the row when the row is shorter than a chunk) and its first `skip` products are left out of
+// the sum.  The image-side surplus is read from the neighbouring row of the tile or from the slack
+// the tile carries on either side, and is never used.
+constexpr int kRlChunk = 16;
+
+// chunks per row / first tap of chunk c of a row
+__device__ __forceinline__ int rl_chunks(int pc) { return (pc + kRlChunk - 1) / kRlChunk; }
+__device__ __forceinline__ int rl_chunk_n0(int c, int nch, int pc) { return c + 1 == nch ? pc - kRlChunk : c * kRlChunk; }
+
+__device__ __forceinline__ float rl_tile_taps(const float *origin, int wsz, const float *k_s, int pr, int pc)
 {
 #pragma clang fp contract(off)
+    const int nch = rl_chunks(pc);
+    const int last_skip = nch * kRlChunk - pc;  // taps of a row's last chunk that belong to the chunk before
+    const int total = pr * nch;
+    int f_a = 0, f_c = 0, f_m = 0, f_t = 0;  // fetch position: row start in the tile, chunk of the row, row, chunk of the sequence
+    auto fetch = [&](float (&av)[kRlChunk], float (&kv)[kRlChunk]) {
+        const float *row = origin + (f_a + rl_chunk_n0(f_c, nch, pc));
+        const float *kr = k_s + f_t * kRlChunk;
+#pragma unroll
+        for (int q = 0; q < kRlChunk; ++q) av[q] = row[q];
+#pragma unroll
+        for (int q = 0; q < kRlChunk; ++q) kv[q] = kr[q];
+        ++f_t;
+        ++f_c;
+        if (f_c == nch) {
+            f_c = 0;
+            if (f_m + 1 < pr) {  // the fetches after the last chunk repeat the last row (never used)
+                ++f_m;
+                f_a += wsz;
+            }
+        }
+    };
+    float sum = 0.0f;
+    int s_c = 0, s_t = 0;  // chunk of its row / of the sequence the next accumulate handles
+    auto accumulate = [&](const float (&av)[kRlChunk], const float (&kv)[kRlChunk]) {
+        int skip = (s_c + 1 == nch) ? last_skip : 0;
+        if (s_t >= total) skip = kRlChunk;  // an odd sequence's filler chunk
+        ++s_t;
+        ++s_c;
+        if (s_c == nch) s_c = 0;
+        if (skip == 0) {
+#pragma unroll
+            for (int q = 0; q < kRlChunk; ++q) sum += av[q] * kv[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < kRlChunk; ++q)
+                if (q >= skip) sum += av[q] * kv[q];  // wave-uniform
+        }
+    };
+    float a0[kRlChunk], k0[kRlChunk], a1[kRlChunk], k1[kRlChunk];
+    fetch(a0, k0);
+    for (int t = 0; t < total; t += 2) {
+        fetch(a1, k1);
+        accumulate(a0, k0);
+        fetch(a0, k0);
+        accumulate(a1, k1);
+    }
+    return sum;
+}
+
+// Wide kernels (mode 1, more than 256 taps) stand for the reference's FFT convolution, whose
+// rounding is not that of any particular summation order, so their sums need not be one chain.
+// Late in a call only the widest bands still iterate — one tile per CU — and a launch then costs
+// what one CU needs for one tile.  With a thread per pixel that is LDS bandwidth: every tap moves
+// 4 bytes of image and 4 bytes of kernel per lane through the 128 bytes/clock LDS port (measured:
+// 35 us per launch, whichever way the operands were fetched).  So a thread owns FOUR pixels side
+// by side and reads a sliding window — 20 image values and 16 taps (a broadcast) feed 64 FMAs — and
+// the rows of the kernel are dealt to kRlSplit waves, whose partial sums meet in LDS.
+// The tile is stored turned by 180 degrees (mode 1 walks the image downwards in both axes):
+// a[(ti + pr-1 - m), (tj + pc-1 - n)] is turned[(15-ti) + m][(15-tj) + n].  Its row stride is padded
+// so that the 16-byte reads of a quarter wave (16 tile rows, one column group) fall into different banks.  Taps are
+// staged row by row, each row zero-padded to whole chunks; everything a window can reach beyond a
+// row's taps is initialised (0 * NaN from stale LDS would poison the sum).
+constexpr int kRlSplit = 16;            // waves per tile
+constexpr int kRlThreads = 64 * kRlSplit;
+constexpr int kRlPix = 4;               // pixels per thread
+
+__host__ __device__ inline int rl_turned_stride(int wsz)
+{
+    // a window reaches up to kRlChunk columns past the halo (the zero-padded taps); a quarter wave
+    // reads 16 bytes in each of 16 consecutive tile rows, which hit 16 different bank groups when
+    // the stride is an odd number of 16-byte units
+    int w = (wsz + kRlChunk + 3) / 4 * 4;
+    if (w / 4 % 2 == 0) w += 4;
+    return w;
+}
+
+__device__ __forceinline__ void rl_tile_taps_split(const float *window0, int wsp, const float *k_s, int pc,
+                                                   int m_begin, int m_end, float (&acc)[kRlPix])
+{
+    const int nch = rl_chunks(pc);
+#pragma unroll
+    for (int p = 0; p < kRlPix; ++p) acc[p] = 0.0f;
+    for (int m = m_begin; m < m_end; ++m) {
+        const float4 *row = reinterpret_cast<const float4 *>(window0 + m * wsp);
+        const float4 *kr = reinterpret_cast<const float4 *>(k_s + m * nch * kRlChunk);
+        for (int c = 0; c < nch; ++c) {
+            float w[kRlChunk + 4], kv[kRlChunk];
+#pragma unroll
+            for (int q = 0; q < kRlChunk / 4 + 1; ++q) {
+                const float4 v = row[c * (kRlChunk / 4) + q];
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < kRlChunk / 4; ++q) {
+                const float4 v = kr[c * (kRlChunk / 4) + q];
+                kv[4 * q] = v.x; kv[4 * q + 1] = v.y; kv[4 * q + 2] = v.z; kv[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < kRlChunk; ++q)
+#pragma unroll
+                for (int p = 0; p < kRlPix; ++p) acc[p] = __builtin_fmaf(w[kRlPix - 1 - p + q], kv[q], acc[p]);
+        }
+    }
+}
+
+// LDS floats of a block: slack | tile + halo | slack | taps (chunk order, or padded rows) | partial sums
+__host__ __device__ inline size_t rl_tile_floats(int pr, int pc, bool turned)
+{
+    const int wsz = kRlTile + pc - 1;
+    const size_t tile = (size_t)(kRlTile + pr - 1) * (turned ? rl_turned_stride(wsz) : wsz);
+    return (2 * (size_t)kRlChunk + tile + 3) / 4 * 4;  // taps start 16-byte aligned
+}
+__host__ __device__ inline size_t rl_tap_floats(int pr, int pc)
+{
+    return ((size_t)pr * ((pc + kRlChunk - 1) / kRlChunk) + 2) * kRlChunk;
+}
+__host__ __device__ inline bool rl_turned(int pr, int pc) { return pr * pc > 256; }  // RlBand::mode == 1
+
+__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__restrict__ bands, int n_bands,
+                                                              const int *__restrict__ it_base, int iteration,
+                                                              int step, float *__restrict__ ws)
+{
     THZ_DYN_LDS(smem);
     if (it_base) iteration += *it_base;
+    // which band this tile belongs to: the bands' first-tile numbers are fetched side by side (one
+    // memory latency), not one dependent load per band
+    __shared__ unsigned tb[64];
     int b = 0;
-    while (b + 1 < n_bands && blockIdx.x >= bands[b + 1].tblk0) ++b;
+    if (n_bands <= 64) {
+        if ((int)threadIdx.x < n_bands) tb[threadIdx.x] = bands[threadIdx.x].tblk0;
+        __syncthreads();
+        while (b + 1 < n_bands && blockIdx.x >= tb[b + 1]) ++b;
+    } else {
+        while (b + 1 < n_bands && blockIdx.x >= bands[b + 1].tblk0) ++b;
+    }
     const RlBand B = bands[b];
     if (iteration >= B.n_iter) return;  // block-uniform
     const unsigned lt = blockIdx.x - B.tblk0;
     const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
     const int pr = B.pr, pc = B.pc;
+    const bool turned = B.mode != 0;
     const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;  // halo tile
-    float *a_s = reinterpret_cast<float *>(smem);
-    float *k_s = a_s + hs * wsz;
+    const int wsp = turned ? rl_turned_stride(wsz) : wsz;     // its row stride in LDS
+    float *a_s = reinterpret_cast<float *>(smem) + kRlChunk;  // slack in front and behind
+    float *k_s = reinterpret_cast<float *>(smem) + rl_tile_floats(pr, pc, turned);
+    float *part_s = k_s + rl_tap_floats(pr, pc);  // [kRlSplit][256], turned tiles only
     const float *a = ws + (step == 0 ? B.off_u : B.off_t);
     const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
     // first image row / column of the halo: mode 0 reads x = i + m - pr/2, mode 1 x = i + (pr-1)/2 - m
     const int r0 = B.mode == 0 ? ti0 - pr / 2 : ti0 + (pr - 1) / 2 - (pr - 1);
     const int c0 = B.mode == 0 ? tj0 - pc / 2 : tj0 + (pc - 1) / 2 - (pc - 1);
-    for (int e = (int)threadIdx.x; e < hs * wsz; e += (int)blockDim.x) {
-        const int x = r0 + e / wsz, y = c0 + e % wsz;
-        a_s[e] = (x >= 0 && x < B.H && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
+    // Tile staging: a wave per halo row, lanes along the row, the block's loads all in flight together
+    // (zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was).
+    const int nch = rl_chunks(pc);
+    {
+        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+#pragma unroll 4
+        for (int r = wv; r < hs; r += kRlThreads / kWave) {
+            const int x = r0 + r;
+            const bool xin = x >= 0 && x < B.H;
+            float *dst = a_s + (turned ? hs - 1 - r : r) * wsp;
+            for (int c = ln; c < wsp; c += kWave) {
+                const int y = c0 + c;
+                const float v = (c < wsz && xin && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
+                dst[c < wsz ? (turned ? wsz - 1 - c : c) : c] = v;
+            }
+        }
+        if (threadIdx.x < 2 * kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // behind the last row
     }
-    for (int e = (int)threadIdx.x; e < pr * pc; e += (int)blockDim.x) k_s[e] = k[e];
+    {
+        const int n_el = pr * nch * kRlChunk;
+        for (int e = (int)threadIdx.x; e < n_el; e += kRlThreads) {
+            const int t = e / kRlChunk, q = e % kRlChunk;
+            const int m = t / nch, c = t - m * nch;
+            if (turned) {  // padded rows
+                const int n = c * kRlChunk + q;
+                k_s[e] = n < pc ? k[m * pc + n] : 0.0f;
+            } else {       // the order rl_tile_taps consumes them in
+                const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
+                k_s[e] = src >= 0 ? k[src] : 0.0f;
+            }
+        }
+    }
     __syncthreads();
-    const int ti = (int)threadIdx.x / kRlTile, tj = (int)threadIdx.x % kRlTile;
-    const int i = ti0 + ti, j = tj0 + tj;
-    if (i >= B.H || j >= B.W) return;
-    float sum = 0.0f;
-    if (B.mode == 0) {
-        for (int m = 0; m < pr; ++m) {
-            const float *row = a_s + (ti + m) * wsz + tj;
-            const float *kr = k_s + m * pc;
-            for (int n = 0; n < pc; ++n) sum += row[n] * kr[n];
-        }
-    } else {
-        for (int m = 0; m < pr; ++m) {
-            const float *row = a_s + (ti + pr - 1 - m) * wsz + tj + (pc - 1);
-            const float *kr = k_s + m * pc;
-            for (int n = 0; n < pc; ++n) sum += row[-n] * kr[n];
-        }
+    if (!turned) {
+        const int px = (int)threadIdx.x;
+        const int ti = px / kRlTile, tj = px % kRlTile;
+        const int i = ti0 + ti, j = tj0 + tj;
+        if (px >= 256 || i >= B.H || j >= B.W) return;  // no barrier below on this path
+        const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);
+        const int idx = i * B.W + j;
+        if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
+        else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
+        return;
     }
+    {
+        // wave g sums kernel rows [g pr/16, (g+1) pr/16) for the whole tile: lane -> tile row and four columns
+        const int g = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+        const int ti = ln % kRlTile, tj = (ln / kRlTile) * kRlPix;
+        float acc[kRlPix];
+        rl_tile_taps_split(a_s + (kRlTile - 1 - ti) * wsp + (kRlTile - kRlPix - tj), wsp, k_s, pc,
+                           g * pr / kRlSplit, (g + 1) * pr / kRlSplit, acc);
+        *reinterpret_cast<float4 *>(part_s + g * 256 + ti * kRlTile + tj) = float4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    const int px = (int)threadIdx.x;
+    const int i = ti0 + px / kRlTile, j = tj0 + px % kRlTile;
+    if (px >= 256 || i >= B.H || j >= B.W) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < kRlSplit; ++g) sum += part_s[g * 256 + px];
     const int idx = i * B.W + j;
     if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
     else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
@@ -1510,7 +1700,8 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 
 size_t rl_tile_lds_bytes(int pr, int pc)
 {
-    return ((size_t)(kRlTile + pr - 1) * (kRlTile + pc - 1) + (size_t)pr * pc) * sizeof(float);
+    const bool turned = rl_turned(pr, pc);
+    return (rl_tile_floats(pr, pc, turned) + rl_tap_floats(pr, pc) + (turned ? (size_t)kRlSplit * 256 : 0)) * sizeof(float);
 }
 
 void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
@@ -1518,7 +1709,7 @@ void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled
 void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_tiles,
                           size_t lds_bytes, const int *it_base, int iteration, int step, float *ws)
 {
-    THZ_LAUNCH(k_rl_step_tiled, total_tiles, 256, lds_bytes, st, d_bands, n_bands, it_base, iteration, step, ws);
+    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_bands, n_bands, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
