@@ -4,6 +4,8 @@
 #include "deconv_host.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -90,6 +92,16 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     const size_t nt = ctx->time.size(), npix = nx * ny;
     const int nb = (int)cfg->n_filters;
     if (progress) *progress = 0.0f;
+    // developer knob: wall time of the call's phases on stderr (each tick drains the stream)
+    const bool timing = getenv("THZ_DEBUG_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "thz_deconvolve: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // guards of the reference: each returns the input unchanged (:781-812, :873-885)
     bool skip = psf->wx_fit.correction.n_knots == 0 || nx < 16 || ny < 16 || nb < 2;
     std::vector<float> filters, centers;
@@ -117,6 +129,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         return THZ_SKIPPED;
     }
 
+    tick("filter bank, widths");
     // ---- transform plan for the padded length M
     size_t M = 1;
     while (M < nt + kDeconvTaps - 1) M <<= 1;
@@ -134,46 +147,35 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
                                 hipMemcpyHostToDevice, ctx->stream));
     const PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
 
-    // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double
-    std::vector<c32> Hh((size_t)nb * nk);
-    {
-        std::vector<double> cs(M), sn(M);
-        for (size_t m = 0; m < M; ++m) {
-            const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)M;
-            cs[m] = std::cos(a);
-            sn[m] = std::sin(a);
-        }
-        for (int b = 0; b < nb; ++b)
-            for (size_t k = 0; k < nk; ++k) {
-                double re = 0.0, im = 0.0;
-                size_t idx = 0;
-                for (int j = 0; j < kDeconvTaps; ++j) {
-                    const double h = (double)filters[(size_t)b * kDeconvTaps + j];
-                    re += h * cs[idx];
-                    im += h * sn[idx];
-                    idx += k;
-                    if (idx >= M) idx -= M;
-                }
-                Hh[(size_t)b * nk + k] = c32{(float)(re / (double)M), (float)(im / (double)M)};
-            }
-    }
-    HIP_TRY(ctx, mem.alloc(&d_H, Hh.size() * sizeof(c32)));
-    HIP_TRY(ctx, hipMemcpyAsync(d_H, Hh.data(), Hh.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
-
-    // ---- band subset of this call (band-parallel multi-GPU): compact the bank
+    tick("plan, twiddles");
+    // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double, for the bands of
+    // this call (band-parallel multi-GPU: cfg->band_begin/band_end select a subset of the bank)
     int b0 = (int)cfg->band_begin, b1 = (int)cfg->band_end;
     if (b0 == 0 && b1 == 0) b1 = nb;
     if (b0 < 0 || b1 > nb || b0 >= b1)
         return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad band range");
-    const int nb_all = nb;
-    (void)nb_all;
-    std::vector<float> centers_sel(centers.begin() + b0, centers.begin() + b1);
-    std::vector<c32> Hsel(Hh.begin() + (size_t)b0 * nk, Hh.begin() + (size_t)b1 * nk);
-    HIP_TRY(ctx, hipMemcpyAsync(d_H, Hsel.data(), Hsel.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    centers = centers_sel;
     const int nbs = b1 - b0;
-
+    {
+        std::vector<double> trig(2 * M);  // cos | sin of -2 pi m / M
+        for (size_t m = 0; m < M; ++m) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)M;
+            trig[m] = std::cos(a);
+            trig[M + m] = std::sin(a);
+        }
+        double *d_trig = nullptr;
+        float *d_filters = nullptr;
+        HIP_TRY(ctx, mem.alloc(&d_trig, trig.size() * sizeof(double)));
+        HIP_TRY(ctx, mem.alloc(&d_filters, (size_t)nbs * kDeconvTaps * sizeof(float)));
+        HIP_TRY(ctx, mem.alloc(&d_H, (size_t)nbs * nk * sizeof(c32)));
+        HIP_TRY(ctx, hipMemcpyAsync(d_trig, trig.data(), trig.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_filters, filters.data() + (size_t)b0 * kDeconvTaps,
+                                    (size_t)nbs * kDeconvTaps * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        launch_dc_filter_spectra(ctx->stream, d_filters, nbs, kDeconvTaps, d_trig, d_trig + M, (unsigned)M,
+                                 (unsigned)nk, d_H);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // trig goes out of scope
+    }
+    centers = std::vector<float>(centers.begin() + b0, centers.begin() + b1);
+    tick("filter spectra");
     // ---- per-band PSFs, iteration counts, workspace layout
     std::vector<RlBand> bands((size_t)nbs);
     std::vector<float> psf_pack;
@@ -223,6 +225,13 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, mem.alloc(&d_ws, (ws_floats + psf_pack.size()) * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
                                 hipMemcpyHostToDevice, ctx->stream));
+    std::vector<RlTileRef> tiles(tblk);
+    for (int b = 0; b < nbs; ++b)
+        for (unsigned t = bands[(size_t)b].tblk0; t < (b + 1 < nbs ? bands[(size_t)b + 1].tblk0 : tblk); ++t)
+            tiles[t] = RlTileRef{b, bands[(size_t)b].n_iter};
+    RlTileRef *d_tiles = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_tiles, tiles.size() * sizeof(RlTileRef)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RlTileRef), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, mem.alloc(&d_bands, bands.size() * sizeof(RlBand)));
     HIP_TRY(ctx, hipMemcpyAsync(d_bands, bands.data(), bands.size() * sizeof(RlBand), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, mem.alloc(&d_spec, npix * nk * sizeof(c32)));
@@ -230,11 +239,13 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nbs * npix * sizeof(float)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope below
 
+    tick("band PSFs, workspace");
     const int shift = (kDeconvTaps - 1) / 2;
     launch_dc_fft(ctx->stream, P, npix, (int)nt, d_in, d_spec);
     launch_dc_energy(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_energy);
     launch_rl_init(ctx->stream, d_bands, nbs, blk, npix, d_energy, d_ws);
     if (int rc = check_launch(ctx)) return rc;
+    tick("transform, band energies");
     // Richardson-Lucy iterations: two dependent launches each, ~10 us of work per launch — the loop
     // is launch-bound.  A batch of kRlBatch iterations is captured once into a hipGraph and replayed;
     // the batch's first iteration number lives in device memory (d_it) so that one graph serves all
@@ -245,8 +256,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     if (tiled) prepare_rl_step_tiled(tile_lds);
     auto enqueue = [&](const int *it_base, int it) {
         if (tiled) {
-            launch_rl_step_tiled(ctx->stream, d_bands, nbs, tblk, tile_lds, it_base, it, 0, d_ws);
-            launch_rl_step_tiled(ctx->stream, d_bands, nbs, tblk, tile_lds, it_base, it, 1, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_bands, d_tiles, tblk, tile_lds, it_base, it, 0, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_bands, d_tiles, tblk, tile_lds, it_base, it, 1, d_ws);
         } else {
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 0, d_ws);
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 1, d_ws);
@@ -277,6 +288,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             if (g) (void)hipGraphDestroy(g);
         }
     } graph_guard{graph, exec};
+    tick("graph capture");
     for (int base = 0; base < max_iter; base += kRlBatch) {
         if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -293,6 +305,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
         if (progress) *progress = (float)std::min(base + kRlBatch, max_iter) / (float)max_iter;
     }
+    tick("iterations");
     launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);
     launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
     if (int rc = check_launch(ctx)) return rc;
@@ -300,6 +313,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nbs * npix * sizeof(float),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // temporaries are freed on return
+    tick("gains, recombination");
     if (progress) *progress = 1.0f;
     return THZ_OK;
 }

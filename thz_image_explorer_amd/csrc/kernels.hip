@@ -1088,25 +1088,19 @@ __host__ __device__ inline size_t rl_tap_floats(int pr, int pc)
 }
 __host__ __device__ inline bool rl_turned(int pr, int pc) { return pr * pc > 256; }  // RlBand::mode == 1
 
-__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__restrict__ bands, int n_bands,
+__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__restrict__ bands,
+                                                              const RlTileRef *__restrict__ tiles,
                                                               const int *__restrict__ it_base, int iteration,
                                                               int step, float *__restrict__ ws)
 {
     THZ_DYN_LDS(smem);
     if (it_base) iteration += *it_base;
-    // which band this tile belongs to: the bands' first-tile numbers are fetched side by side (one
-    // memory latency), not one dependent load per band
-    __shared__ unsigned tb[64];
-    int b = 0;
-    if (n_bands <= 64) {
-        if ((int)threadIdx.x < n_bands) tb[threadIdx.x] = bands[threadIdx.x].tblk0;
-        __syncthreads();
-        while (b + 1 < n_bands && blockIdx.x >= tb[b + 1]) ++b;
-    } else {
-        while (b + 1 < n_bands && blockIdx.x >= bands[b + 1].tblk0) ++b;
-    }
-    const RlBand B = bands[b];
-    if (iteration >= B.n_iter) return;  // block-uniform
+    // which band this tile belongs to, and whether that band still iterates: one scalar load from the
+    // per-tile table, so that the tiles of finished bands (most of the grid, most of the time) leave
+    // after a single memory latency
+    const RlTileRef T = tiles[blockIdx.x];
+    if (iteration >= T.n_iter) return;  // block-uniform
+    const RlBand B = bands[T.band];
     const unsigned lt = blockIdx.x - B.tblk0;
     const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
     const int pr = B.pr, pc = B.pc;
@@ -1184,6 +1178,31 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__re
     const int idx = i * B.W + j;
     if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
     else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
+}
+
+// Filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M) in double, one thread per (band, bin),
+// from the host's cos/sin table (cs[m], sn[m] of angle -2 pi m / M) with the index stepped modulo M:
+// the sums a single host core spent 10 ms of every call on, term for term.
+__global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restrict__ filters, int n_bands,
+                                                           int n_taps, const double *__restrict__ cs,
+                                                           const double *__restrict__ sn, unsigned M,
+                                                           unsigned nk, c32 *__restrict__ H)
+{
+#pragma clang fp contract(off)
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)blockIdx.y;
+    if (k >= nk || b >= n_bands) return;
+    const float *h = filters + (size_t)b * n_taps;
+    double re = 0.0, im = 0.0;
+    unsigned idx = 0;
+    for (int j = 0; j < n_taps; ++j) {
+        const double hj = (double)h[j];
+        re += hj * cs[idx];
+        im += hj * sn[idx];
+        idx += k;
+        if (idx >= M) idx -= M;
+    }
+    H[(size_t)b * nk + k] = c32{(float)(re / (double)M), (float)(im / (double)M)};
 }
 
 __global__ __launch_bounds__(256) void k_dc_gain(const RlBand *__restrict__ bands, int n_bands,
@@ -1657,6 +1676,13 @@ static inline void dc_geometry(const PlanDev &P, size_t npix, int bufs, unsigned
     *grid = (unsigned)g;
 }
 
+void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands, int n_taps, const double *cs,
+                              const double *sn, unsigned M, unsigned nk, c32 *H)
+{
+    const dim3 grid((nk + 255) / 256, (unsigned)n_bands);
+    hipLaunchKernelGGL(k_dc_filter_spectra, grid, dim3(256), 0, st, filters, n_bands, n_taps, cs, sn, M, nk, H);
+}
+
 void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec)
 {
     unsigned grid, block;
@@ -1706,10 +1732,10 @@ size_t rl_tile_lds_bytes(int pr, int pc)
 
 void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
 
-void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_tiles,
+void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, const RlTileRef *d_tiles, unsigned total_tiles,
                           size_t lds_bytes, const int *it_base, int iteration, int step, float *ws)
 {
-    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_bands, n_bands, it_base, iteration, step, ws);
+    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_bands, d_tiles, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,

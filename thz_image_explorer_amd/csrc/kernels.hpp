@@ -52,6 +52,8 @@ struct RlBand {
     unsigned off_d, off_u, off_t, off_psf, off_mirror;
 };
 
+void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands, int n_taps, const double *cs,
+                              const double *sn, unsigned M, unsigned nk, c32 *H);
 void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec);
 void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                       const c32 *spec, const c32 *H, float *energy);
@@ -65,7 +67,11 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 // LDS-tiled form of the same step: total_tiles blocks, lds_bytes = rl_tile_lds_bytes of the largest band
 size_t rl_tile_lds_bytes(int pr, int pc);
 void prepare_rl_step_tiled(size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
-void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_tiles,
+struct RlTileRef {
+    int band;    // index into the band table
+    int n_iter;  // that band's iteration count
+};
+void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, const RlTileRef *d_tiles, unsigned total_tiles,
                           size_t lds_bytes, const int *it_base, int iteration, int step, float *ws);
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
                     const float *energy, const float *ws, float *gain);
