@@ -1046,33 +1046,54 @@ __host__ __device__ inline int rl_turned_stride(int wsz)
     return w;
 }
 
+typedef float rl_f2 __attribute__((ext_vector_type(2)));
+
+// Pixels in pairs, taps one at a time: (sum[p+1], sum[p]) += (w[x], w[x+1]) * (k, k) is one packed FMA when
+// (w[x], w[x+1]) is an even-aligned register pair — which it is for every other tap.  The odd pairs
+// are made in registers (one v_pk_mov_b32 each) rather than read from LDS a second time.
 __device__ __forceinline__ void rl_tile_taps_split(const float *window0, int wsp, const float *k_s, int pc,
                                                    int m_begin, int m_end, float (&acc)[kRlPix])
 {
+    static_assert(kRlPix == 4 && kRlChunk == 16, "register layout below");
     const int nch = rl_chunks(pc);
-#pragma unroll
-    for (int p = 0; p < kRlPix; ++p) acc[p] = 0.0f;
+    rl_f2 s10 = {0.0f, 0.0f}, s32 = {0.0f, 0.0f};  // (pixel 1, pixel 0), (pixel 3, pixel 2)
     for (int m = m_begin; m < m_end; ++m) {
         const float4 *row = reinterpret_cast<const float4 *>(window0 + m * wsp);
         const float4 *kr = reinterpret_cast<const float4 *>(k_s + m * nch * kRlChunk);
         for (int c = 0; c < nch; ++c) {
-            float w[kRlChunk + 4], kv[kRlChunk];
+            rl_f2 we[10], wo[9];  // we[i] = (w[2i], w[2i+1]), wo[i] = (w[2i+1], w[2i+2])
+            float kv[kRlChunk];
 #pragma unroll
-            for (int q = 0; q < kRlChunk / 4 + 1; ++q) {
-                const float4 v = row[c * (kRlChunk / 4) + q];
-                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            for (int q = 0; q < 5; ++q) {
+                const float4 v = row[c * 4 + q];
+                we[2 * q] = rl_f2{v.x, v.y};
+                we[2 * q + 1] = rl_f2{v.z, v.w};
             }
 #pragma unroll
-            for (int q = 0; q < kRlChunk / 4; ++q) {
-                const float4 v = kr[c * (kRlChunk / 4) + q];
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = kr[c * 4 + q];
                 kv[4 * q] = v.x; kv[4 * q + 1] = v.y; kv[4 * q + 2] = v.z; kv[4 * q + 3] = v.w;
             }
 #pragma unroll
-            for (int q = 0; q < kRlChunk; ++q)
+            for (int i = 0; i < 9; ++i) {
+#ifdef THZ_EMU
+                wo[i] = rl_f2{we[i].y, we[i + 1].x};
+#else
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(wo[i]) : "v"(we[i]), "v"(we[i + 1]));
+#endif
+            }
+            // pixel p, tap q reads w[3 - p + q]: pair (1, 0) reads (w[2 + q], w[3 + q]), pair (3, 2) reads (w[q], w[q + 1])
 #pragma unroll
-                for (int p = 0; p < kRlPix; ++p) acc[p] = __builtin_fmaf(w[kRlPix - 1 - p + q], kv[q], acc[p]);
+            for (int q = 0; q < kRlChunk; ++q) {
+                const rl_f2 kk = {kv[q], kv[q]};
+                const rl_f2 x10 = (q % 2 == 0) ? we[(2 + q) / 2] : wo[(1 + q) / 2];
+                const rl_f2 x32 = (q % 2 == 0) ? we[q / 2] : wo[(q - 1) / 2];
+                s10 = __builtin_elementwise_fma(x10, kk, s10);
+                s32 = __builtin_elementwise_fma(x32, kk, s32);
+            }
         }
     }
+    acc[0] = s10.y; acc[1] = s10.x; acc[2] = s32.y; acc[3] = s32.x;
 }
 
 // LDS floats of a block: slack | tile + halo | slack | taps (chunk order, or padded rows) | partial sums
