@@ -1210,9 +1210,10 @@ __global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restri
                                                            unsigned nk, c32 *__restrict__ H)
 {
 #pragma clang fp contract(off)
-    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = (int)blockIdx.y;
-    if (k >= nk || b >= n_bands) return;
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned k = e % nk;
+    const int b = (int)(e / nk);
+    if (b >= n_bands) return;
     const float *h = filters + (size_t)b * n_taps;
     double re = 0.0, im = 0.0;
     unsigned idx = 0;
@@ -1700,8 +1701,8 @@ static inline void dc_geometry(const PlanDev &P, size_t npix, int bufs, unsigned
 void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands, int n_taps, const double *cs,
                               const double *sn, unsigned M, unsigned nk, c32 *H)
 {
-    const dim3 grid((nk + 255) / 256, (unsigned)n_bands);
-    hipLaunchKernelGGL(k_dc_filter_spectra, grid, dim3(256), 0, st, filters, n_bands, n_taps, cs, sn, M, nk, H);
+    THZ_LAUNCH(k_dc_filter_spectra, ((unsigned)n_bands * nk + 255) / 256, 256, 0, st, filters, n_bands, n_taps, cs, sn, M,
+               nk, H);
 }
 
 void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec)
