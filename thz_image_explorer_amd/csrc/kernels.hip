@@ -1154,18 +1154,17 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__re
         }
         if (threadIdx.x < 2 * kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // behind the last row
     }
-    {
+    if (turned) {  // padded rows: a wave per kernel row
+        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+        for (int m = wv; m < pr; m += kRlThreads / kWave)
+            for (int n = ln; n < nch * kRlChunk; n += kWave) k_s[m * nch * kRlChunk + n] = n < pc ? k[m * pc + n] : 0.0f;
+    } else {       // the order rl_tile_taps consumes them in
         const int n_el = pr * nch * kRlChunk;
         for (int e = (int)threadIdx.x; e < n_el; e += kRlThreads) {
             const int t = e / kRlChunk, q = e % kRlChunk;
             const int m = t / nch, c = t - m * nch;
-            if (turned) {  // padded rows
-                const int n = c * kRlChunk + q;
-                k_s[e] = n < pc ? k[m * pc + n] : 0.0f;
-            } else {       // the order rl_tile_taps consumes them in
-                const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
-                k_s[e] = src >= 0 ? k[src] : 0.0f;
-            }
+            const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
+            k_s[e] = src >= 0 ? k[src] : 0.0f;
         }
     }
     __syncthreads();
@@ -1180,6 +1179,13 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__re
         else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
         return;
     }
+    const int px = (int)threadIdx.x;
+    const int i = ti0 + px / kRlTile, j = tj0 + px % kRlTile;
+    const bool writer = px < 256 && i < B.H && j < B.W;
+    const int idx = i * B.W + j;
+    // the other operand of the update does not depend on the sums: fetched now, it arrives under them
+    float other = 0.0f;
+    if (writer) other = ws[(step == 0 ? B.off_d : B.off_u) + idx];
     {
         // wave g sums kernel rows [g pr/16, (g+1) pr/16) for the whole tile: lane -> tile row and four columns
         const int g = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
@@ -1190,20 +1196,14 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__re
         *reinterpret_cast<float4 *>(part_s + g * 256 + ti * kRlTile + tj) = float4{acc[0], acc[1], acc[2], acc[3]};
     }
     __syncthreads();
-    const int px = (int)threadIdx.x;
-    const int i = ti0 + px / kRlTile, j = tj0 + px % kRlTile;
-    if (px >= 256 || i >= B.H || j >= B.W) return;
+    if (!writer) return;
     float sum = 0.0f;
 #pragma unroll
     for (int g = 0; g < kRlSplit; ++g) sum += part_s[g * 256 + px];
-    const int idx = i * B.W + j;
-    if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
-    else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
+    if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
+    else ws[B.off_u + idx] = other * sum;
 }
 
-// Filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M) in double, one thread per (band, bin),
-// from the host's cos/sin table (cs[m], sn[m] of angle -2 pi m / M) with the index stepped modulo M:
-// the sums a single host core spent 10 ms of every call on, term for term.
 __global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restrict__ filters, int n_bands,
                                                            int n_taps, const double *__restrict__ cs,
                                                            const double *__restrict__ sn, unsigned M,
