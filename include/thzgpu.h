@@ -403,6 +403,19 @@ void thz_session_destroy(thz_session *s);
 int thz_session_upload(thz_session *s, const float *cube, int subtract_bias);
 /* UpdateType::Filter(start_idx) for any start_idx: recomputes every output. */
 int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg);
+/* UpdateType::Filter(<Deconvolution>): the chain's last stage (FilterDomain::
+ * TimeAfterFFTPrioLast, deconvolution.rs:751) — Deconvolution::filter
+ * (deconvolution.rs:766-1041) on the "Time Band Pass" output of the last
+ * recompute, with the session's dx / dy.  Its result is THZ_BUF_DATA /
+ * THZ_BUF_IMG (and what thz_session_voxels / thz_session_plot read) until the
+ * next thz_session_recompute: the reference does not re-run the deconvolution
+ * when another filter is updated (data_thread.rs:1080, 1139-1149), the stage
+ * then passes its input through (:1186-1188).  Calling it again deconvolves the
+ * Time Band Pass output again, not the previous result.  Returns THZ_OK,
+ * THZ_SKIPPED (a guard returned the input unchanged; the output is that copy)
+ * or a negative code (THZ_ERR_ABORTED: the final output is the input again). */
+int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_cfg *cfg,
+                           volatile const int *abort_flag, float *progress);
 /* trace length of the final cube (nt, or nt + 2*steps after a tilt) and its axis */
 size_t thz_session_nt_out(const thz_session *s);
 int thz_session_time_out(const thz_session *s, float *time /* nt_out */);

@@ -204,6 +204,50 @@ def test_real_thz_file_through_session(engine):
         sess.close()
 
 
+def test_session_deconvolution_stage(engine):
+    """the chain's last stage and its gating (data_thread.rs:1080, 1139-1149, 1186-1188): updating the
+    Deconvolution filter deconvolves the Time Band Pass output; updating any other filter passes it through"""
+    import os
+    from test_gpu_deconv import _bar_target_cube
+    nx, ny, nt = 32, 32, 256
+    time, cube = _bar_target_cube(nx, ny, nt)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "psf_sample.npz"))
+    psf, opsf = pkg.psf_from_npz(z), ob.psf_from_npz(z)
+    dcfg = pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5)
+    sess = pkg.Session(engine, nx, ny, time, 0.5, 0.5)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        with pytest.raises(pkg.ThzError):
+            sess.deconvolve(psf, dcfg)                      # nothing computed yet
+        cfg = pkg.chain_cfg_default(time)
+        sess.recompute(cfg)
+        stage_in = sess.download(pkg.BUF_DATA).reshape(nx, ny, nt)
+        img_in = sess.download(pkg.BUF_IMG).reshape(nx, ny)
+        assert sess.deconvolve(psf, dcfg) == 0
+        out = sess.download(pkg.BUF_DATA).reshape(nx, ny, nt)
+        img = sess.download(pkg.BUF_IMG).reshape(nx, ny)
+        rc, oref, oimg, _, _ = ob.deconvolution(stage_in, time, 0.5, 0.5, opsf, 20, 6, 0.4, 3.0, 0.5)
+        assert rc == 0
+        assert np.abs(out - oref).max() / np.abs(oref).max() < 2e-4
+        assert np.abs(img - oimg).max() / oimg.max() < 5e-4
+        assert np.abs(out - stage_in).max() / np.abs(stage_in).max() > 1e-2
+        # the plot copy-out and a second update read the same stage input, not the previous result
+        po = sess.plot(3, 4)
+        assert np.array_equal(po["filtered_signal"], out[3, 4])
+        assert sess.deconvolve(psf, dcfg) == 0
+        assert np.array_equal(sess.download(pkg.BUF_DATA).reshape(nx, ny, nt), out)
+        # a guard (fewer than 2 bands) hands the input through
+        assert sess.deconvolve(psf, pkg.DeconvCfg(20, 1, 0.4, 3.0, 0.5)) == 1
+        assert np.array_equal(sess.download(pkg.BUF_DATA).reshape(nx, ny, nt), stage_in)
+        assert sess.deconvolve(psf, dcfg) == 0
+        # another filter is updated: the deconvolution is not re-run, its stage passes the input through
+        sess.recompute(cfg)
+        assert np.array_equal(sess.download(pkg.BUF_DATA).reshape(nx, ny, nt), stage_in)
+        assert np.array_equal(sess.download(pkg.BUF_IMG).reshape(nx, ny), img_in)
+    finally:
+        sess.close()
+
+
 def test_session_download_bounds_and_missing_means(engine):
     time, cube = synth.make_cube(2, 2, 256)
     sess = pkg.Session(engine, 2, 2, time)

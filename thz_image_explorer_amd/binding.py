@@ -164,6 +164,7 @@ SYMBOLS = [
     ("thz_session_destroy", None, [_P]),
     ("thz_session_upload", C.c_int, [_P, _P, C.c_int]),
     ("thz_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg)]),
+    ("thz_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_session_nt_out", _SZ, [_P]),
     ("thz_session_time_out", C.c_int, [_P, _P]),
     ("thz_session_buffer", _P, [_P, C.c_int]),
@@ -389,6 +390,15 @@ class Session:
 
     def recompute(self, cfg: ChainCfg):
         self.eng._check(self.eng.lib.thz_session_recompute(self.h, C.byref(cfg)))
+
+    def deconvolve(self, psf, cfg, abort=None, progress=None):
+        """the chain's Deconvolution stage on the last recompute's output -> status (0 applied, 1 skipped)"""
+        rc = self.eng.lib.thz_session_deconvolve(self.h, C.byref(psf), C.byref(cfg),
+                                                 C.byref(abort) if abort is not None else None,
+                                                 C.byref(progress) if progress is not None else None)
+        if rc < 0:
+            self.eng._check(rc)
+        return rc
 
     @property
     def nt_out(self):

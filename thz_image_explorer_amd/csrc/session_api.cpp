@@ -17,6 +17,9 @@ struct thz_session {
           *d_img = nullptr, *d_avg = nullptr;  // d_avg: [2 nf | nf | nf]
     float *d_vec = nullptr;                    // pre | mask | post multipliers (+ tilt scratch)
     float *d_tilt = nullptr;                   // extended cube when tilt != 0
+    float *d_deconv = nullptr, *d_deconv_img = nullptr;  // output of the Deconvolution stage (thz_session_deconvolve)
+    size_t deconv_floats = 0;
+    bool deconv_current = false;               // ... and whether it is the chain's final output right now
     float *d_opacity = nullptr;                // voxel opacities of the final cube (thz_session_voxels)
     size_t opacity_floats = 0;
     int32_t *d_ins = nullptr;
@@ -26,6 +29,10 @@ struct thz_session {
 };
 
 namespace {
+
+// the chain's final trace cube / image: the Deconvolution stage's output while it is current
+float *final_data(const thz_session *s) { return s->deconv_current ? s->d_deconv : s->d_data; }
+float *final_img(const thz_session *s) { return s->deconv_current ? s->d_deconv_img : s->d_img; }
 
 template <class T>
 int dev_alloc(thz_ctx *ctx, T **p, size_t n)
@@ -100,7 +107,7 @@ void thz_session_destroy(thz_session *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
                     (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins,
-                    (void *)s->d_opacity})
+                    (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -192,6 +199,7 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
         return rc;
     s->have_means = false;
     s->have_outputs = true;
+    s->deconv_current = false;  // the stage passes its input through unless it is the one updated
     s->src_is_tilt = src != s->d_raw;
     if (cfg->want_means) {
         if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 2, s->d_fft, s->d_avg)) return rc;
@@ -201,6 +209,35 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return THZ_OK;
+}
+
+int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_cfg *cfg,
+                           volatile const int *abort_flag, float *progress)
+{
+    if (!s || !psf || !cfg) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_deconvolve: no recompute has run");
+    if (int rc = use_device(ctx)) return rc;
+    const size_t npix = s->nx * s->ny, n = npix * s->nt_out;
+    if (s->deconv_floats != n) {
+        s->deconv_floats = 0;
+        s->deconv_current = false;
+        if (int rc = dev_alloc(ctx, &s->d_deconv, n)) return rc;
+        if (int rc = dev_alloc(ctx, &s->d_deconv_img, npix)) return rc;
+        s->deconv_floats = n;
+    }
+    // the engine's axis is the chain's current one unless a plot call re-planned in between
+    if (ctx->time.size() != s->nt_out)
+        if (int rc = thz_set_time_axis(ctx, s->time_out.data(), s->nt_out)) return rc;
+    // the stage's input is always the Time Band Pass output, never its own earlier result
+    const int rc = thz_deconvolve(ctx, psf, cfg, s->nx, s->ny, s->dx, s->dy, s->d_data, s->d_deconv, s->d_deconv_img,
+                                  nullptr, abort_flag, progress);
+    if (rc < 0) {  // aborted or failed: filter() hands back input.clone()
+        s->deconv_current = false;
+        return rc;
+    }
+    s->deconv_current = true;  // THZ_SKIPPED too: the guards copied the input through
+    return rc;
 }
 
 size_t thz_session_nt_out(const thz_session *s) { return s ? s->nt_out : 0; }
@@ -221,8 +258,8 @@ void *thz_session_buffer(thz_session *s, int which)
     case THZ_BUF_FFT: return s->d_fft;
     case THZ_BUF_AMPLITUDES: return s->d_amp;
     case THZ_BUF_PHASES: return s->d_ph;
-    case THZ_BUF_DATA: return s->d_data;
-    case THZ_BUF_IMG: return s->d_img;
+    case THZ_BUF_DATA: return final_data(s);
+    case THZ_BUF_IMG: return final_img(s);
     case THZ_BUF_AVG_FFT: return s->have_means ? s->d_avg : nullptr;
     case THZ_BUF_AVG_AMPLITUDES: return s->have_means ? s->d_avg + 2 * nf : nullptr;
     case THZ_BUF_AVG_PHASES: return s->have_means ? s->d_avg + 3 * nf : nullptr;
@@ -268,7 +305,7 @@ int thz_session_voxels(thz_session *s, const thz_voxel_cfg *cfg, uint64_t max_in
         if (int rc = dev_alloc(ctx, &s->d_opacity, n)) return rc;
         s->opacity_floats = n;
     }
-    if (int rc = thz_voxel_opacity(ctx, npix, nt, s->d_data, cfg, s->d_opacity)) return rc;
+    if (int rc = thz_voxel_opacity(ctx, npix, nt, final_data(s), cfg, s->d_opacity)) return rc;
     float thr = 0.0f;
     if (int rc = thz_voxel_threshold(ctx, s->d_opacity, n, max_instances, &thr)) return rc;
     if (threshold) *threshold = thr;
@@ -326,7 +363,7 @@ int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *o
             if (!rc && out->phase_fft) rc = thz_memcpy_d2h(ctx, out->phase_fft, d_tmp + nf, nf * sizeof(float));
         }
         if (!rc && out->avg_signal) {
-            rc = thz_pixel_mean(ctx, s->nx, s->ny, nt, 1, s->d_data, d_tmp + 2 * nf);
+            rc = thz_pixel_mean(ctx, s->nx, s->ny, nt, 1, final_data(s), d_tmp + 2 * nf);
             if (!rc) rc = thz_memcpy_d2h(ctx, out->avg_signal, d_tmp + 2 * nf, nt * sizeof(float));
         }
         (void)hipStreamSynchronize(ctx->stream);
