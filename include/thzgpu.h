@@ -205,6 +205,14 @@ int thz_apply_fd_cmask(thz_ctx *ctx, size_t npix, float *d_fft, float *d_amp,
 int thz_ifft(thz_ctx *ctx, size_t npix, const float *d_fft, const float *d_td_win,
              float *d_data_out, float *d_img);
 
+/* The avg_in_fourier_space branch of math_tools::ifft (math_tools.rs:442-470) and
+ * its per-ROI twin (:496-529): spectrum[k] = from_polar(amp[k], phase[k]) of an
+ * AVERAGED amplitude / unwrapped-phase pair, C2R, / nt — one trace, so host
+ * vectors in and out (amp, phase: nf; out: nt).  zero_dc_imag: the ROI branch
+ * clears Im(spectrum[0]) by hand (:510-512).  The transform ignores the
+ * imaginary parts of bin 0 and (even nt) the last bin, as realfft's does. */
+int thz_polar_ifft(thz_ctx *ctx, const float *amp, const float *phase, int zero_dc_imag, float *out);
+
 /* Whole default chain for one cube tile in ONE launch (the hot path):
  * raw -> *pre window -> R2C -> amp/phase/unwrap -> *fd mask -> store
  *     -> C2R /nt -> *post window -> store + intensity.

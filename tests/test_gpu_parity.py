@@ -555,3 +555,19 @@ def test_chirpz_without_windows_matches_numpy(engine, nt):
     assert rel(d_img.download((nx, ny), np.float32), (cube.astype(np.float64) ** 2).sum(-1)) < TOL
     for b in (d_raw, d_fft, d_amp, d_ph, d_out, d_img):
         b.free()
+
+
+@pytest.mark.parametrize("nt", [256, 1001, 4096])
+def test_polar_ifft_of_averaged_spectra(engine, nt):
+    """ifft's avg_in_fourier_space branch (math_tools.rs:442-470) and its ROI twin (:496-529): the pixel
+    means of amplitudes and unwrapped phases of a small cube, back to one time trace"""
+    nx, ny = 4, 3
+    time, cube = synth.make_cube(nx, ny, nt)
+    st = ob.fft_stage(cube, time, 0, 1.0, 7.0)
+    amp, ph = ob.pixel_mean(st["amplitudes"]), ob.pixel_mean(st["phases"])
+    engine.set_time_axis(time)
+    for zero_dc in (False, True):
+        got = engine.polar_ifft(amp, ph, zero_dc)
+        ref = ob.polar_irfft(amp, ph, nt, zero_dc)
+        assert rel(got, ref) < TOL
+    assert np.abs(ref).max() > 0

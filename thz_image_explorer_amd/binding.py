@@ -156,6 +156,7 @@ SYMBOLS = [
     ("thz_host_filter_bank", C.c_int, [_P, _SZ, C.POINTER(DeconvCfg), _P, _P]),
     ("thz_host_band_psf", C.c_int, [C.POINTER(Psf), C.c_float, C.c_float, C.c_float, _SZ, _SZ, _P,
                                     C.POINTER(_SZ), C.POINTER(_SZ)]),
+    ("thz_polar_ifft", C.c_int, [_P, _P, _P, C.c_int, _P]),
     ("thz_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _SZ, _SZ, C.c_float, C.c_float,
                                  _P, _P, _P, _P, _P, _P]),
     ("thz_synth_cube", C.c_int, [_P, _P, _SZ, C.c_uint64, _P, C.c_uint32, C.c_int]),
@@ -611,6 +612,13 @@ class Engine:
     def tilt_apply(self, npix, d_in, nt_in, d_taper, d_insert, nt_out, d_out):
         self._check(self.lib.thz_tilt_apply(self.ctx, npix, _dp(d_in), nt_in, _dp(d_taper), _dp(d_insert),
                                             nt_out, _dp(d_out)))
+
+    def polar_ifft(self, amp, phase, zero_dc_imag=False):
+        """ifft's avg_in_fourier_space branch: from_polar(avg amplitude, avg phase) -> C2R / nt (host vectors)"""
+        a, p = (np.ascontiguousarray(x, np.float32) for x in (amp, phase))
+        out = np.empty(self.nt, np.float32)
+        self._check(self.lib.thz_polar_ifft(self.ctx, a.ctypes.data, p.ctypes.data, int(zero_dc_imag), out.ctypes.data))
+        return out
 
     def deconvolve(self, psf: Psf, cfg: DeconvCfg, nx, ny, dx, dy, d_in, d_out, d_img=None, d_gains=None,
                    abort=None, progress=None):

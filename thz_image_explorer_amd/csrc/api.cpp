@@ -355,6 +355,28 @@ int thz_ifft(thz_ctx *ctx, size_t npix, const float *d_fft, const float *d_td_wi
     return check_launch(ctx);
 }
 
+int thz_polar_ifft(thz_ctx *ctx, const float *amp, const float *phase, int zero_dc_imag, float *out)
+{
+    if (int rc = need_plan(ctx)) return rc;
+    if (!amp || !phase || !out) return fail(ctx, THZ_ERR_INVALID, "thz_polar_ifft: null argument");
+    const size_t nt = ctx->time.size(), nf = nt / 2 + 1;
+    std::vector<float> spec(2 * nf);
+    for (size_t k = 0; k < nf; ++k) {  // Complex::from_polar, f32
+        spec[2 * k] = amp[k] * std::cos(phase[k]);
+        spec[2 * k + 1] = amp[k] * std::sin(phase[k]);
+    }
+    if (zero_dc_imag) spec[1] = 0.0f;
+    float *d = nullptr;
+    const size_t o = (2 * nf + 3) & ~(size_t)3;  // the trace starts 16-byte aligned, like a cube's first row
+    HIP_TRY(ctx, hipMalloc((void **)&d, (o + nt) * sizeof(float)));
+    int rc = thz_memcpy_h2d(ctx, d, spec.data(), 2 * nf * sizeof(float));
+    if (!rc) rc = thz_ifft(ctx, 1, d, nullptr, d + o, nullptr);
+    if (!rc) rc = thz_memcpy_d2h(ctx, out, d + o, nt * sizeof(float));
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
 int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_pre_win,
                  const float *d_fd_mask, const float *d_post_win, float *d_fft, float *d_amp,
                  float *d_phase, float *d_data_out, float *d_img)
