@@ -381,6 +381,12 @@ typedef struct thz_chain_cfg {
     double td_after_low, td_after_high, td_after_width;
     /* pixel means of the ifft stage (math_tools.rs:421-440) */
     int32_t want_means;
+    /* ConfigContainer.scale_factor: the chain's first stage, math_tools::scaling
+     * (math_tools.rs:242-310).  s > 1 replaces the raw cube by its s x s block
+     * means (sum / s^2, also on ragged edges), every later stage and output then
+     * lives on the (nx / s, ny / s) grid with dx * s, dy * s (thz_session_grid);
+     * s <= 1, or a side shorter than s, leaves the grid alone. */
+    int32_t scale_factor;
 } thz_chain_cfg;
 
 /* Defaults of the reference after OpenFile + reset(): every filter active, bounds
@@ -411,6 +417,9 @@ void thz_session_destroy(thz_session *s);
 int thz_session_upload(thz_session *s, const float *cube, int subtract_bias);
 /* UpdateType::Filter(start_idx) for any start_idx: recomputes every output. */
 int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg);
+/* Grid of the last recompute's outputs (the raw grid until then): every buffer
+ * except THZ_BUF_RAW has nx * ny pixels of this grid.  Any pointer may be NULL. */
+int thz_session_grid(const thz_session *s, size_t *nx, size_t *ny, float *dx, float *dy);
 /* UpdateType::Filter(<Deconvolution>): the chain's last stage (FilterDomain::
  * TimeAfterFFTPrioLast, deconvolution.rs:751) — Deconvolution::filter
  * (deconvolution.rs:766-1041) on the "Time Band Pass" output of the last

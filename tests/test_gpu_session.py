@@ -204,6 +204,42 @@ def test_real_thz_file_through_session(engine):
         sess.close()
 
 
+def test_session_scaling_stage(engine):
+    """ConfigContainer.scale_factor: the chain's first stage (math_tools.rs:242-310) — block means of the raw
+    cube incl. the ragged-edge rule, dx / dy grown by s, everything behind it on the block grid"""
+    nx, ny, nt, sf = 9, 7, 1024, 2
+    time, cube = synth.make_cube(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time, 0.5, 0.25)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        assert sess.grid() == (nx, ny, 0.5, 0.25)
+        cfg = pkg.chain_cfg_default(time)
+        assert cfg.scale_factor == 1
+        cfg.scale_factor = sf
+        cfg.tilt_x_deg, cfg.tilt_y_deg = 1.5, -0.5            # uses the grown dx / dy
+        sess.recompute(cfg)
+        gx, gy, gdx, gdy = sess.grid()
+        assert (gx, gy, gdx, gdy) == (nx // sf, ny // sf, 1.0, 0.5)
+        small = ob.scale3d(cube, sf)
+        ref = oracle_chain(small, time, cfg, gdx, gdy)
+        assert ref["time"].size > nt                            # the tilt really extended the axis
+        check(sess, ref, gx, gy)
+        # plot copy-out: raw trace of the pixel itself, processed traces of its block
+        po = sess.plot(5, 3)
+        assert np.array_equal(po["signal"], cube[5, 3])
+        assert np.array_equal(po["filtered_signal"], sess.download(pkg.BUF_DATA).reshape(gx, gy, -1)[5 // sf, 3 // sf])
+        with pytest.raises(pkg.ThzError):
+            sess.plot(8, 0)                                     # ragged edge: no block behind this pixel
+        # a factor larger than a side leaves the grid alone (:251-256); so does going back to 1
+        for f in (8, 1):
+            cfg.scale_factor = f
+            sess.recompute(cfg)
+            assert sess.grid() == (nx, ny, 0.5, 0.25)
+        check(sess, oracle_chain(cube, time, cfg, 0.5, 0.25), nx, ny)
+    finally:
+        sess.close()
+
+
 def test_session_deconvolution_stage(engine):
     """the chain's last stage and its gating (data_thread.rs:1080, 1139-1149, 1186-1188): updating the
     Deconvolution filter deconvolves the Time Band Pass output; updating any other filter passes it through"""

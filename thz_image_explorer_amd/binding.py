@@ -89,7 +89,7 @@ class ChainCfg(C.Structure):
                 ("td_before_width", C.c_double), ("fft_window", WindowCfg),
                 ("fd_active", C.c_int32), ("fd_low", C.c_double), ("fd_high", C.c_double), ("fd_width", C.c_double),
                 ("td_after_active", C.c_int32), ("td_after_low", C.c_double), ("td_after_high", C.c_double),
-                ("td_after_width", C.c_double), ("want_means", C.c_int32)]
+                ("td_after_width", C.c_double), ("want_means", C.c_int32), ("scale_factor", C.c_int32)]
 
 
 class PlotOut(C.Structure):
@@ -165,6 +165,7 @@ SYMBOLS = [
     ("thz_session_destroy", None, [_P]),
     ("thz_session_upload", C.c_int, [_P, _P, C.c_int]),
     ("thz_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg)]),
+    ("thz_session_grid", C.c_int, [_P, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("thz_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_session_nt_out", _SZ, [_P]),
     ("thz_session_time_out", C.c_int, [_P, _P]),
@@ -405,6 +406,12 @@ class Session:
     def nt_out(self):
         return int(self.eng.lib.thz_session_nt_out(self.h))
 
+    def grid(self):
+        """(nx, ny, dx, dy) of the outputs: the raw grid, or the block grid behind a scaling stage"""
+        nx, ny, dx, dy = _SZ(), _SZ(), C.c_float(), C.c_float()
+        self.eng._check(self.eng.lib.thz_session_grid(self.h, C.byref(nx), C.byref(ny), C.byref(dx), C.byref(dy)))
+        return nx.value, ny.value, dx.value, dy.value
+
     def time_out(self):
         t = np.empty(self.nt_out, np.float32)
         self.eng._check(self.eng.lib.thz_session_time_out(self.h, t.ctypes.data))
@@ -444,7 +451,8 @@ class Session:
         per = {BUF_RAW: (self.nt,), BUF_FFT: (nf, 2), BUF_AMPLITUDES: (nf,), BUF_PHASES: (nf,), BUF_DATA: (nto,),
                BUF_IMG: (), BUF_OPACITY: (nto,)}
         if which in per:
-            npix = self.nx * self.ny - pix0 if npix is None else npix
+            gx, gy = (self.nx, self.ny) if which == BUF_RAW else self.grid()[:2]
+            npix = gx * gy - pix0 if npix is None else npix
             out = np.empty((npix,) + per[which], np.float32)
         else:
             out = np.empty((nf, 2) if which == BUF_AVG_FFT else (nf,), np.float32)

@@ -11,6 +11,11 @@ struct thz_session {
     thz_ctx *ctx = nullptr;
     size_t nx = 0, ny = 0, nt = 0, nf = 0;
     float dx = 1.0f, dy = 1.0f;
+    // grid of everything behind the scaling stage (math_tools.rs:242-310): nx / s, ny / s, dx * s, dy * s
+    size_t nx_cur = 0, ny_cur = 0, scale = 1, out_pix = 0;
+    float dx_cur = 1.0f, dy_cur = 1.0f;
+    float *d_scaled = nullptr;                 // block-averaged raw cube when scale > 1
+    size_t scaled_floats = 0;
     std::vector<float> time, time_out;
     size_t nt_out = 0, nf_out = 0;
     float *d_raw = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr, *d_data = nullptr,
@@ -25,7 +30,7 @@ struct thz_session {
     int32_t *d_ins = nullptr;
     bool have_means = false;
     bool have_outputs = false;   // a recompute has run
-    bool src_is_tilt = false;    // the fft stage read d_tilt (extended axis) instead of d_raw
+    const float *d_src = nullptr;  // what the fft stage read: d_raw, d_scaled or d_tilt (extended axis)
 };
 
 namespace {
@@ -45,8 +50,9 @@ int dev_alloc(thz_ctx *ctx, T **p, size_t n)
 int alloc_outputs(thz_session *s, size_t nt_out)
 {
     thz_ctx *ctx = s->ctx;
-    const size_t npix = s->nx * s->ny, nf = nt_out / 2 + 1;
-    if (nt_out == s->nt_out && s->d_fft) return THZ_OK;
+    const size_t npix = s->nx_cur * s->ny_cur, nf = nt_out / 2 + 1;
+    if (nt_out == s->nt_out && npix == s->out_pix && s->d_fft) return THZ_OK;
+    s->out_pix = 0;
     if (int rc = dev_alloc(ctx, &s->d_fft, npix * nf * 2)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_amp, npix * nf)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_ph, npix * nf)) return rc;
@@ -55,6 +61,7 @@ int alloc_outputs(thz_session *s, size_t nt_out)
     if (int rc = dev_alloc(ctx, &s->d_vec, 3 * nt_out + nf + 8)) return rc;
     s->nt_out = nt_out;
     s->nf_out = nf;
+    s->out_pix = npix;
     return THZ_OK;
 }
 
@@ -79,6 +86,7 @@ int thz_chain_cfg_default(const float *time, size_t nt, thz_chain_cfg *out)
     out->td_after_high = (double)time[nt - 1];
     out->td_after_width = 0.1;
     out->want_means = 1;
+    out->scale_factor = 1;  // ConfigContainer.scale_factor, config.rs:193-212
     return THZ_OK;
 }
 
@@ -90,6 +98,7 @@ int thz_session_create(thz_ctx *ctx, size_t nx, size_t ny, size_t nt, const floa
     if (int rc = thz_set_time_axis(ctx, time, nt)) return rc;
     thz_session *s = new thz_session();
     s->ctx = ctx; s->nx = nx; s->ny = ny; s->nt = nt; s->nf = nt / 2 + 1; s->dx = dx; s->dy = dy;
+    s->nx_cur = nx; s->ny_cur = ny; s->dx_cur = dx; s->dy_cur = dy;
     s->time.assign(time, time + nt);
     s->time_out = s->time;
     int rc = dev_alloc(ctx, &s->d_raw, nx * ny * nt);
@@ -107,7 +116,7 @@ void thz_session_destroy(thz_session *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
                     (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins,
-                    (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img})
+                    (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img, (void *)s->d_scaled})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -119,6 +128,9 @@ int thz_session_upload(thz_session *s, const float *cube, int subtract_bias)
     if (int rc = use_device(ctx)) return rc;
     const size_t npix = s->nx * s->ny;
     if (int rc = thz_set_time_axis(ctx, s->time.data(), s->nt)) return rc;
+    // the image below is the raw grid's: outputs of an earlier (possibly scaled) recompute are void
+    s->have_outputs = false; s->have_means = false; s->deconv_current = false;
+    s->scale = 1; s->nx_cur = s->nx; s->ny_cur = s->ny; s->dx_cur = s->dx; s->dy_cur = s->dy;
     if (cube) HIP_TRY(ctx, hipMemcpyAsync(s->d_raw, cube, npix * s->nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     launch_intensity(ctx->stream, npix, (int)s->nt, s->d_raw, s->d_img, subtract_bias ? 1 : 0);
     if (int rc = check_launch(ctx)) return rc;
@@ -131,18 +143,37 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     if (!s || !cfg) return THZ_ERR_INVALID;
     thz_ctx *ctx = s->ctx;
     if (int rc = use_device(ctx)) return rc;
-    const size_t npix = s->nx * s->ny;
     const float *src = s->d_raw;
     std::vector<float> time = s->time;
     std::vector<float> tilt_taper;
     size_t nt_cur = s->nt;
     bool tilt_as_multiplier = false;
 
+    // ---- scaling (math_tools.rs:242-310): s x s block means of the raw cube, / s^2 also on ragged
+    // edges; dx, dy grow by s; identity when s <= 1 or when a side would vanish (:244-256)
+    size_t sf = cfg->scale_factor > 1 ? (size_t)cfg->scale_factor : 1;
+    if (s->nx / sf == 0 || s->ny / sf == 0) sf = 1;
+    s->have_outputs = false;  // the grid may change under the buffers below
+    s->deconv_current = false;
+    s->scale = sf;
+    s->nx_cur = s->nx / sf; s->ny_cur = s->ny / sf;
+    s->dx_cur = s->dx * (float)sf; s->dy_cur = s->dy * (float)sf;
+    const size_t npix = s->nx_cur * s->ny_cur;
+    if (sf > 1) {
+        if (s->scaled_floats != npix * s->nt) {
+            s->scaled_floats = 0;
+            if (int rc = dev_alloc(ctx, &s->d_scaled, npix * s->nt)) return rc;
+            s->scaled_floats = npix * s->nt;
+        }
+        if (int rc = thz_scale3d(ctx, s->d_raw, s->nx, s->ny, s->nt, 1, sf, s->d_scaled)) return rc;
+        src = s->d_scaled;
+    }
+
     // ---- Tilt Compensation: zero tilt is just its tail taper (a multiplier); otherwise the
     // cube is re-laid out on an extended axis and the chain continues at the new length
     if (cfg->tilt_active) {
-        const size_t steps = tilt_plan(time.data(), nt_cur, s->nx, s->ny, cfg->tilt_x_deg, cfg->tilt_y_deg,
-                                       s->dx, s->dy, nullptr, nullptr);
+        const size_t steps = tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg,
+                                       s->dx_cur, s->dy_cur, nullptr, nullptr);
         tilt_taper.resize(nt_cur);
         adapted_blackman(time.data(), nt_cur, 0.0f, 7.0f, tilt_taper.data());
         if (steps == 0) {
@@ -151,14 +182,14 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
             const size_t nt2 = nt_cur + 2 * steps;
             std::vector<float> new_time(nt2);
             std::vector<int32_t> ins(npix);
-            tilt_plan(time.data(), nt_cur, s->nx, s->ny, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx, s->dy,
+            tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx_cur, s->dy_cur,
                       new_time.data(), ins.data());
             if (int rc = dev_alloc(ctx, &s->d_tilt, npix * nt2)) return rc;
             if (int rc = dev_alloc(ctx, &s->d_ins, npix)) return rc;
             if (int rc = alloc_outputs(s, nt2)) return rc;
             HIP_TRY(ctx, hipMemcpyAsync(s->d_ins, ins.data(), npix * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(s->d_vec, tilt_taper.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-            launch_tilt(ctx->stream, npix, (int)nt_cur, (int)nt2, s->d_raw, s->d_vec, s->d_ins, s->d_tilt);
+            launch_tilt(ctx->stream, npix, (int)nt_cur, (int)nt2, src, s->d_vec, s->d_ins, s->d_tilt);
             if (int rc = check_launch(ctx)) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             src = s->d_tilt;
@@ -200,11 +231,11 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     s->have_means = false;
     s->have_outputs = true;
     s->deconv_current = false;  // the stage passes its input through unless it is the one updated
-    s->src_is_tilt = src != s->d_raw;
+    s->d_src = src;
     if (cfg->want_means) {
-        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 2, s->d_fft, s->d_avg)) return rc;
-        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 1, s->d_amp, s->d_avg + 2 * nf)) return rc;
-        if (int rc = thz_pixel_mean(ctx, s->nx, s->ny, nf, 1, s->d_ph, s->d_avg + 3 * nf)) return rc;
+        if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 2, s->d_fft, s->d_avg)) return rc;
+        if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 1, s->d_amp, s->d_avg + 2 * nf)) return rc;
+        if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 1, s->d_ph, s->d_avg + 3 * nf)) return rc;
         s->have_means = true;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -218,7 +249,7 @@ int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_
     thz_ctx *ctx = s->ctx;
     if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_deconvolve: no recompute has run");
     if (int rc = use_device(ctx)) return rc;
-    const size_t npix = s->nx * s->ny, n = npix * s->nt_out;
+    const size_t npix = s->nx_cur * s->ny_cur, n = npix * s->nt_out;
     if (s->deconv_floats != n) {
         s->deconv_floats = 0;
         s->deconv_current = false;
@@ -230,7 +261,7 @@ int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_
     if (ctx->time.size() != s->nt_out)
         if (int rc = thz_set_time_axis(ctx, s->time_out.data(), s->nt_out)) return rc;
     // the stage's input is always the Time Band Pass output, never its own earlier result
-    const int rc = thz_deconvolve(ctx, psf, cfg, s->nx, s->ny, s->dx, s->dy, s->d_data, s->d_deconv, s->d_deconv_img,
+    const int rc = thz_deconvolve(ctx, psf, cfg, s->nx_cur, s->ny_cur, s->dx_cur, s->dy_cur, s->d_data, s->d_deconv, s->d_deconv_img,
                                   nullptr, abort_flag, progress);
     if (rc < 0) {  // aborted or failed: filter() hands back input.clone()
         s->deconv_current = false;
@@ -241,6 +272,16 @@ int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_
 }
 
 size_t thz_session_nt_out(const thz_session *s) { return s ? s->nt_out : 0; }
+
+int thz_session_grid(const thz_session *s, size_t *nx, size_t *ny, float *dx, float *dy)
+{
+    if (!s) return THZ_ERR_INVALID;
+    if (nx) *nx = s->nx_cur;
+    if (ny) *ny = s->ny_cur;
+    if (dx) *dx = s->dx_cur;
+    if (dy) *dy = s->dy_cur;
+    return THZ_OK;
+}
 
 int thz_session_time_out(const thz_session *s, float *time)
 {
@@ -263,7 +304,7 @@ void *thz_session_buffer(thz_session *s, int which)
     case THZ_BUF_AVG_FFT: return s->have_means ? s->d_avg : nullptr;
     case THZ_BUF_AVG_AMPLITUDES: return s->have_means ? s->d_avg + 2 * nf : nullptr;
     case THZ_BUF_AVG_PHASES: return s->have_means ? s->d_avg + 3 * nf : nullptr;
-    case THZ_BUF_OPACITY: return s->opacity_floats == s->nx * s->ny * s->nt_out ? s->d_opacity : nullptr;
+    case THZ_BUF_OPACITY: return s->opacity_floats == s->nx_cur * s->ny_cur * s->nt_out ? s->d_opacity : nullptr;
     default: return nullptr;
     }
 }
@@ -275,7 +316,7 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     const float *base = static_cast<const float *>(thz_session_buffer(s, which));
     if (!base) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_download: buffer not available");
     size_t per = 0;  // floats per pixel
-    const size_t total_pix = s->nx * s->ny;
+    const size_t total_pix = which == THZ_BUF_RAW ? s->nx * s->ny : s->nx_cur * s->ny_cur;
     switch (which) {
     case THZ_BUF_RAW: per = s->nt; break;
     case THZ_BUF_FFT: per = 2 * s->nf_out; break;
@@ -299,7 +340,7 @@ int thz_session_voxels(thz_session *s, const thz_voxel_cfg *cfg, uint64_t max_in
     if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_voxels: no recompute has run");
     if (capacity && !host_out) return fail(ctx, THZ_ERR_INVALID, "thz_session_voxels: capacity without a buffer");
     if (int rc = use_device(ctx)) return rc;
-    const size_t npix = s->nx * s->ny, nt = s->nt_out, n = npix * nt;
+    const size_t npix = s->nx_cur * s->ny_cur, nt = s->nt_out, n = npix * nt;
     if (s->opacity_floats != n) {
         s->opacity_floats = 0;
         if (int rc = dev_alloc(ctx, &s->d_opacity, n)) return rc;
@@ -312,7 +353,7 @@ int thz_session_voxels(thz_session *s, const thz_voxel_cfg *cfg, uint64_t max_in
     const float time_span = s->time_out.back() - s->time_out.front();
     thz_voxel_instance *d_inst = nullptr;
     if (capacity) HIP_TRY(ctx, hipMalloc((void **)&d_inst, capacity * sizeof(thz_voxel_instance)));
-    int rc = thz_voxel_instances(ctx, s->d_opacity, s->nx, s->ny, nt, 0, s->nx, thr, time_span, scaling, orig_w, orig_h,
+    int rc = thz_voxel_instances(ctx, s->d_opacity, s->nx_cur, s->ny_cur, nt, 0, s->nx_cur, thr, time_span, scaling, orig_w, orig_h,
                                  orig_d, d_inst, capacity, count, cube_dims);
     if (!rc && capacity) {
         const uint64_t n_copy = *count < capacity ? *count : capacity;
@@ -331,13 +372,16 @@ int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *o
     thz_ctx *ctx = s->ctx;
     if (px >= s->nx || py >= s->ny) return fail(ctx, THZ_ERR_INVALID, "thz_session_plot: pixel out of bounds");
     if (int rc = use_device(ctx)) return rc;
-    const size_t pix = px * s->ny + py;
     if (out->signal)
-        if (int rc = thz_session_download(s, THZ_BUF_RAW, pix, 1, out->signal)) return rc;
+        if (int rc = thz_session_download(s, THZ_BUF_RAW, px * s->ny + py, 1, out->signal)) return rc;
     const bool need_outputs = out->signal_fft || out->phase_fft || out->filtered_signal || out->filtered_signal_fft
                               || out->filtered_phase_fft || out->avg_signal || out->avg_signal_fft || out->avg_phase_fft;
     if (!need_outputs) return THZ_OK;
     if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_plot: no recompute has run");
+    // everything behind the scaling stage lives on the block grid: pixel / scale (a ragged edge has no block)
+    if (px / s->scale >= s->nx_cur || py / s->scale >= s->ny_cur)
+        return fail(ctx, THZ_ERR_INVALID, "thz_session_plot: pixel beyond the scaled grid");
+    const size_t pix = (px / s->scale) * s->ny_cur + py / s->scale;
     const size_t nt = s->nt_out, nf = s->nf_out;
     if (out->filtered_signal)
         if (int rc = thz_session_download(s, THZ_BUF_DATA, pix, 1, out->filtered_signal)) return rc;
@@ -357,13 +401,13 @@ int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *o
         if (out->signal_fft || out->phase_fft) {
             // the fft stage's own amplitudes / phases (no band-pass yet): one trace through K1-K3 again
             if (ctx->time.size() != nt) rc = thz_set_time_axis(ctx, s->time_out.data(), nt);
-            const float *src = (s->src_is_tilt ? s->d_tilt : s->d_raw) + pix * nt;
+            const float *src = s->d_src + pix * nt;
             if (!rc) rc = thz_fft(ctx, 1, src, s->d_vec /* pre */, nullptr, nullptr, nullptr, d_tmp, d_tmp + nf, nullptr);
             if (!rc && out->signal_fft) rc = thz_memcpy_d2h(ctx, out->signal_fft, d_tmp, nf * sizeof(float));
             if (!rc && out->phase_fft) rc = thz_memcpy_d2h(ctx, out->phase_fft, d_tmp + nf, nf * sizeof(float));
         }
         if (!rc && out->avg_signal) {
-            rc = thz_pixel_mean(ctx, s->nx, s->ny, nt, 1, final_data(s), d_tmp + 2 * nf);
+            rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nt, 1, final_data(s), d_tmp + 2 * nf);
             if (!rc) rc = thz_memcpy_d2h(ctx, out->avg_signal, d_tmp + 2 * nf, nt * sizeof(float));
         }
         (void)hipStreamSynchronize(ctx->stream);
