@@ -134,19 +134,39 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     size_t M = 1;
     while (M < nt + kDeconvTaps - 1) M <<= 1;
     PlanHost H;
-    if (M > 16384 || !build_plan(M, H, false))
+    const c32 *d_f[3] = {nullptr, nullptr, nullptr};
+    if (M > 16384 || !build_plan(M, H, true))  // with the F core's tables where M has them (band energies)
         return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
     const size_t N = M / 2, nk = N + 1;
     DevFree mem;
     c32 *d_tw = nullptr, *d_spec = nullptr, *d_H = nullptr;
     float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
     RlBand *d_bands = nullptr;
-    HIP_TRY(ctx, mem.alloc(&d_tw, (H.tw.size() + H.tw_split.size()) * sizeof(c32)));
-    HIP_TRY(ctx, hipMemcpyAsync(d_tw, H.tw.data(), H.tw.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_tw + H.tw.size(), H.tw_split.data(), H.tw_split.size() * sizeof(c32),
-                                hipMemcpyHostToDevice, ctx->stream));
-    const PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
-
+    {
+        std::vector<c32> pack(H.tw);
+        pack.insert(pack.end(), H.tw_split.begin(), H.tw_split.end());
+        const bool f = H.family == kFamilyF && !H.f_t1.empty();
+        const size_t o1 = pack.size();
+        if (f) pack.insert(pack.end(), H.f_t1.begin(), H.f_t1.end());
+        const size_t o2 = pack.size();
+        if (f) pack.insert(pack.end(), H.f_t2.begin(), H.f_t2.end());
+        const size_t o3 = pack.size();
+        if (f) pack.insert(pack.end(), H.f_w2n.begin(), H.f_w2n.end());
+        HIP_TRY(ctx, mem.alloc(&d_tw, pack.size() * sizeof(c32)));
+        HIP_TRY(ctx, hipMemcpyAsync(d_tw, pack.data(), pack.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack goes out of scope
+        H.f_t1.clear();  // offsets only from here on
+        H.f_t2.clear();
+        H.f_w2n.clear();
+        // the transform kernels of this call are the generic (LDS) ones; only the tables ride along
+        d_f[0] = f ? d_tw + o1 : nullptr;
+        d_f[1] = f ? d_tw + o2 : nullptr;
+        d_f[2] = f ? d_tw + o3 : nullptr;
+    }
+    PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
+    P.f_t1 = d_f[0];
+    P.f_t2 = d_f[1];
+    P.f_w2n = d_f[2];
     tick("plan, twiddles");
     // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double, for the bands of
     // this call (band-parallel multi-GPU: cfg->band_begin/band_end select a subset of the bank)
