@@ -28,6 +28,11 @@ def _bar_target_cube(nx, ny, nt):
 @pytest.mark.parametrize("case", [
     dict(nx=32, ny=32, nt=256, dx=0.5, dy=0.5, n_iter=20, n_filters=6, f0=0.4, f1=3.0, mode=0),
     dict(nx=48, ny=40, nt=128, dx=1.0, dy=1.0, n_iter=12, n_filters=4, f0=0.25, f1=2.0, mode=1),
+    # the FIR transform length M = next_pow2(nt + 498) picks the kernels: 1024 above, 2048 and 4096 (both
+    # on the register-resident core) and 8192 (generic LDS transform) here
+    dict(nx=20, ny=18, nt=1001, dx=0.5, dy=0.5, n_iter=6, n_filters=5, f0=0.4, f1=3.0, mode=0),
+    dict(nx=18, ny=20, nt=2000, dx=0.5, dy=0.5, n_iter=6, n_filters=4, f0=0.4, f1=3.0, mode=0),
+    dict(nx=16, ny=17, nt=4000, dx=0.5, dy=0.5, n_iter=4, n_filters=3, f0=0.4, f1=3.0, mode=0),
 ])
 def test_deconvolution_vs_oracle(engine, case):
     z = np.load(os.path.join(GOLD, "psf_sample.npz"))

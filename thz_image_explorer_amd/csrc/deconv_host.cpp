@@ -100,7 +100,19 @@ static double bessel_i0(double x)
     return sum;
 }
 
-static void lowpass(int n_taps, double cutoff_hz, double beta, double fs, double *out)
+// Kaiser window of the design, w[n] = I0(beta sqrt(1 - arg^2)) / I0(beta) with zero end points as the
+// reference writes it: it depends on (taps, beta) only, so a bank evaluates it once instead of once
+// per cut-off (the Bessel series was 1.3 of the 1.5 ms a call spent designing its 25 filters).
+static void kaiser_window(int adj, double beta, std::vector<double> &win)
+{
+    win.assign((size_t)adj, 0.0);
+    for (int n = 1; n + 1 < adj; ++n) {
+        const double arg = 2.0 * (double)n / ((double)adj - 1.0) - 1.0;
+        win[(size_t)n] = bessel_i0(beta * std::sqrt(1.0 - arg * arg)) / bessel_i0(beta);
+    }
+}
+
+static void lowpass(int n_taps, double cutoff_hz, const std::vector<double> &win, double fs, double *out)
 {
     const int adj = (n_taps % 2 == 0) ? n_taps - 1 : n_taps;
     const double mid = (double)(adj - 1) / 2.0;
@@ -109,12 +121,7 @@ static void lowpass(int n_taps, double cutoff_hz, double beta, double fs, double
     for (int n = 0; n < adj; ++n) {
         const double a = 2.0 * kPi * cutoff * ((double)n - mid);
         const double sinc = std::fabs(a) < 1e-10 ? 1.0 : std::sin(a) / a;
-        double win = 0.0;
-        if (n != 0 && n != adj - 1) {
-            const double arg = 2.0 * (double)n / ((double)adj - 1.0) - 1.0;
-            win = bessel_i0(beta * std::sqrt(1.0 - arg * arg)) / bessel_i0(beta);
-        }
-        out[n] = sinc * win;
+        out[n] = sinc * win[(size_t)n];
         sum += out[n];
     }
     if (std::fabs(sum) > 1e-10)
@@ -122,11 +129,11 @@ static void lowpass(int n_taps, double cutoff_hz, double beta, double fs, double
     if (n_taps % 2 == 0) out[adj] = 0.0;
 }
 
-static void highpass(int n_taps, double cutoff_hz, double beta, double fs, double *out)
+static void highpass(int n_taps, double cutoff_hz, const std::vector<double> &win, double fs, double *out)
 {
     const int adj = (n_taps % 2 == 0) ? n_taps - 1 : n_taps;
     const int mid = (int)((double)(adj - 1) / 2.0);
-    lowpass(adj, cutoff_hz, beta, fs, out);
+    lowpass(adj, cutoff_hz, win, fs, out);
     for (int i = 0; i < adj; ++i) out[i] = (i == mid) ? 1.0 - out[i] : -out[i];
     if (n_taps % 2 == 0) out[adj] = 0.0;
 }
@@ -143,18 +150,19 @@ void filter_bank(int n_filters, double start_freq, double end_freq, double win_w
     for (int i = 0; i < n_filters; ++i) centers[(size_t)i] = (float)std::exp(log_start + (double)i * log_step);
     filters.assign((size_t)n_filters * ntaps, 0.0f);
     const double beta = kaiser_beta_for(ntaps, win_width / (0.5 * fs));
-    std::vector<double> h((size_t)ntaps), h2((size_t)ntaps);
+    std::vector<double> h((size_t)ntaps), h2((size_t)ntaps), win;
+    kaiser_window((ntaps % 2 == 0) ? ntaps - 1 : ntaps, beta, win);
     for (int i = 0; i < n_filters; ++i) {
         const double cf = (double)centers[(size_t)i];
         const double lowcut = (i == 0) ? 0.0 : std::sqrt((double)centers[(size_t)i - 1] * cf);
         const double highcut = (i == n_filters - 1) ? 0.5 * fs : std::sqrt(cf * (double)centers[(size_t)i + 1]);
         if (lowcut <= 0.0) {
-            lowpass(ntaps, highcut, beta, fs, h.data());
+            lowpass(ntaps, highcut, win, fs, h.data());
         } else if (highcut >= 0.5 * fs) {
-            highpass(ntaps, lowcut, beta, fs, h.data());
+            highpass(ntaps, lowcut, win, fs, h.data());
         } else {
-            highpass(ntaps, lowcut, beta, fs, h.data());
-            highpass(ntaps, highcut, beta, fs, h2.data());
+            highpass(ntaps, lowcut, win, fs, h.data());
+            highpass(ntaps, highcut, win, fs, h2.data());
             for (int j = 0; j < ntaps; ++j) h[(size_t)j] -= h2[(size_t)j];
         }
         for (int j = 0; j < ntaps; ++j) filters[(size_t)i * ntaps + j] = (float)h[(size_t)j];

@@ -1800,6 +1800,107 @@ void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const 
     THZ_LAUNCH(k_dc_fft, grid, block, lds, st, P, npix, nt, in, spec);
 }
 
+// The recombination on the F core: per pixel the gain-weighted sum of the filter spectra is built in
+// registers (bin by bin in the spectrum's register layout), multiplied into the spectrum, and ONE
+// inverse transform gives the "same" slice of the output trace and its intensity.
+template <class PL>
+__global__ __launch_bounds__(512) void k_dc_combine_f(FTables T, size_t npix, int nt, int n_bands, int shift,
+                                                      const cx *__restrict__ spec, const cx *__restrict__ H,
+                                                      const float *__restrict__ gain, float *__restrict__ out,
+                                                      float *__restrict__ img)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int N = PL::N, R1 = PL::R1, C1 = PL::C1;
+    const int nf = N + 1;
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + PL::T1_ENTRIES;
+    cx *w2n_s = t2 + PL::T2_ENTRIES;
+    cx *wg_s = w2n_s + PL::W2N_HEAD;
+    cx *buf = wg_s + PL::WG_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
+    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = T.w2n[i];
+    if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[PL::M1 * (int)threadIdx.x];
+    for (int i = (int)threadIdx.x; i < PL::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < PL::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    __syncthreads();
+    FAddr<PL> ad;
+    ad.init(lane);
+    const int s2 = (lane >> 4) & 3;
+    const int sb2 = (2 * lane) ^ (s2 & 2);
+    const bool swap2 = (s2 & 1) != 0;
+    const int sb1a = nat(lane), sb1b = nat(kWave + lane) - kWave;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        float hc[R1][2 * C1], hs[R1][2 * C1];
+#pragma unroll
+        for (int j = 0; j < R1; ++j)
+#pragma unroll
+            for (int i = 0; i < 2 * C1; ++i) hc[j][i] = 0.0f;
+        float hc_nyq = 0.0f;
+        f_load_spec<PL>(H, lane, hs);
+        float h_nyq = H[N].x;
+#pragma unroll 1
+        for (int b = 0; b < n_bands; ++b) {
+            const float g = gain[(size_t)b * npix + p];
+#pragma unroll
+            for (int j = 0; j < R1; ++j)
+#pragma unroll
+                for (int i = 0; i < 2 * C1; ++i) hc[j][i] += g * hs[j][i];
+            hc_nyq += g * h_nyq;
+            if (b + 1 < n_bands) {
+                f_load_spec<PL>(H + (size_t)(b + 1) * nf, lane, hs);
+                h_nyq = H[(size_t)(b + 1) * nf + N].x;
+            }
+        }
+        f_load_spec<PL>(spec + p * nf, lane, hs);  // the pixel's spectrum
+        const float x_nyq = spec[p * nf + N].x;
+        ad.refresh();
+#pragma unroll
+        for (int j = 0; j < R1; ++j) {
+            if constexpr (C1 == 2) {
+                const cx e0 = cx_mul(cx{hs[j][0], hs[j][1]}, cx{hc[j][0], hc[j][1]});
+                const cx e1 = cx_mul(cx{hs[j][2], hs[j][3]}, cx{hc[j][2], hc[j][3]});
+                st2(buf + sb2 + 2 * kWave * j, swap2 ? e1 : e0, swap2 ? e0 : e1);
+            } else {
+                buf[((j & 1) ? sb1b : sb1a) + kWave * j] = cx_mul(cx{hs[j][0], hs[j][1]}, cx{hc[j][0], hc[j][1]});
+            }
+        }
+        if (lane == 0) buf[N] = cx{x_nyq * hc_nyq, 0.0f};
+        wave_sync();
+        cx r[C1][R1];
+        f_inverse_input<PL, false>(buf, w2n_s, wg_s, nullptr, lane, r);
+        wave_sync();
+        f_core_pass1<PL>(r, buf, t1, ad, lane);
+        f_core_pass23<PL>(buf, t2, ad, lane);
+        float acc = 0.0f;
+        float *o = out + p * (size_t)nt;
+#pragma unroll
+        for (int j = 0; j < R1; ++j) {
+            float v[2 * C1];
+            if constexpr (C1 == 2) {
+                const cx2 rr = ld2(buf + sb2 + 2 * kWave * j);
+                const cx e0 = swap2 ? rr.b : rr.a, e1 = swap2 ? rr.a : rr.b;
+                v[0] = e0.y; v[1] = e0.x; v[2] = e1.y; v[3] = e1.x;
+            } else {
+                const cx rr = buf[((j & 1) ? sb1b : sb1a) + kWave * j];
+                v[0] = rr.y; v[1] = rr.x;
+            }
+            const int t0 = 2 * C1 * (kWave * j + lane) - shift;
+#pragma unroll
+            for (int i = 0; i < 2 * C1; ++i)
+                if (t0 + i >= 0 && t0 + i < nt) {
+                    o[t0 + i] = v[i];
+                    acc += v[i] * v[i];
+                }
+        }
+        if (img) {
+            acc = wave_reduce_add(acc);
+            if (lane == 0) img[p] = acc;
+        }
+        wave_sync();
+    }
+}
+
 template <class PL>
 static void launch_dc_energy_f(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                                const c32 *spec, const c32 *H, float *energy)
@@ -1837,9 +1938,36 @@ void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int
     THZ_LAUNCH(k_dc_energy, grid, block, lds, st, P, npix, nt, n_bands, shift, spec, H, energy);
 }
 
+template <class PL>
+static void launch_dc_combine_f(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
+                                const c32 *spec, const c32 *H, const float *gain, float *out, float *img)
+{
+    const unsigned wpb = 8;
+    const size_t lds = (size_t)(PL::T1_ENTRIES + PL::T2_ENTRIES + PL::W2N_HEAD + PL::WG_ENTRIES + wpb * PL::WAVE_ENTRIES)
+                       * sizeof(cx);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    size_t g = (npix + wpb - 1) / wpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
+              reinterpret_cast<const cx *>(P.f_w2n)};
+    allow_dynamic_lds(k_dc_combine_f<PL>, lds);
+    THZ_LAUNCH((k_dc_combine_f<PL>), (unsigned)g, wpb * kWave, lds, st, T, npix, nt, n_bands, shift,
+               reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), gain, out, img);
+}
+
 void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                        const c32 *spec, const c32 *H, const float *gain, float *out, float *img)
 {
+    if (P.f_t1 && P.f_t2 && P.f_w2n && nt + shift <= P.nt) {
+        switch (P.nt) {
+        case 4096: launch_dc_combine_f<FPlan4096>(st, P, npix, nt, n_bands, shift, spec, H, gain, out, img); return;
+        case 2048: launch_dc_combine_f<FPlan2048>(st, P, npix, nt, n_bands, shift, spec, H, gain, out, img); return;
+        case 1024: launch_dc_combine_f<FPlan1024>(st, P, npix, nt, n_bands, shift, spec, H, gain, out, img); return;
+        default: break;
+        }
+    }
     unsigned grid, block;
     size_t lds;
     dc_geometry(P, npix, 3, &grid, &block, &lds);
