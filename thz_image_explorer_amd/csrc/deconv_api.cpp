@@ -248,7 +248,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     std::vector<RlTileRef> tiles(tblk);
     for (int b = 0; b < nbs; ++b)
         for (unsigned t = bands[(size_t)b].tblk0; t < (b + 1 < nbs ? bands[(size_t)b + 1].tblk0 : tblk); ++t)
-            tiles[t] = RlTileRef{b, bands[(size_t)b].n_iter};
+            tiles[t] = RlTileRef{bands[(size_t)b]};
     RlTileRef *d_tiles = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_tiles, tiles.size() * sizeof(RlTileRef)));
     HIP_TRY(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RlTileRef), hipMemcpyHostToDevice, ctx->stream));
@@ -276,8 +276,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     if (tiled) prepare_rl_step_tiled(tile_lds);
     auto enqueue = [&](const int *it_base, int it) {
         if (tiled) {
-            launch_rl_step_tiled(ctx->stream, d_bands, d_tiles, tblk, tile_lds, it_base, it, 0, d_ws);
-            launch_rl_step_tiled(ctx->stream, d_bands, d_tiles, tblk, tile_lds, it_base, it, 1, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_tiles, tblk, tile_lds, it_base, it, 0, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_tiles, tblk, tile_lds, it_base, it, 1, d_ws);
         } else {
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 0, d_ws);
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 1, d_ws);

@@ -1195,19 +1195,16 @@ __host__ __device__ inline size_t rl_tap_floats(int pr, int pc)
 }
 __host__ __device__ inline bool rl_turned(int pr, int pc) { return pr * pc > 256; }  // RlBand::mode == 1
 
-__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlBand *__restrict__ bands,
-                                                              const RlTileRef *__restrict__ tiles,
+__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
                                                               const int *__restrict__ it_base, int iteration,
                                                               int step, float *__restrict__ ws)
 {
     THZ_DYN_LDS(smem);
     if (it_base) iteration += *it_base;
-    // which band this tile belongs to, and whether that band still iterates: one scalar load from the
-    // per-tile table, so that the tiles of finished bands (most of the grid, most of the time) leave
-    // after a single memory latency
-    const RlTileRef T = tiles[blockIdx.x];
-    if (iteration >= T.n_iter) return;  // block-uniform
-    const RlBand B = bands[T.band];
+    // the tile's band record, by value in the per-tile table: the tiles of finished bands (most of the
+    // grid, most of the time) leave after a single memory latency
+    const RlBand B = tiles[blockIdx.x].band;
+    if (iteration >= B.n_iter) return;  // block-uniform
     const unsigned lt = blockIdx.x - B.tblk0;
     const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
     const int pr = B.pr, pc = B.pc;
@@ -1995,10 +1992,10 @@ size_t rl_tile_lds_bytes(int pr, int pc)
 
 void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
 
-void launch_rl_step_tiled(hipStream_t st, const RlBand *d_bands, const RlTileRef *d_tiles, unsigned total_tiles,
-                          size_t lds_bytes, const int *it_base, int iteration, int step, float *ws)
+void launch_rl_step_tiled(hipStream_t st, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
+                          const int *it_base, int iteration, int step, float *ws)
 {
-    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_bands, d_tiles, it_base, iteration, step, ws);
+    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
