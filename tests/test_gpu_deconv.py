@@ -156,3 +156,33 @@ def test_deconvolution_abort_and_progress(engine):
     assert np.abs(d_out.download((nx, ny, nt), np.float32) - cube).max() > 0
     for b in (d_in, d_out, d_img):
         b.free()
+
+
+def test_untiled_fallback_matches_tiled(engine, monkeypatch):
+    """PSFs too wide for an LDS tile take k_rl_step (every tap from L2); forced here with the developer knob:
+    narrow kernels (the reference's direct sums) must agree bit for bit, wide ones within rounding"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    for case in (dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 4, 0.8, 3.0, 0.5), exact=True),
+                 dict(nx=48, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5), exact=False)):
+        nx, ny, nt = case["nx"], case["ny"], case["nt"]
+        time, cube = _bar_target_cube(nx, ny, nt)
+        sizes = [pkg.host_band_psf(psf, f, case["d"], case["d"], nx, ny).size
+                 for f in pkg.host_filter_bank(time, case["cfg"])[1]]
+        assert (max(sizes) <= 256) == case["exact"]
+        engine.set_time_axis(time)
+        d_in = engine.to_device(cube); d_out = engine.empty((nx * ny, nt))
+        outs = []
+        for knob in (None, "1"):
+            if knob:
+                monkeypatch.setenv("THZ_NO_TILE", knob)
+            else:
+                monkeypatch.delenv("THZ_NO_TILE", raising=False)
+            assert engine.deconvolve(psf, case["cfg"], nx, ny, case["d"], case["d"], d_in, d_out) == 0
+            outs.append(d_out.download((nx, ny, nt), np.float32))
+        monkeypatch.delenv("THZ_NO_TILE", raising=False)
+        if case["exact"]:
+            assert np.array_equal(outs[0], outs[1])
+        else:
+            assert np.abs(outs[0] - outs[1]).max() / np.abs(outs[1]).max() < 1e-5
+        d_in.free(); d_out.free()

@@ -272,7 +272,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // batches.  Bands that have finished return at once (iteration >= n_iter), which also covers
     // the tail of the last batch.  The abort flag is polled between batches.
     constexpr int kRlBatch = 32;
-    const bool tiled = tile_lds <= (size_t)150 * 1024;  // image tile + halo + PSF fit in LDS
+    // image tile + halo + taps fit in LDS (THZ_NO_TILE: developer knob, forces the fallback for tests)
+    const bool tiled = tile_lds <= (size_t)150 * 1024 && !getenv("THZ_NO_TILE");
     if (tiled) prepare_rl_step_tiled(tile_lds);
     auto enqueue = [&](const int *it_base, int it) {
         if (tiled) {
