@@ -569,8 +569,8 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
         }
         if constexpr (want_phase) {
             float ph[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ph[c] = fast_atan2f(X[c].y, X[c].x);
+            fast_atan2f_x2(X[0].y, X[0].x, X[1].y, X[1].x, ph[0], ph[1]);
+            fast_atan2f_x2(X[2].y, X[2].x, X[3].y, X[3].x, ph[2], ph[3]);
             if (g == 0) first = wave_bcast<0>(ph[0]);
             float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;

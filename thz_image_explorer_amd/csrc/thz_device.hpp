@@ -136,26 +136,67 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // 1 ulp
 #endif
 
-// atan2f to ~2e-7 rad: octant reduction to a = min/max in [0,1], the Cephes atanf
-// second reduction t = (a-1)/(a+1) for a > tan(pi/8), degree-4 polynomial in t^2.
-// atan2(0, 0) = 0 (num_complex::arg's atan2 gives 0 or pi depending on the
-// sign of zero; bins that are exactly zero carry no phase information).
-__device__ __forceinline__ float fast_atan2f(float y, float x)
+// atan2f to ~3e-7 rad: octant reduction to a = min/max in [0,1], then ONE odd polynomial
+// a * P(a^2) over the whole octant (degree 7 in a^2, Chebyshev-node fit of atan(sqrt z)/sqrt z on
+// [0,1]: 6e-8 in exact arithmetic).  The Cephes form it replaces had a second range reduction
+// t = (a-1)/(a+1) — a compare, two adds, two selects and a second reciprocal, which on CDNA costs four
+// issue slots by itself — in front of a degree-4 polynomial; three more FMAs are cheaper, and the
+// polynomial of two bins at a time is packed math (fast_atan2f_x2).
+// atan2(0, 0) = 0 (num_complex::arg's atan2 gives 0 or pi depending on the sign of zero; bins
+// that are exactly zero carry no phase information).
+#define THZ_ATAN_C0 9.999998808e-01f
+#define THZ_ATAN_C1 -3.333181143e-01f
+#define THZ_ATAN_C2 1.996696144e-01f
+#define THZ_ATAN_C3 -1.400329024e-01f
+#define THZ_ATAN_C4 9.868865460e-02f
+#define THZ_ATAN_C5 -5.882975459e-02f
+#define THZ_ATAN_C6 2.378051914e-02f
+#define THZ_ATAN_C7 -4.559792113e-03f
+
+// a = min(|x|,|y|) / max(|x|,|y|) in [0, 1]; 0 for x = y = 0 (0 * rcp(tiny) = 0)
+__device__ __forceinline__ float atan_octant_ratio(float x, float y)
 {
     const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float a = mn * fast_rcp(mx);
-    if (!(mx > 0.0f)) a = 0.0f;  // 0/0
-    const bool hi = a > 0.41421356237309503f;
-    const float t = hi ? (a - 1.0f) * fast_rcp(a + 1.0f) : a;
-    const float z = t * t;
-    float r = fmaf(fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z,
-                        -3.33329491539e-1f) * z,
-                   t, t);
-    r += hi ? 0.78539816339744831f : 0.0f;
-    r = (ay > ax) ? 1.57079632679489662f - r : r;
+    return fminf(ax, ay) * fast_rcp(fmaxf(fmaxf(ax, ay), 1e-37f));
+}
+// from atan(a) of the octant back to the angle of (x, y)
+__device__ __forceinline__ float atan_unfold(float r, float y, float x)
+{
+    r = (fabsf(y) > fabsf(x)) ? 1.57079632679489662f - r : r;
     r = (x < 0.0f) ? 3.14159265358979324f - r : r;
     return copysignf(r, y);
+}
+
+__device__ __forceinline__ float fast_atan2f(float y, float x)
+{
+    const float a = atan_octant_ratio(x, y);
+    const float z = a * a;
+    float p = fmaf(THZ_ATAN_C7, z, THZ_ATAN_C6);
+    p = fmaf(p, z, THZ_ATAN_C5);
+    p = fmaf(p, z, THZ_ATAN_C4);
+    p = fmaf(p, z, THZ_ATAN_C3);
+    p = fmaf(p, z, THZ_ATAN_C2);
+    p = fmaf(p, z, THZ_ATAN_C1);
+    p = fmaf(p, z, THZ_ATAN_C0);
+    return atan_unfold(p * a, y, x);
+}
+
+// two angles at once: same values as two fast_atan2f calls, the polynomial as v_pk_fma_f32
+typedef float thz_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fast_atan2f_x2(float y0, float x0, float y1, float x1, float &r0, float &r1)
+{
+    const thz_f2 a = {atan_octant_ratio(x0, y0), atan_octant_ratio(x1, y1)};
+    const thz_f2 z = a * a;
+    thz_f2 p = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C5, THZ_ATAN_C5});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C4, THZ_ATAN_C4});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C3, THZ_ATAN_C3});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C2, THZ_ATAN_C2});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C1, THZ_ATAN_C1});
+    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C0, THZ_ATAN_C0});
+    const thz_f2 r = p * a;
+    r0 = atan_unfold(r.x, y0, x0);
+    r1 = atan_unfold(r.y, y1, x1);
 }
 
 struct alignas(8) c32 {
