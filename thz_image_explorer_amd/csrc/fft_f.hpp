@@ -569,9 +569,16 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
         }
         if constexpr (want_phase) {
             float ph[4];
-            fast_atan2f_x2(X[0].y, X[0].x, X[1].y, X[1].x, ph[0], ph[1]);
-            fast_atan2f_x2(X[2].y, X[2].x, X[3].y, X[3].x, ph[2], ph[3]);
-            if (g == 0) first = wave_bcast<0>(ph[0]);
+            {
+                const float yy[4] = {X[0].y, X[1].y, X[2].y, X[3].y}, xx[4] = {X[0].x, X[1].x, X[2].x, X[3].x};
+                fast_atan2f_x4(yy, xx, ph);
+            }
+            {
+                // unconditional read + select: a branch here splits the block between the two packed
+                // chains of the arctangent and they end up one after the other again
+                const float lane0 = wave_bcast<0>(ph[0]);
+                first = g == 0 ? lane0 : first;
+            }
             float prev = wave_shr1(ph[3]);
             if (lane == 0) prev = prev_tail;
             float s_[4];

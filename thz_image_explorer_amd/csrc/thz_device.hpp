@@ -181,22 +181,33 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
     return atan_unfold(p * a, y, x);
 }
 
-// two angles at once: same values as two fast_atan2f calls, the polynomial as v_pk_fma_f32
+// four angles at once: same values as four fast_atan2f calls.  The polynomial runs as two packed
+// Horner chains written side by side: a dependent v_pk_fma_f32 needs a wait state after its
+// producer, and the compiler, left with two calls of a two-angle routine, emitted one chain after
+// the other with an s_nop behind every step.
 typedef float thz_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void fast_atan2f_x2(float y0, float x0, float y1, float x1, float &r0, float &r1)
+__device__ __forceinline__ void fast_atan2f_x4(const float (&y)[4], const float (&x)[4], float (&r)[4])
 {
-    const thz_f2 a = {atan_octant_ratio(x0, y0), atan_octant_ratio(x1, y1)};
-    const thz_f2 z = a * a;
-    thz_f2 p = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C5, THZ_ATAN_C5});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C4, THZ_ATAN_C4});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C3, THZ_ATAN_C3});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C2, THZ_ATAN_C2});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C1, THZ_ATAN_C1});
-    p = __builtin_elementwise_fma(p, z, thz_f2{THZ_ATAN_C0, THZ_ATAN_C0});
-    const thz_f2 r = p * a;
-    r0 = atan_unfold(r.x, y0, x0);
-    r1 = atan_unfold(r.y, y1, x1);
+    const thz_f2 a0 = {atan_octant_ratio(x[0], y[0]), atan_octant_ratio(x[1], y[1])};
+    const thz_f2 a1 = {atan_octant_ratio(x[2], y[2]), atan_octant_ratio(x[3], y[3])};
+    const thz_f2 z0 = a0 * a0, z1 = a1 * a1;
+    thz_f2 p0 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z0, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
+    thz_f2 p1 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z1, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
+#define THZ_ATAN_STEP(C)                                            \
+    p0 = __builtin_elementwise_fma(p0, z0, thz_f2{C, C});           \
+    p1 = __builtin_elementwise_fma(p1, z1, thz_f2{C, C});
+    THZ_ATAN_STEP(THZ_ATAN_C5)
+    THZ_ATAN_STEP(THZ_ATAN_C4)
+    THZ_ATAN_STEP(THZ_ATAN_C3)
+    THZ_ATAN_STEP(THZ_ATAN_C2)
+    THZ_ATAN_STEP(THZ_ATAN_C1)
+    THZ_ATAN_STEP(THZ_ATAN_C0)
+#undef THZ_ATAN_STEP
+    const thz_f2 r0 = p0 * a0, r1 = p1 * a1;
+    r[0] = atan_unfold(r0.x, y[0], x[0]);
+    r[1] = atan_unfold(r0.y, y[1], x[1]);
+    r[2] = atan_unfold(r1.x, y[2], x[2]);
+    r[3] = atan_unfold(r1.y, y[3], x[3]);
 }
 
 struct alignas(8) c32 {
