@@ -337,23 +337,33 @@ __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr
 }
 
 // --------------------------------------------------------- R2C / C2R algebra
-// X[k] and conj(X[N-k]) from Z[k], Z[N-k]  (w = exp(-i*pi*k/N))
-__device__ __forceinline__ void r2c_pair(cx a, cx b, cx w, cx &xk, cx &xnk_conj)
+// Both directions take the split twiddle as w2 = -(i/2) w, w = exp(-i*pi*k/N): the kernels fold the
+// factor into the per-lane table when they stage it in LDS (f_stage_w2n).  With
+//   s = Z[k] + conj(Z[N-k]),  d = Z[k] - conj(Z[N-k])
+// the forward split is  X[k] = s/2 + d w2,  conj(X[N-k]) = s/2 - d w2  — two packed adds, one complex
+// multiply and two packed FMAs; written with E = s/2, O = -(i/2) d as before, the rotation by -i cost
+// a move and a sign flip per bin pair on top (the compiler does not fold a swap-and-negate into the
+// consumer's op_sel/neg modifiers).  The products are the same real products; only which of the two
+// is rounded before the fused add changes.
+__device__ __forceinline__ cx f_stage_w2n(cx w) { return cx{0.5f * w.y, -0.5f * w.x}; }
+
+__device__ __forceinline__ void r2c_pair(cx a, cx b, cx w2, cx &xk, cx &xnk_conj)
 {
-    const cx E = cx{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
-    const cx O = cx{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
-    const cx t = cx_mul(O, w);
-    xk = (E + t);
-    xnk_conj = (E - t);
+    const cx bc = cx_conj(b);
+    const cx s = a + bc, d = a - bc;
+    const cx t = cx_mul(d, w2);
+    const cx h = {0.5f, 0.5f};
+    xk = __builtin_elementwise_fma(s, h, t);
+    xnk_conj = __builtin_elementwise_fma(s, h, -t);
 }
 
-// Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k])
-__device__ __forceinline__ cx c2r_elem(cx xk, cx xnk_conj, cx w)
+// Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k]):  E + i (D conj(w)) = E + 2 D conj(w2)
+__device__ __forceinline__ cx c2r_elem(cx xk, cx xnk_conj, cx w2)
 {
     const cx E = (xk + xnk_conj);
     const cx D = (xk - xnk_conj);
-    const cx O = cx{D.x * w.x + D.y * w.y, D.y * w.x - D.x * w.y};  // D * conj(w)
-    return cx{E.x - O.y, E.y + O.x};
+    const cx t = cx_mul(D, cx_conj(w2));
+    return __builtin_elementwise_fma(t, cx{2.0f, 2.0f}, E);
 }
 
 }  // namespace thz
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     cx *wg_s = w2n_s + P::W2N_HEAD;
     float *win_s = reinterpret_cast<float *>(wg_s + P::WG_ENTRIES);
     cx *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + P::EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
-    for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = T.w2n[i];
+    for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[P::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];

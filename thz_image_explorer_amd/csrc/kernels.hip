@@ -826,7 +826,7 @@ __global__ __launch_bounds__(512) void k_dc_energy_f(FTables T, size_t npix, int
     cx *w2n_s = t2 + PL::T2_ENTRIES;
     cx *wg_s = w2n_s + PL::W2N_HEAD;
     cx *buf = wg_s + PL::WG_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
-    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = T.w2n[i];
+    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[PL::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < PL::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < PL::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
@@ -1816,7 +1816,7 @@ __global__ __launch_bounds__(512) void k_dc_combine_f(FTables T, size_t npix, in
     cx *w2n_s = t2 + PL::T2_ENTRIES;
     cx *wg_s = w2n_s + PL::W2N_HEAD;
     cx *buf = wg_s + PL::WG_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
-    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = T.w2n[i];
+    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[PL::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < PL::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < PL::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
