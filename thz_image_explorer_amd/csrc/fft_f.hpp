@@ -341,20 +341,22 @@ __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr
 // factor into the per-lane table when they stage it in LDS (f_stage_w2n).  With
 //   s = Z[k] + conj(Z[N-k]),  d = Z[k] - conj(Z[N-k])
 // the forward split is  X[k] = s/2 + d w2,  conj(X[N-k]) = s/2 - d w2  — two packed adds, one complex
-// multiply and two packed FMAs; written with E = s/2, O = -(i/2) d as before, the rotation by -i cost
+// multiply and four FMAs; written with E = s/2, O = -(i/2) d as before, the rotation by -i cost
 // a move and a sign flip per bin pair on top (the compiler does not fold a swap-and-negate into the
 // consumer's op_sel/neg modifiers).  The products are the same real products; only which of the two
 // is rounded before the fused add changes.
 __device__ __forceinline__ cx f_stage_w2n(cx w) { return cx{0.5f * w.y, -0.5f * w.x}; }
 
-__device__ __forceinline__ void r2c_pair(cx a, cx b, cx w2, cx &xk, cx &xnk_conj)
+// Written on p = a + b, m = a - b (s = {p.x, m.y}, d = {m.x, p.y}): the conjugate never exists as a
+// value, the multiply takes its splats straight from p and m, and X[N-k] comes out unconjugated —
+// a conj() of a packed value is a negate plus a move here, as is building {b.x, -b.y}.
+__device__ __forceinline__ void r2c_pair(cx a, cx b, cx w2, cx &xk, cx &xn)
 {
-    const cx bc = cx_conj(b);
-    const cx s = a + bc, d = a - bc;
-    const cx t = cx_mul(d, w2);
-    const cx h = {0.5f, 0.5f};
-    xk = __builtin_elementwise_fma(s, h, t);
-    xnk_conj = __builtin_elementwise_fma(s, h, -t);
+    const cx p = a + b, m = a - b;
+    const cx bs = {-w2.y, w2.x};
+    const cx t = m.xx * w2 + p.yy * bs;  // d * w2
+    xk = cx{fmaf(p.x, 0.5f, t.x), fmaf(m.y, 0.5f, t.y)};
+    xn = cx{fmaf(p.x, 0.5f, -t.x), fmaf(-m.y, 0.5f, t.y)};  // conj(s/2 - t)
 }
 
 // Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k]):  E + i (D conj(w)) = E + 2 D conj(w2)
@@ -544,11 +546,12 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const cx a = zf[fb[c]], b = zm[mb[c]];
-                cx xk, xnc;
-                r2c_pair(a, b, g == 0 ? wl[c] : cx_mul(wl[c], wg), xk, xnc);
+                cx xk, xn;
+                // g = 0: wg = w2n[0] = (1, 0) and the product is wl[c] itself — no select needed
+                r2c_pair(a, b, cx_mul(wl[c], wg), xk, xn);
                 X[c] = xk;
-                zf[fb[c]] = xk;          // X[k]
-                zm[mb[c]] = cx_conj(xnc);  // X[N-k]  (k = 0: buf[N] = X[N], and X[0] over Z[0])
+                zf[fb[c]] = xk;  // X[k]
+                zm[mb[c]] = xn;  // X[N-k]  (k = 0: buf[N] = X[N], and X[0] over Z[0])
             }
             if (g == NG / 2 - 1) {
                 // the one bin without a partner: X[N/2] = conj(Z[N/2]); every lane has
