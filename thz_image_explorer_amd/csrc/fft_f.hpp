@@ -359,13 +359,16 @@ __device__ __forceinline__ void r2c_pair(cx a, cx b, cx w2, cx &xk, cx &xn)
     xn = cx{fmaf(p.x, 0.5f, -t.x), fmaf(-m.y, 0.5f, t.y)};  // conj(s/2 - t)
 }
 
-// Z'[k] (unnormalised C2R input) from X[k] and conj(X[N-k]):  E + i (D conj(w)) = E + 2 D conj(w2)
-__device__ __forceinline__ cx c2r_elem(cx xk, cx xnk_conj, cx w2)
+// swap(Z'[k]) — the inverse core takes its input with re/im exchanged — from X[k], X[N-k] (as stored,
+// unconjugated) and wc = conj(w2):  Z' = E + i (D conj(w)) = E + 2 D wc  with E = {p.x, m.y},
+// D = {m.x, p.y}, p = X[k] + X[N-k], m = X[k] - X[N-k].  Same idea as r2c_pair: no conjugate is ever
+// built, and the two FMAs write the exchanged pair directly.
+__device__ __forceinline__ cx c2r_swapped(cx xk, cx xn, cx wc)
 {
-    const cx E = (xk + xnk_conj);
-    const cx D = (xk - xnk_conj);
-    const cx t = cx_mul(D, cx_conj(w2));
-    return __builtin_elementwise_fma(t, cx{2.0f, 2.0f}, E);
+    const cx p = xk + xn, m = xk - xn;
+    const cx bs = {-wc.y, wc.x};
+    const cx t = m.xx * wc + p.yy * bs;  // D * wc
+    return cx{fmaf(2.0f, t.y, m.y), fmaf(2.0f, t.x, p.x)};
 }
 
 }  // namespace thz
@@ -645,9 +648,9 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
                                                 cx (&r)[P::C1][P::R1])
 {
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
-    cx wl[C1];
+    cx wlc[C1];  // conj of the lane's staged twiddles: the product below is conj(w2) directly
 #pragma unroll
-    for (int c = 0; c < C1; ++c) wl[c] = w2n_s[C1 * lane + c];
+    for (int c = 0; c < C1; ++c) wlc[c] = cx_conj(w2n_s[C1 * lane + c]);
     // n = M1 j1 + C1 lane + c and its mirror N - n; M1 is a multiple of 32*4 only for
     // C1 = 2 (M1 = 128), so (n >> 5) & 3 is lane-constant there; for C1 = 1 (M1 = 64)
     // it alternates with j1 & 1 -> two base variants cover both plans.
@@ -664,28 +667,27 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
     const int mk_r = launder_v(N - TOP - C1 * lane);       // mask[N - n] = mask[mk_r + TOP - (M1 j1 + c)]
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
-        const cx wg = wg_s[j1];  // w2n[M1 j1], wave-uniform
+        const cx wgc = cx_conj(wg_s[j1]);  // conj(w2n[M1 j1]), wave-uniform
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
             const int off = M1 * j1 + c;
-            const cx w = j1 == 0 ? wl[c] : cx_mul(wl[c], wg);
+            const cx wc = j1 == 0 ? wlc[c] : cx_mul(wlc[c], wgc);
             cx xk = buf[fbase[j1 & 1][c] + M1 * j1];
-            cx xnc = cx_conj(buf[mbase[j1 & 1][c] - M1 * j1]);
+            cx xn = buf[mbase[j1 & 1][c] - M1 * j1];
             if (off == 0) {
                 // n == 0 only in lane 0: X[0] and X[N] are real (realfft ignores /
                 // rejects their imaginary parts, SURVEY a'-4)
                 if (lane == 0) {
                     xk.y = 0.0f;
-                    xnc.y = 0.0f;
+                    xn.y = 0.0f;
                 }
             }
             if constexpr (MASKED) {
                 const float mk = mask[mk_f + off], mn = mask[mk_r + (TOP - off)];
                 xk = cx{xk.x * mk, xk.y * mk};
-                xnc = cx{xnc.x * mn, xnc.y * mn};
+                xn = cx{xn.x * mn, xn.y * mn};
             }
-            const cx z = c2r_elem(xk, xnc, w);
-            r[c][j1] = cx{z.y, z.x};
+            r[c][j1] = c2r_swapped(xk, xn, wc);
         }
         if ((j1 & 1) == 1) THZ_SCHED_FENCE();
     }
