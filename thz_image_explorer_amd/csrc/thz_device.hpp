@@ -136,22 +136,23 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // 1 ulp
 #endif
 
-// atan2f to ~3e-7 rad: octant reduction to a = min/max in [0,1], then ONE odd polynomial
-// a * P(a^2) over the whole octant (degree 7 in a^2, Chebyshev-node fit of atan(sqrt z)/sqrt z on
-// [0,1]: 6e-8 in exact arithmetic).  The Cephes form it replaces had a second range reduction
-// t = (a-1)/(a+1) — a compare, two adds, two selects and a second reciprocal, which on CDNA costs four
-// issue slots by itself — in front of a degree-4 polynomial; three more FMAs are cheaper, and the
-// polynomial of two bins at a time is packed math (fast_atan2f_x2).
+// atan2f to 3e-7 rad: octant reduction to a = min/max in [0,1], then ONE odd polynomial over the
+// whole octant, atan(a) = a + a^3 Q(a^2) with Q of degree 7 (Chebyshev-node fit of
+// (atan(sqrt z)/sqrt z - 1)/z on [0,1]: 5.5e-8 in exact arithmetic; the rest of the 3e-7 is the ratio's
+// 1.5 ulp and the half ulp of pi/2 - r and pi - r, 1.2e-7 at |angle| ~ pi).  The Cephes form it replaces
+// had a second range reduction t = (a-1)/(a+1) — a compare, two adds, two selects and a second
+// reciprocal, which on CDNA costs four issue slots by itself — in front of a degree-4 polynomial; four
+// more FMAs are cheaper, and the polynomial of four bins runs as packed math (fast_atan2f_x4).
 // atan2(0, 0) = 0 (num_complex::arg's atan2 gives 0 or pi depending on the sign of zero; bins
 // that are exactly zero carry no phase information).
-#define THZ_ATAN_C0 9.999998808e-01f
-#define THZ_ATAN_C1 -3.333181143e-01f
-#define THZ_ATAN_C2 1.996696144e-01f
-#define THZ_ATAN_C3 -1.400329024e-01f
-#define THZ_ATAN_C4 9.868865460e-02f
-#define THZ_ATAN_C5 -5.882975459e-02f
-#define THZ_ATAN_C6 2.378051914e-02f
-#define THZ_ATAN_C7 -4.559792113e-03f
+#define THZ_ATAN_Q0 -3.333332241e-01f
+#define THZ_ATAN_Q1 1.999868155e-01f
+#define THZ_ATAN_Q2 -1.425704509e-01f
+#define THZ_ATAN_Q3 1.086575910e-01f
+#define THZ_ATAN_Q4 -8.009681851e-02f
+#define THZ_ATAN_Q5 4.891432077e-02f
+#define THZ_ATAN_Q6 -2.002674714e-02f
+#define THZ_ATAN_Q7 3.866738873e-03f
 
 // a = min(|x|,|y|) / max(|x|,|y|) in [0, 1]; 0 for x = y = 0 (0 * rcp(tiny) = 0)
 __device__ __forceinline__ float atan_octant_ratio(float x, float y)
@@ -171,14 +172,14 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
 {
     const float a = atan_octant_ratio(x, y);
     const float z = a * a;
-    float p = fmaf(THZ_ATAN_C7, z, THZ_ATAN_C6);
-    p = fmaf(p, z, THZ_ATAN_C5);
-    p = fmaf(p, z, THZ_ATAN_C4);
-    p = fmaf(p, z, THZ_ATAN_C3);
-    p = fmaf(p, z, THZ_ATAN_C2);
-    p = fmaf(p, z, THZ_ATAN_C1);
-    p = fmaf(p, z, THZ_ATAN_C0);
-    return atan_unfold(p * a, y, x);
+    float q = fmaf(THZ_ATAN_Q7, z, THZ_ATAN_Q6);
+    q = fmaf(q, z, THZ_ATAN_Q5);
+    q = fmaf(q, z, THZ_ATAN_Q4);
+    q = fmaf(q, z, THZ_ATAN_Q3);
+    q = fmaf(q, z, THZ_ATAN_Q2);
+    q = fmaf(q, z, THZ_ATAN_Q1);
+    q = fmaf(q, z, THZ_ATAN_Q0);
+    return atan_unfold(fmaf(a * z, q, a), y, x);
 }
 
 // four angles at once: same values as four fast_atan2f calls.  The polynomial runs as two packed
@@ -191,19 +192,19 @@ __device__ __forceinline__ void fast_atan2f_x4(const float (&y)[4], const float 
     const thz_f2 a0 = {atan_octant_ratio(x[0], y[0]), atan_octant_ratio(x[1], y[1])};
     const thz_f2 a1 = {atan_octant_ratio(x[2], y[2]), atan_octant_ratio(x[3], y[3])};
     const thz_f2 z0 = a0 * a0, z1 = a1 * a1;
-    thz_f2 p0 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z0, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
-    thz_f2 p1 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_C7, THZ_ATAN_C7}, z1, thz_f2{THZ_ATAN_C6, THZ_ATAN_C6});
+    thz_f2 q0 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_Q7, THZ_ATAN_Q7}, z0, thz_f2{THZ_ATAN_Q6, THZ_ATAN_Q6});
+    thz_f2 q1 = __builtin_elementwise_fma(thz_f2{THZ_ATAN_Q7, THZ_ATAN_Q7}, z1, thz_f2{THZ_ATAN_Q6, THZ_ATAN_Q6});
 #define THZ_ATAN_STEP(C)                                            \
-    p0 = __builtin_elementwise_fma(p0, z0, thz_f2{C, C});           \
-    p1 = __builtin_elementwise_fma(p1, z1, thz_f2{C, C});
-    THZ_ATAN_STEP(THZ_ATAN_C5)
-    THZ_ATAN_STEP(THZ_ATAN_C4)
-    THZ_ATAN_STEP(THZ_ATAN_C3)
-    THZ_ATAN_STEP(THZ_ATAN_C2)
-    THZ_ATAN_STEP(THZ_ATAN_C1)
-    THZ_ATAN_STEP(THZ_ATAN_C0)
+    q0 = __builtin_elementwise_fma(q0, z0, thz_f2{C, C});           \
+    q1 = __builtin_elementwise_fma(q1, z1, thz_f2{C, C});
+    THZ_ATAN_STEP(THZ_ATAN_Q5)
+    THZ_ATAN_STEP(THZ_ATAN_Q4)
+    THZ_ATAN_STEP(THZ_ATAN_Q3)
+    THZ_ATAN_STEP(THZ_ATAN_Q2)
+    THZ_ATAN_STEP(THZ_ATAN_Q1)
+    THZ_ATAN_STEP(THZ_ATAN_Q0)
 #undef THZ_ATAN_STEP
-    const thz_f2 r0 = p0 * a0, r1 = p1 * a1;
+    const thz_f2 r0 = __builtin_elementwise_fma(a0 * z0, q0, a0), r1 = __builtin_elementwise_fma(a1 * z1, q1, a1);
     r[0] = atan_unfold(r0.x, y[0], x[0]);
     r[1] = atan_unfold(r0.y, y[1], x[1]);
     r[2] = atan_unfold(r1.x, y[2], x[2]);
