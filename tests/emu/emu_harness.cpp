@@ -106,3 +106,35 @@ int emu_voxel_instances(size_t npix, int nt, size_t gh, const float *opacity, co
     return 0;
 }
 }
+
+// One Richardson-Lucy iteration (both steps) of ONE band on padded images d, u (H x W, H = h + 2 (pr/2),
+// W = w + 2 (pc/2)), through the untiled kernel (tiled = 0) or the LDS-tiled one: t_out = d / (u (*) psf + eps),
+// u_out = u * (t (*) mirror).  Workspace laid out as thz_deconvolve does it.
+extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d,
+                                const float *u, int tiled, float *t_out, float *u_out)
+{
+    RlBand B{};
+    B.h = h; B.w = w; B.pr = pr; B.pc = pc; B.pad_y = pr / 2; B.pad_x = pc / 2;
+    B.H = h + 2 * B.pad_y; B.W = w + 2 * B.pad_x;
+    B.n_iter = 1; B.mode = mode; B.blk0 = 0; B.tblk0 = 0; B.tiles_w = (B.W + 15) / 16;
+    const size_t img = (size_t)B.H * B.W, taps = (size_t)pr * pc;
+    B.off_d = 0; B.off_u = (unsigned)img; B.off_t = (unsigned)(2 * img);
+    B.off_psf = (unsigned)(3 * img); B.off_mirror = (unsigned)(3 * img + taps);
+    std::vector<float> ws(3 * img + 2 * taps + 32, 0.0f);
+    std::memcpy(ws.data() + B.off_d, d, img * sizeof(float));
+    std::memcpy(ws.data() + B.off_u, u, img * sizeof(float));
+    for (size_t i = 0; i < taps; ++i) {
+        ws[B.off_psf + i] = psf[i];
+        ws[B.off_mirror + i] = psf[taps - 1 - i];
+    }
+    const unsigned blocks = (unsigned)((img + 255) / 256);
+    const unsigned tiles_n = (unsigned)(B.tiles_w * ((B.H + 15) / 16));
+    std::vector<RlTileRef> tiles(tiles_n, RlTileRef{B});
+    for (int step = 0; step < 2; ++step) {
+        if (tiled) launch_rl_step_tiled(nullptr, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());
+        else launch_rl_step(nullptr, &B, 1, blocks, nullptr, 0, step, ws.data());
+    }
+    std::memcpy(t_out, ws.data() + B.off_t, img * sizeof(float));
+    std::memcpy(u_out, ws.data() + B.off_u, img * sizeof(float));
+    return 0;
+}

@@ -182,3 +182,60 @@ def test_fast_atan2_accuracy(emu):
     ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
     assert np.abs(out - ref).max() < 3.2e-7  # half an ulp of pi is 1.2e-7 of it
     assert out[6] == 0.0 and abs(out[1] - np.pi) < 3e-7 and abs(out[3] + np.pi / 2) < 3e-7
+
+
+def _rl_reference(d, u, psf, mode):
+    """one Richardson-Lucy iteration with the reference's loops (deconvolution.rs:432-458 for kernels of at
+    most 256 elements: correlation-indexed, m outer / n inner, f32, no FMA; the 'same' true convolution the
+    FFT branch stands for otherwise), numpy float32 scalars so that every rounding is the reference's"""
+    H, W = d.shape
+    pr, pc = psf.shape
+    f32 = np.float32
+
+    def conv(a, k):
+        out = np.zeros((H, W), f32)
+        for i in range(H):
+            for j in range(W):
+                s = f32(0)
+                for m in range(pr):
+                    x = i + m - pr // 2 if mode == 0 else i + (pr - 1) // 2 - m
+                    if x < 0 or x >= H:
+                        continue
+                    for n in range(pc):
+                        y = j + n - pc // 2 if mode == 0 else j + (pc - 1) // 2 - n
+                        if 0 <= y < W:
+                            s = f32(s + f32(a[x, y] * k[m, n]))
+                out[i, j] = s
+        return out
+
+    t = (d / (conv(u, psf) + f32(1e-12))).astype(f32)
+    return t, (u * conv(t, psf[::-1, ::-1])).astype(f32)
+
+
+@pytest.mark.parametrize("case", [dict(h=14, w=19, pr=7, pc=9, mode=0), dict(h=9, w=21, pr=13, pc=17, mode=0),
+                                  dict(h=12, w=12, pr=3, pc=5, mode=0), dict(h=11, w=13, pr=19, pc=21, mode=1)])
+def test_rl_step_kernels(emu, case):
+    """k_rl_step (every tap from memory) and k_rl_step_tiled (LDS tile, chunked taps, end-aligned last chunk;
+    for wide kernels four pixels per thread and a 16-way row split): narrow kernels bit for bit in the
+    reference's order, wide ones within rounding"""
+    h, w, pr, pc, mode = (case[k] for k in ("h", "w", "pr", "pc", "mode"))
+    assert (pr * pc > 256) == (mode == 1)
+    rng = np.random.default_rng(pr * 100 + pc)
+    H, W = h + 2 * (pr // 2), w + 2 * (pc // 2)
+    d = (0.5 + rng.random((H, W))).astype(np.float32)
+    u = (0.5 + rng.random((H, W))).astype(np.float32)
+    psf = rng.random((pr, pc)).astype(np.float32)
+    psf /= psf.max()
+    res = []
+    for tiled in (0, 1):
+        t, un = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+        assert emu.emu_rl_iteration(h, w, pr, pc, mode, _p(psf), _p(d), _p(u), tiled, _p(t), _p(un)) == 0
+        res.append((t, un))
+    rt, ru = _rl_reference(d, u, psf, mode)
+    if mode == 0:
+        for t, un in res:
+            assert np.array_equal(t, rt) and np.array_equal(un, ru)
+    else:
+        assert np.array_equal(res[0][0], rt) and np.array_equal(res[0][1], ru)   # untiled: the same loops
+        assert np.abs(res[1][0] - rt).max() / np.abs(rt).max() < 1e-5
+        assert np.abs(res[1][1] - ru).max() / np.abs(ru).max() < 1e-5

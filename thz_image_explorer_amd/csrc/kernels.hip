@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *_
                 dst[c < wsz ? (turned ? wsz - 1 - c : c) : c] = v;
             }
         }
-        if (threadIdx.x < 2 * kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // behind the last row
+        if (threadIdx.x < kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // the slack behind the last row (the taps start right after it)
     }
     if (turned) {  // padded rows: a wave per kernel row
         const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
