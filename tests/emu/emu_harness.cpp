@@ -138,3 +138,26 @@ extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const fl
     std::memcpy(u_out, ws.data() + B.off_u, img * sizeof(float));
     return 0;
 }
+
+// The deconvolution's transform kernels on the padded length M (a power of two): forward transform of the
+// zero-padded traces, band energies over the "same" slice and the gain-weighted recombination — with the
+// register-resident F core (use_f != 0, M = 1024 / 2048 / 4096) or the generic LDS transform.
+extern "C" int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, const float *in, const float *H,
+                            const float *gain, int use_f, float *energy, float *out, float *img)
+{
+    PlanHost P;
+    if (!build_plan((size_t)M, P, use_f != 0)) return -2;
+    PlanDev D = plan_dev(P, P.tw.data(), P.tw_split.data(), nullptr, nullptr);
+    if (use_f) {
+        if (P.f_t1.empty()) return -3;
+        D.f_t1 = P.f_t1.data();
+        D.f_t2 = P.f_t2.data();
+        D.f_w2n = P.f_w2n.data();
+    }
+    const size_t nk = (size_t)M / 2 + 1;
+    std::vector<c32> spec(npix * nk);
+    launch_dc_fft(nullptr, D, npix, nt, in, spec.data());
+    launch_dc_energy(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, energy);
+    launch_dc_combine(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, gain, out, img);
+    return 0;
+}

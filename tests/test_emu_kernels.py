@@ -20,8 +20,11 @@ _P = C.c_void_p
 
 @pytest.fixture(scope="module")
 def emu():
-    src = os.path.join(HERE, "..", "thz_image_explorer_amd", "csrc", "kernels.hip")
-    if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < os.path.getmtime(src):
+    import glob
+    csrc = os.path.join(HERE, "..", "thz_image_explorer_amd", "csrc")
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) \
+        + glob.glob(os.path.join(HERE, "emu", "*.cpp")) + glob.glob(os.path.join(HERE, "emu", "*.h"))
+    if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["bash", os.path.join(HERE, "emu", "build_emu.sh")])
     return C.CDLL(EMU_SO)
 
@@ -239,3 +242,32 @@ def test_rl_step_kernels(emu, case):
         assert np.array_equal(res[0][0], rt) and np.array_equal(res[0][1], ru)   # untiled: the same loops
         assert np.abs(res[1][0] - rt).max() / np.abs(rt).max() < 1e-5
         assert np.abs(res[1][1] - ru).max() / np.abs(ru).max() < 1e-5
+
+
+@pytest.mark.parametrize("M,nt", [(1024, 300), (2048, 1001), (4096, 2000)])
+def test_deconvolution_transform_kernels(emu, M, nt):
+    """k_dc_fft -> k_dc_energy(_f) -> k_dc_combine(_f): band energies of FIR-filtered traces over the 'same'
+    slice and the gain-weighted recombination, register-resident core against the generic LDS transform and
+    both against numpy float64"""
+    rng = np.random.default_rng(M + nt)
+    npix, nb, taps = 5, 3, 499
+    shift = (taps - 1) // 2
+    x = synth.make_traces(np.arange(npix) + 3, max(nt, 320))[:, :nt].astype(np.float32)
+    h = (rng.standard_normal((nb, taps)) * np.hanning(taps)).astype(np.float32) / 20
+    Hs = (np.fft.rfft(h.astype(np.float64), M, axis=-1) / M)
+    H = np.stack([Hs.real, Hs.imag], -1).astype(np.float32)
+    gain = (0.5 + rng.random((nb, npix))).astype(np.float32)
+    y = np.stack([[np.convolve(x[p].astype(np.float64), h[b].astype(np.float64))[shift:shift + nt] for p in range(npix)]
+                  for b in range(nb)])                                   # (nb, npix, nt) 'same' slices
+    e_ref = (y ** 2).sum(-1)
+    o_ref = (gain[..., None] * y).sum(0)
+    res = []
+    for use_f in (0, 1):
+        en = np.zeros((nb, npix), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+        rc = emu.emu_dc_chain(M, nt, C.c_size_t(npix), nb, shift, _p(x), _p(H), _p(gain), use_f, _p(en), _p(out), _p(img))
+        assert rc == 0
+        assert np.abs(en - e_ref).max() / e_ref.max() < 2e-5
+        assert np.abs(out - o_ref).max() / np.abs(o_ref).max() < 2e-5
+        assert np.abs(img - (o_ref ** 2).sum(-1)).max() / (o_ref ** 2).sum(-1).max() < 2e-5
+        res.append((en, out))
+    assert np.abs(res[0][0] - res[1][0]).max() / e_ref.max() < 5e-6
