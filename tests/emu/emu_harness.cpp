@@ -161,3 +161,55 @@ extern "C" int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, 
     launch_dc_combine(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, gain, out, img);
     return 0;
 }
+
+// ---- the bandwidth-shaped helper kernels (multiplier, column sums, pixel-list sums, block means, tilt copy)
+extern "C" {
+
+int emu_td_window(size_t npix, int nt, const float *in, const float *win, float *out)
+{
+    launch_td_window(nullptr, npix, nt, in, win, out);
+    return 0;
+}
+
+// thz_pixel_sum's launch sequence (api.cpp): column sums of an (nrows, L) array
+int emu_pixel_sum(size_t nrows, size_t L, const float *arr, float *out)
+{
+    if (nrows < 64) {
+        launch_sum_axis0(nullptr, arr, nrows, L, 0.0f, out);
+        return 0;
+    }
+    const size_t max_groups = 2048, mid_groups = 32;
+    std::vector<float> part((max_groups + mid_groups) * L);
+    float *part2 = part.data() + max_groups * L;
+    size_t groups = launch_colsum_partial(nullptr, arr, nrows, L, part.data(), max_groups);
+    if (groups == 0) {
+        launch_sum_axis0(nullptr, arr, nrows, L, 0.0f, out);
+        return 1;
+    }
+    const float *src = part.data();
+    if (groups > 4 * mid_groups) {
+        groups = launch_colsum_partial(nullptr, part.data(), groups, L, part2, mid_groups);
+        src = part2;
+    }
+    launch_sum_axis0(nullptr, src, groups, L, 0.0f, out);
+    return 0;
+}
+
+int emu_gather_sum(const float *arr, size_t len, const uint32_t *list, uint32_t count, float div, float *out)
+{
+    launch_gather_sum(nullptr, arr, len, list, count, div, out);
+    return 0;
+}
+
+int emu_scale3d(const float *arr, size_t nx, size_t ny, size_t L, size_t s, float *out)
+{
+    launch_scale3d(nullptr, arr, nx, ny, L, s, out);
+    return 0;
+}
+
+int emu_tilt(size_t npix, int nt_in, int nt_out, const float *in, const float *taper, const int *ins, float *out)
+{
+    launch_tilt(nullptr, npix, nt_in, nt_out, in, taper, ins, out);
+    return 0;
+}
+}

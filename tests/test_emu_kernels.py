@@ -271,3 +271,54 @@ def test_deconvolution_transform_kernels(emu, M, nt):
         assert np.abs(img - (o_ref ** 2).sum(-1)).max() / (o_ref ** 2).sum(-1).max() < 2e-5
         res.append((en, out))
     assert np.abs(res[0][0] - res[1][0]).max() / e_ref.max() < 5e-6
+
+
+def test_helper_kernels(emu):
+    """the bandwidth-shaped kernels around the transforms, each in its batched / wave-per-trace form:
+    window multiply, two-level column sums (ragged row length), pixel-list sums in list order, block means
+    with the ragged-edge rule, tilt copy — against numpy / the oracle, bit for bit where the order is fixed"""
+    rng = np.random.default_rng(5)
+    # K6 multiplier: odd length, more traces than one block handles
+    npix, nt = 37, 1001
+    x = rng.standard_normal((npix, nt)).astype(np.float32)
+    wv = rng.random(nt).astype(np.float32)
+    out = np.empty_like(x)
+    assert emu.emu_td_window(C.c_size_t(npix), nt, _p(x), _p(wv), _p(out)) == 0
+    assert np.array_equal(out, x * wv)
+    # K8 sums: rows of nf and 2 nf floats (only 4-byte aligned), above and below the two-level threshold
+    for nrows, L in ((300, 513), (70, 1026), (40, 129), (9000, 130)):
+        a = rng.standard_normal((nrows, L)).astype(np.float32)
+        s = np.empty(L, np.float32)
+        assert emu.emu_pixel_sum(C.c_size_t(nrows), C.c_size_t(L), _p(a), _p(s)) == 0
+        ref = a.astype(np.float64).sum(0)
+        assert np.abs(s - ref).max() <= 2e-6 * np.abs(a).sum(0).max()
+    # K9 pixel-list mean: the adds in list order (the reference's iteration order)
+    n_pix, ln = 500, 257
+    a = rng.standard_normal((n_pix, ln)).astype(np.float32)
+    for count in (1, 63, 64, 65, 200):
+        lst = rng.permutation(n_pix)[:count].astype(np.uint32)
+        s = np.empty(ln, np.float32)
+        assert emu.emu_gather_sum(_p(a), C.c_size_t(ln), _p(lst), count, C.c_float(float(count)), _p(s)) == 0
+        acc = np.zeros(ln, np.float32)
+        for i in lst:
+            acc = acc + a[i]
+        assert np.array_equal(s, acc / np.float32(count))
+    # K10 block means incl. ragged edges (sum / s^2 whatever the block holds)
+    nx, ny, L, sf = 7, 9, 130, 2
+    a = rng.standard_normal((nx, ny, L)).astype(np.float32)
+    o = np.empty((nx // sf, ny // sf, L), np.float32)
+    assert emu.emu_scale3d(_p(a), C.c_size_t(nx), C.c_size_t(ny), C.c_size_t(L), C.c_size_t(sf), _p(o)) == 0
+    assert np.array_equal(o, ob.scale3d(a, sf))
+    # K11 tilt copy: front fill with the first sample, tapered trace at its insert index, clipped at the end
+    npix, nt_in, nt_out = 13, 300, 340
+    x = rng.standard_normal((npix, nt_in)).astype(np.float32)
+    taper = rng.random(nt_in).astype(np.float32)
+    ins = rng.integers(0, 60, npix).astype(np.int32)
+    o = np.empty((npix, nt_out), np.float32)
+    assert emu.emu_tilt(C.c_size_t(npix), nt_in, nt_out, _p(x), _p(taper), _p(ins), _p(o)) == 0
+    ref = np.zeros((npix, nt_out), np.float32)
+    for p in range(npix):
+        ref[p, :ins[p]] = x[p, 0]
+        n = min(nt_in, nt_out - ins[p])
+        ref[p, ins[p]:ins[p] + n] = (x[p] * taper)[:n]
+    assert np.array_equal(o, ref)
