@@ -213,3 +213,16 @@ int emu_tilt(size_t npix, int nt_in, int nt_out, const float *in, const float *t
     return 0;
 }
 }
+
+extern "C" int emu_dc_filter_spectra(const float *filters, int n_bands, int n_taps, int M, float *H)
+{
+    std::vector<double> cs((size_t)M), sn((size_t)M);
+    for (int m = 0; m < M; ++m) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)M;
+        cs[(size_t)m] = std::cos(a);
+        sn[(size_t)m] = std::sin(a);
+    }
+    launch_dc_filter_spectra(nullptr, filters, n_bands, n_taps, cs.data(), sn.data(), (unsigned)M, (unsigned)(M / 2 + 1),
+                             (c32 *)H);
+    return 0;
+}

@@ -322,3 +322,14 @@ def test_helper_kernels(emu):
         n = min(nt_in, nt_out - ins[p])
         ref[p, ins[p]:ins[p] + n] = (x[p] * taper)[:n]
     assert np.array_equal(o, ref)
+
+
+def test_filter_spectra_kernel(emu):
+    """H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M): the kernel's table-stepped double sums vs numpy's rfft"""
+    rng = np.random.default_rng(11)
+    nb, taps, M = 3, 499, 2048
+    h = rng.standard_normal((nb, taps)).astype(np.float32)
+    H = np.zeros((nb, M // 2 + 1, 2), np.float32)
+    assert emu.emu_dc_filter_spectra(_p(h), nb, taps, M, _p(H)) == 0
+    ref = np.fft.rfft(h.astype(np.float64), M, axis=-1) / M
+    assert np.abs((H[..., 0] + 1j * H[..., 1]) - ref).max() / np.abs(ref).max() < 2e-7

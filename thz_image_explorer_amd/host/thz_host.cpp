@@ -337,22 +337,15 @@ static std::vector<float> roi_mean(const DeviceArray &arr, size_t shape0, size_t
     return out.download();
 }
 
-// from_polar + C2R + /nt for one spectrum (math_tools.rs:446-468, 499-529)
+// from_polar + C2R + /nt for one spectrum (math_tools.rs:446-468, 499-529): thz_polar_ifft
 static std::vector<float> polar_irfft(const std::vector<float> &amp, const std::vector<float> &phase, size_t nt,
                                       bool zero_dc_imag)
 {
     Engine &e = Engine::instance();
-    const size_t nf = amp.size();
-    std::vector<float> spec(2 * nf);
-    for (size_t i = 0; i < nf; ++i) {
-        spec[2 * i] = amp[i] * std::cos(phase[i]);
-        spec[2 * i + 1] = amp[i] * std::sin(phase[i]);
-    }
-    if (zero_dc_imag && nf) spec[1] = 0.0f;
-    DeviceArray d_s, d_o(nt);
-    d_s.upload(spec.data(), spec.size());
-    thz_ifft(e.ctx(), 1, d_s.ptr(), nullptr, d_o.ptr(), nullptr);
-    return d_o.download();
+    std::vector<float> out(nt, 0.0f);
+    if (thz_polar_ifft(e.ctx(), amp.data(), phase.data(), zero_dc_imag ? 1 : 0, out.data()) != THZ_OK)
+        log_error("ifft: " + e.last_error());
+    return out;
 }
 
 // math_tools.rs:418-571
