@@ -1,0 +1,132 @@
+// tsan_driver.cpp — runs the emulated kernels (every lane a host thread) under ThreadSanitizer.
+// TEST INFRASTRUCTURE ONLY.  A data race between two host threads here is an LDS / global-memory access
+// pair of two lanes that no barrier (__syncthreads, wave_sync) orders — code that only works while a wave
+// runs in lock-step.  Build and run: tests/emu/run_tsan.sh
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+extern "C" {
+int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const float *wb, float *data_out, float *fft,
+                float *amp, float *ph, const float *mask);
+int emu_fft_inv(int nt, size_t npix, const float *fft, const float *win, float *out, float *img);
+int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *post,
+                 float *fft, float *amp, float *ph, float *out, float *img);
+void emu_allow_f(int on);
+int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d, const float *u,
+                     int tiled, float *t_out, float *u_out);
+int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, const float *in, const float *H,
+                 const float *gain, int use_f, float *energy, float *out, float *img);
+int emu_td_window(size_t npix, int nt, const float *in, const float *win, float *out);
+int emu_pixel_sum(size_t nrows, size_t L, const float *arr, float *out);
+int emu_gather_sum(const float *arr, size_t len, const uint32_t *list, uint32_t count, float div, float *out);
+int emu_scale3d(const float *arr, size_t nx, size_t ny, size_t L, size_t s, float *out);
+int emu_tilt(size_t npix, int nt_in, int nt_out, const float *in, const float *taper, const int *ins, float *out);
+int emu_voxel_opacity(size_t npix, int nt, const float *data, const float *kernel, int radius, float contrast,
+                      float opacity_threshold, float *out);
+int emu_select_hist(const float *vals, size_t n, int level, uint32_t prefix, unsigned long long *hist);
+}
+
+static std::vector<float> noise(size_t n, unsigned seed, float lo = -1.0f, float hi = 1.0f)
+{
+    std::vector<float> v(n);
+    uint32_t s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        v[i] = lo + (hi - lo) * (float)(s >> 8) / 16777216.0f;
+    }
+    return v;
+}
+
+static void chain(int nt, size_t npix, int allow_f)
+{
+    emu_allow_f(allow_f);
+    const size_t nf = (size_t)nt / 2 + 1;
+    auto x = noise(npix * nt, (unsigned)nt);
+    auto pre = noise((size_t)nt, 1, 0.5f, 1.0f), post = noise((size_t)nt, 2, 0.5f, 1.0f), mask = noise(nf, 3, 0.0f, 1.0f);
+    std::vector<float> fft(npix * nf * 2), amp(npix * nf), ph(npix * nf), out(npix * nt), img(npix), dat(npix * nt);
+    int rc = emu_pipeline(nt, npix, x.data(), pre.data(), mask.data(), post.data(), fft.data(), amp.data(), ph.data(),
+                          out.data(), img.data());
+    if (rc == -2) {  // no fused kernel for this length: the staged pair
+        emu_fft_fwd(nt, npix, x.data(), pre.data(), nullptr, dat.data(), fft.data(), amp.data(), ph.data(), mask.data());
+        emu_fft_inv(nt, npix, fft.data(), post.data(), out.data(), img.data());
+    } else {
+        emu_fft_fwd(nt, npix, x.data(), pre.data(), nullptr, dat.data(), fft.data(), amp.data(), ph.data(), mask.data());
+        emu_fft_inv(nt, npix, fft.data(), post.data(), out.data(), img.data());
+    }
+    std::printf("chain nt=%d allow_f=%d done\n", nt, allow_f);
+    std::fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const char *only = argc > 1 ? argv[1] : "";
+    auto want = [&](const char *name) { return !only[0] || std::string(only) == name; };
+    if (want("f")) { chain(1024, 11, 1); chain(2048, 9, 1); chain(4096, 9, 1); }
+    if (want("g")) { chain(256, 7, 0); chain(1024, 5, 0); }
+    if (want("fb")) { chain(1001, 5, 1); chain(300, 6, 1); }
+    if (want("fbc")) { chain(1500, 3, 1); chain(3000, 3, 1); chain(5000, 3, 1); }
+    if (want("rl")) {
+        for (int mode = 0; mode < 2; ++mode) {
+            const int h = 12, w = 13, pr = mode ? 19 : 7, pc = mode ? 21 : 9;
+            const int H = h + 2 * (pr / 2), W = w + 2 * (pc / 2);
+            auto d = noise((size_t)H * W, 5, 0.5f, 1.5f), u = noise((size_t)H * W, 6, 0.5f, 1.5f);
+            auto psf = noise((size_t)pr * pc, 7, 0.0f, 1.0f);
+            std::vector<float> t((size_t)H * W), un((size_t)H * W);
+            emu_rl_iteration(h, w, pr, pc, mode, psf.data(), d.data(), u.data(), 1, t.data(), un.data());
+            emu_rl_iteration(h, w, pr, pc, mode, psf.data(), d.data(), u.data(), 0, t.data(), un.data());
+        }
+        std::printf("rl done\n");
+    }
+    if (want("dc")) {
+        const int M = 1024, nt = 300, nb = 2;
+        const size_t npix = 3, nk = M / 2 + 1;
+        auto x = noise(npix * nt, 8), H = noise((size_t)nb * nk * 2, 9, -0.01f, 0.01f), g = noise((size_t)nb * npix, 10, 0.5f, 1.5f);
+        std::vector<float> en((size_t)nb * npix), out(npix * nt), img(npix);
+        for (int use_f = 0; use_f < 2; ++use_f)
+            emu_dc_chain(M, nt, npix, nb, 249, x.data(), H.data(), g.data(), use_f, en.data(), out.data(), img.data());
+        {   // the two-values-per-lane plans of the core (M = 2048, 4096)
+            for (int M2 : {2048, 4096}) {
+                const int nt2 = M2 - 600;
+                const size_t nk2 = (size_t)M2 / 2 + 1;
+                auto x2 = noise(npix * nt2, 18), H2 = noise((size_t)nb * nk2 * 2, 19, -0.01f, 0.01f);
+                std::vector<float> out2(npix * nt2);
+                emu_dc_chain(M2, nt2, npix, nb, 249, x2.data(), H2.data(), g.data(), 1, en.data(), out2.data(), img.data());
+            }
+        }
+        std::printf("dc done\n");
+    }
+    if (want("helpers")) {
+        const size_t npix = 9;
+        const int nt = 333;
+        auto x = noise(npix * nt, 11), wv = noise((size_t)nt, 12);
+        std::vector<float> o(npix * nt);
+        emu_td_window(npix, nt, x.data(), wv.data(), o.data());
+        auto a = noise((size_t)300 * 130, 13);
+        std::vector<float> s(130);
+        emu_pixel_sum(300, 130, a.data(), s.data());
+        std::vector<uint32_t> lst = {5, 1, 200, 7, 7, 123, 64, 65, 66, 67};
+        emu_gather_sum(a.data(), 130, lst.data(), (uint32_t)lst.size(), (float)lst.size(), s.data());
+        auto c = noise((size_t)5 * 7 * 66, 14);
+        std::vector<float> sc((size_t)2 * 3 * 66);
+        emu_scale3d(c.data(), 5, 7, 66, 2, sc.data());
+        std::vector<int> ins = {0, 3, 10, 39, 40, 1, 2, 7, 20};
+        std::vector<float> to(npix * 373);
+        emu_tilt(npix, nt, 373, x.data(), wv.data(), ins.data(), to.data());
+        std::printf("helpers done\n");
+    }
+    if (want("voxel")) {
+        const size_t npix = 6;
+        const int nt = 300, radius = 9;
+        auto x = noise(npix * nt, 15);
+        std::vector<float> k((size_t)2 * radius + 1, 1.0f / (2 * radius + 1)), o(npix * nt);
+        emu_voxel_opacity(npix, nt, x.data(), k.data(), radius, 0.7f, 0.05f, o.data());
+        std::vector<unsigned long long> hist(2048, 0);
+        emu_select_hist(o.data(), o.size(), 0, 0, hist.data());
+        std::printf("voxel done\n");
+    }
+    return 0;
+}
