@@ -63,8 +63,13 @@ static void chain(int nt, size_t npix, int allow_f)
 
 int main(int argc, char **argv)
 {
-    const char *only = argc > 1 ? argv[1] : "";
-    auto want = [&](const char *name) { return !only[0] || std::string(only) == name; };
+    // arguments: the kernel families to run (none: all of them)
+    auto want = [&](const char *name) {
+        if (argc <= 1) return true;
+        for (int i = 1; i < argc; ++i)
+            if (std::string(argv[i]) == name) return true;
+        return false;
+    };
     if (want("f")) { chain(1024, 11, 1); chain(2048, 9, 1); chain(4096, 9, 1); }
     if (want("g")) { chain(256, 7, 0); chain(1024, 5, 0); }
     if (want("fb")) { chain(1001, 5, 1); chain(300, 6, 1); }

@@ -12,17 +12,44 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the ThreadSanitizer runtime")
+def _run(san, families=()):
+    env = dict(os.environ, SAN=san, TSAN_OPTIONS="halt_on_error=0 history_size=2 exitcode=0",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    return subprocess.run(["bash", os.path.join(HERE, "emu", "run_tsan.sh"), *families], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, timeout=1500)
+
+
+REACHED = ("chain nt=4096 allow_f=1 done", "chain nt=1001 allow_f=1 done", "chain nt=5000 allow_f=1 done",
+           "rl done", "dc done", "helpers done", "voxel done")
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the sanitizer runtimes")
 def test_kernels_are_race_free():
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 history_size=2 exitcode=0")
-    p = subprocess.run(["bash", os.path.join(HERE, "emu", "run_tsan.sh")], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=1500)
+    p = _run("thread")
     out = p.stdout
     if "unsupported option '-fsanitize=thread'" in out or "cannot find" in out and "tsan" in out:
         pytest.skip("ThreadSanitizer runtime not available")
     assert p.returncode == 0, out[-4000:]
-    for tag in ("chain nt=4096 allow_f=1 done", "chain nt=1001 allow_f=1 done", "chain nt=5000 allow_f=1 done",
-                "rl done", "dc done", "helpers done", "voxel done"):
+    for tag in REACHED:
         assert tag in out, f"driver did not reach: {tag}\n{out[-2000:]}"
     reports = [l for l in out.splitlines() if "WARNING: ThreadSanitizer" in l]
     assert not reports, out[-6000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the sanitizer runtimes")
+@pytest.mark.skipif(os.environ.get("THZ_SANITIZE_ALL") != "1",
+                    reason="two more minutes of build + run; set THZ_SANITIZE_ALL=1 (last run clean: round 1)")
+def test_kernels_stay_in_bounds():
+    """the same driver under AddressSanitizer + UBSan: the emulation's LDS is a heap block of exactly the
+    launch's dynamic-LDS size, so a lane reading or writing past it (the GPU would hand back zeros or a
+    neighbour's data) is an error here, as is any global access outside the caller's arrays"""
+    # the cooperative chirp-z kernels (nt = 3000, 5000) take minutes under this sanitizer: the other families
+    p = _run("address,undefined", ("f", "g", "fb", "rl", "dc", "helpers", "voxel"))
+    out = p.stdout
+    if "unsupported option" in out:
+        pytest.skip("sanitizer runtime not available")
+    assert p.returncode == 0, out[-4000:]
+    for tag in REACHED:
+        if "nt=5000" not in tag:
+            assert tag in out, f"driver did not reach: {tag}\n{out[-2000:]}"
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-6000:]
