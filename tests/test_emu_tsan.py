@@ -53,3 +53,23 @@ def test_kernels_stay_in_bounds():
         if "nt=5000" not in tag:
             assert tag in out, f"driver did not reach: {tag}\n{out[-2000:]}"
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-6000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the sanitizer runtimes")
+def test_host_math_under_sanitizers(tmp_path):
+    """the O(Nt) host math (windows, band-pass index rules, tilt plan, reference alignment, FIR bank, PSF
+    evaluation) under AddressSanitizer + UBSan, on ordinary and on edge inputs (tests/emu/host_san_driver.cpp)"""
+    csrc = os.path.join(HERE, "..", "thz_image_explorer_amd", "csrc")
+    exe = str(tmp_path / "host_san")
+    b = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                        "-fno-sanitize=float-divide-by-zero", "-ffp-contract=off", "-I" + csrc,
+                        "-I" + os.path.join(HERE, "..", "include"), os.path.join(HERE, "emu", "host_san_driver.cpp"),
+                        os.path.join(csrc, "host_windows.cpp"), os.path.join(csrc, "deconv_host.cpp"), "-lm", "-o", exe],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if b.returncode != 0 and "unsupported option" in b.stdout:
+        pytest.skip("sanitizer runtime not available")
+    assert b.returncode == 0, b.stdout[-3000:]
+    r = subprocess.run([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "host math done" in r.stdout, r.stdout[-4000:]
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, r.stdout[-4000:]
