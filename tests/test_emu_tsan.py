@@ -73,3 +73,25 @@ def test_host_math_under_sanitizers(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "host math done" in r.stdout, r.stdout[-4000:]
     assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the sanitizer runtimes")
+@pytest.mark.skipif(not os.path.exists("/opt/conda/include/hdf5.h"), reason="HDF5 headers not installed")
+def test_thz_io_under_sanitizers(tmp_path):
+    """the dotTHz reader / writer under AddressSanitizer + UBSan: a real sample file, write + re-read, caller
+    buffers smaller than the values, a missing file and a file that is not HDF5 (tests/emu/io_san_driver.cpp)"""
+    root = os.path.join(HERE, "..")
+    exe = str(tmp_path / "io_san")
+    b = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-I" + os.path.join(root, "include"),
+                        "-I/opt/conda/include", os.path.join(HERE, "emu", "io_san_driver.cpp"),
+                        os.path.join(root, "thz_image_explorer_amd", "io", "thz_io.cpp"), "/opt/conda/lib/libhdf5.so",
+                        "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if b.returncode != 0 and "unsupported option" in b.stdout:
+        pytest.skip("sanitizer runtime not available")
+    assert b.returncode == 0, b.stdout[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1",
+               LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib")   # the system's libstdc++, conda's HDF5
+    r = subprocess.run([exe, os.path.join(HERE, "golden", "knife_edge_2groups.thz"), str(tmp_path)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "io done" in r.stdout, r.stdout[-4000:]
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, r.stdout[-4000:]
