@@ -1,7 +1,7 @@
 // host_san_driver.cpp — the O(Nt) host math of the engine (csrc/host_windows.cpp, csrc/deconv_host.cpp:
 // windows, band-pass index rules, tilt plan, reference alignment, optical properties, FIR bank, PSF
 // evaluation) under AddressSanitizer + UBSan, on ordinary and on edge inputs (shortest axes, bounds outside
-// the axis, zero widths, PSFs wider than the image).  TEST INFRASTRUCTURE ONLY; see tests/test_emu_tsan.py.
+// the axis, zero widths, PSFs wider than the image).  TEST INFRASTRUCTURE ONLY; see tests/test_sanitizers.py.
 #include "deconv_host.hpp"
 #include "host_windows.hpp"
 
