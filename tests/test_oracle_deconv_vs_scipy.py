@@ -92,3 +92,44 @@ def test_richardson_lucy_against_scipy(shape, pshape):
             (lambda a, k: signal.correlate2d(a, k, mode="same"))
     v = iterate(other)
     assert np.abs(got - v).max() / np.abs(v).max() > 1e-3
+
+
+def test_whole_deconvolution_against_a_numpy_model():
+    """Deconvolution::filter end to end (deconvolution.rs:766-1041) as a float64 model: FIR bank -> per band the
+    'same'-filtered cube, its energy image, Richardson-Lucy with the band's PSF and iteration count, gain
+    sqrt(max(u, 0) / d) -> sum of gain-weighted filtered cubes -> intensity image.  The bank and the band PSFs are
+    taken from the (separately pinned) oracle functions, everything else is numpy / scipy."""
+    import os
+    nx, ny, nt = 20, 18, 128
+    time, cube = synth.make_cube(nx, ny, nt)
+    xx, yy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    cube = (cube * (0.4 + 0.6 * ((xx // 3) % 2 == 0))[..., None]).astype(np.float32)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "psf_sample.npz"))
+    psf = ob.psf_from_npz(z)
+    n_iter, nb, f0, f1, width, dx, dy = 6, 5, 0.4, 3.0, 0.5, 0.5, 0.5
+    rc, out, img, gains, niter = ob.deconvolution(cube, time, dx, dy, psf, n_iter, nb, f0, f1, width)
+    assert rc == 0 and niter.max() == n_iter and niter.min() >= 1
+    filters, centers = ob.filter_bank(time, nb, f0, f1, width)
+    taps = filters.shape[1]
+    shift = (taps - 1) // 2
+    c64 = cube.astype(np.float64)
+    model = np.zeros_like(c64)
+    for b in range(nb):
+        h = filters[b].astype(np.float64)
+        y = np.apply_along_axis(lambda v: np.convolve(v, h)[shift:shift + nt], -1, c64)
+        d = (y ** 2).sum(-1)
+        p = ob.band_psf(psf, centers[b], dx, dy, nx, ny).astype(np.float64)
+        py, px = p.shape[0] // 2, p.shape[1] // 2
+        dp = np.pad(d, ((py, py), (px, px)), mode="reflect")
+        cv = (lambda a, k: signal.correlate2d(a, k, mode="same")) if p.size <= 256 else \
+             (lambda a, k: signal.convolve2d(a, k, mode="same"))
+        u = dp.copy()
+        for _ in range(int(niter[b])):
+            t = dp / (cv(u, p) + 1e-12)
+            u = u * cv(t, p[::-1, ::-1])
+        u = u[py:py + nx, px:px + ny]
+        g = np.sqrt(np.maximum(u, 0.0) / d)
+        assert np.abs(gains[b] - g).max() / np.abs(g).max() < 2e-4, b
+        model += g[..., None] * y
+    assert np.abs(out - model).max() / np.abs(model).max() < 2e-4
+    assert np.abs(img - (model ** 2).sum(-1)).max() / (model ** 2).sum(-1).max() < 4e-4
