@@ -128,7 +128,8 @@ extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const fl
         ws[B.off_mirror + i] = psf[taps - 1 - i];
     }
     const unsigned blocks = (unsigned)((img + 255) / 256);
-    const unsigned tiles_n = (unsigned)(B.tiles_w * ((B.H + 15) / 16));
+    B.n_tiles = B.tiles_w * ((B.H + 15) / 16);
+    const unsigned tiles_n = rl_tile_block_count(pr, pc, (unsigned)B.n_tiles);  // blocks of the tiled grid
     std::vector<RlTileRef> tiles(tiles_n, RlTileRef{B});
     for (int step = 0; step < 2; ++step) {
         if (tiled) launch_rl_step_tiled(nullptr, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());

@@ -221,7 +221,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
         B.tblk0 = tblk;
         B.tiles_w = (B.W + 15) / 16;
-        tblk += (unsigned)(B.tiles_w * ((B.H + 15) / 16));
+        B.n_tiles = B.tiles_w * ((B.H + 15) / 16);
+        tblk += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
         tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;

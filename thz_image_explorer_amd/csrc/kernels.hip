@@ -1121,6 +1121,7 @@ __device__ __forceinline__ float rl_tile_taps(const float *origin, int wsz, cons
 constexpr int kRlSplit = 16;            // waves per tile
 constexpr int kRlThreads = 64 * kRlSplit;
 constexpr int kRlPix = 4;               // pixels per thread
+constexpr int kRlTilesPerBlock = 4;     // narrow-kernel tiles per block (one per 256 threads)
 
 __host__ __device__ inline int rl_turned_stride(int wsz)
 {
@@ -1195,6 +1196,15 @@ __host__ __device__ inline size_t rl_tap_floats(int pr, int pc)
 }
 __host__ __device__ inline bool rl_turned(int pr, int pc) { return pr * pc > 256; }  // RlBand::mode == 1
 
+// A block of the tiled grid: one tile of a wide-kernel band (all 16 waves share it, see above), or
+// kRlTilesPerBlock = 4 consecutive tiles of a narrow-kernel band, one per group of 256 threads — a narrow
+// kernel keeps the reference's one-chain-per-pixel sums, so a tile can use 256 threads only, and a block
+// of 1024 that held one such tile left three quarters of its waves with nothing to do but stage.
+__host__ __device__ inline unsigned rl_tile_blocks(bool turned, unsigned n_tiles)
+{
+    return turned ? n_tiles : (n_tiles + kRlTilesPerBlock - 1) / kRlTilesPerBlock;
+}
+
 __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
                                                               const int *__restrict__ it_base, int iteration,
                                                               int step, float *__restrict__ ws)
@@ -1205,63 +1215,82 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *_
     // grid, most of the time) leave after a single memory latency
     const RlBand B = tiles[blockIdx.x].band;
     if (iteration >= B.n_iter) return;  // block-uniform
-    const unsigned lt = blockIdx.x - B.tblk0;
-    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
     const int pr = B.pr, pc = B.pc;
     const bool turned = B.mode != 0;
     const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;  // halo tile
-    const int wsp = turned ? rl_turned_stride(wsz) : wsz;     // its row stride in LDS
-    float *a_s = reinterpret_cast<float *>(smem) + kRlChunk;  // slack in front and behind
-    float *k_s = reinterpret_cast<float *>(smem) + rl_tile_floats(pr, pc, turned);
-    float *part_s = k_s + rl_tap_floats(pr, pc);  // [kRlSplit][256], turned tiles only
+    const int nch = rl_chunks(pc);
     const float *a = ws + (step == 0 ? B.off_u : B.off_t);
     const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
-    // first image row / column of the halo: mode 0 reads x = i + m - pr/2, mode 1 x = i + (pr-1)/2 - m
-    const int r0 = B.mode == 0 ? ti0 - pr / 2 : ti0 + (pr - 1) / 2 - (pr - 1);
-    const int c0 = B.mode == 0 ? tj0 - pc / 2 : tj0 + (pc - 1) / 2 - (pc - 1);
-    // Tile staging: a wave per halo row, lanes along the row, the block's loads all in flight together
-    // (zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was).
-    const int nch = rl_chunks(pc);
-    {
-        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+    if (!turned) {
+        // ---- narrow kernel: four tiles, one per 256-thread group; the taps are staged once for all four
+        const int grp = (int)(threadIdx.x >> 8), px = (int)(threadIdx.x & 255);
+        const unsigned lt = (blockIdx.x - B.tblk0) * kRlTilesPerBlock + (unsigned)grp;
+        const bool live = lt < (unsigned)B.n_tiles;
+        const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+        const size_t tile_fl = rl_tile_floats(pr, pc, false);
+        float *a_s = reinterpret_cast<float *>(smem) + (size_t)grp * tile_fl + kRlChunk;  // slack in front and behind
+        float *k_s = reinterpret_cast<float *>(smem) + kRlTilesPerBlock * tile_fl;
+        // first image row / column of the halo: x = i + m - pr/2
+        const int r0 = ti0 - pr / 2, c0 = tj0 - pc / 2;
+        if (live) {  // zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was
+            const int wv = px >> 6, ln = px & 63;
 #pragma unroll 4
-        for (int r = wv; r < hs; r += kRlThreads / kWave) {
-            const int x = r0 + r;
-            const bool xin = x >= 0 && x < B.H;
-            float *dst = a_s + (turned ? hs - 1 - r : r) * wsp;
-            for (int c = ln; c < wsp; c += kWave) {
-                const int y = c0 + c;
-                const float v = (c < wsz && xin && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
-                dst[c < wsz ? (turned ? wsz - 1 - c : c) : c] = v;
+            for (int r = wv; r < hs; r += 4) {
+                const int x = r0 + r;
+                const bool xin = x >= 0 && x < B.H;
+                for (int c = ln; c < wsz; c += kWave) {
+                    const int y = c0 + c;
+                    a_s[r * wsz + c] = (xin && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
+                }
             }
         }
-        if (threadIdx.x < kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // the slack behind the last row (the taps start right after it)
-    }
-    if (turned) {  // padded rows: a wave per kernel row
-        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
-        for (int m = wv; m < pr; m += kRlThreads / kWave)
-            for (int n = ln; n < nch * kRlChunk; n += kWave) k_s[m * nch * kRlChunk + n] = n < pc ? k[m * pc + n] : 0.0f;
-    } else {       // the order rl_tile_taps consumes them in
-        const int n_el = pr * nch * kRlChunk;
-        for (int e = (int)threadIdx.x; e < n_el; e += kRlThreads) {
-            const int t = e / kRlChunk, q = e % kRlChunk;
-            const int m = t / nch, c = t - m * nch;
-            const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
-            k_s[e] = src >= 0 ? k[src] : 0.0f;
+        {   // the order rl_tile_taps consumes them in
+            const int n_el = pr * nch * kRlChunk;
+            for (int e = (int)threadIdx.x; e < n_el; e += kRlThreads) {
+                const int t = e / kRlChunk, q = e % kRlChunk;
+                const int m = t / nch, c = t - m * nch;
+                const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
+                k_s[e] = src >= 0 ? k[src] : 0.0f;
+            }
         }
-    }
-    __syncthreads();
-    if (!turned) {
-        const int px = (int)threadIdx.x;
+        __syncthreads();
         const int ti = px / kRlTile, tj = px % kRlTile;
         const int i = ti0 + ti, j = tj0 + tj;
-        if (px >= 256 || i >= B.H || j >= B.W) return;  // no barrier below on this path
+        if (!live || i >= B.H || j >= B.W) return;  // no barrier below on this path
         const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);
         const int idx = i * B.W + j;
         if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
         else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
         return;
     }
+    // ---- wide kernel: one tile, stored turned by 180 degrees, the kernel's rows dealt to the 16 waves
+    const unsigned lt = blockIdx.x - B.tblk0;
+    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+    const int wsp = rl_turned_stride(wsz);                    // the tile's row stride in LDS
+    float *a_s = reinterpret_cast<float *>(smem) + kRlChunk;  // slack in front and behind
+    float *k_s = reinterpret_cast<float *>(smem) + rl_tile_floats(pr, pc, true);
+    float *part_s = k_s + rl_tap_floats(pr, pc);  // [kRlSplit][256]
+    // first image row / column of the halo: x = i + (pr-1)/2 - m
+    const int r0 = ti0 + (pr - 1) / 2 - (pr - 1), c0 = tj0 + (pc - 1) / 2 - (pc - 1);
+    {   // a wave per halo row, lanes along the row, the block's loads all in flight together
+        const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+#pragma unroll 4
+        for (int r = wv; r < hs; r += kRlThreads / kWave) {
+            const int x = r0 + r;
+            const bool xin = x >= 0 && x < B.H;
+            float *dst = a_s + (hs - 1 - r) * wsp;
+            for (int c = ln; c < wsp; c += kWave) {
+                const int y = c0 + c;
+                const float v = (c < wsz && xin && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
+                dst[c < wsz ? wsz - 1 - c : c] = v;
+            }
+        }
+        if (threadIdx.x < kRlChunk) a_s[hs * wsp + (int)threadIdx.x] = 0.0f;  // the slack behind the last row (the taps start right after it)
+        // padded rows of taps: a wave per kernel row
+        for (int m = wv; m < pr; m += kRlThreads / kWave)
+            for (int n = ln; n < nch * kRlChunk; n += kWave) k_s[m * nch * kRlChunk + n] = n < pc ? k[m * pc + n] : 0.0f;
+    }
+    __syncthreads();
     const int px = (int)threadIdx.x;
     const int i = ti0 + px / kRlTile, j = tj0 + px % kRlTile;
     const bool writer = px < 256 && i < B.H && j < B.W;
@@ -1987,8 +2016,11 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 size_t rl_tile_lds_bytes(int pr, int pc)
 {
     const bool turned = rl_turned(pr, pc);
-    return (rl_tile_floats(pr, pc, turned) + rl_tap_floats(pr, pc) + (turned ? (size_t)kRlSplit * 256 : 0)) * sizeof(float);
+    if (!turned) return (kRlTilesPerBlock * rl_tile_floats(pr, pc, false) + rl_tap_floats(pr, pc)) * sizeof(float);
+    return (rl_tile_floats(pr, pc, true) + rl_tap_floats(pr, pc) + (size_t)kRlSplit * 256) * sizeof(float);
 }
+
+unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles) { return rl_tile_blocks(rl_turned(pr, pc), n_tiles); }
 
 void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
 

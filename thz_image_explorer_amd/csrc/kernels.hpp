@@ -49,6 +49,7 @@ struct RlBand {
     unsigned blk0;      // first block of this band in the flattened grid (256 pixels per block)
     unsigned tblk0;     // first block of this band in the tiled grid (16 x 16 pixels per block)
     int tiles_w;        // tiles per row of the padded image
+    int n_tiles;        // tiles of the padded image (a block holds one, or four for kernels of <= 256 taps)
     unsigned off_d, off_u, off_t, off_psf, off_mirror;
 };
 
@@ -66,6 +67,7 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
                     const int *it_base, int iteration, int step, float *ws);
 // LDS-tiled form of the same step: total_tiles blocks, lds_bytes = rl_tile_lds_bytes of the largest band
 size_t rl_tile_lds_bytes(int pr, int pc);
+unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles);  // blocks of the tiled grid a band's tiles take
 void prepare_rl_step_tiled(size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
 // per tile of the tiled grid: its band's record by value — a block needs one (scalar) load to know
 // whether its band still iterates and everything else about it, not a chain of two
