@@ -84,6 +84,14 @@ int main(int argc, char **argv)
             emu_rl_iteration(h, w, pr, pc, mode, psf.data(), d.data(), u.data(), 1, t.data(), un.data());
             emu_rl_iteration(h, w, pr, pc, mode, psf.data(), d.data(), u.data(), 0, t.data(), un.data());
         }
+        {   // six tiles of a narrow kernel: the second block has two groups of threads without a tile
+            const int h = 20, w = 30, pr = 7, pc = 9;
+            const int H = h + 2 * (pr / 2), W = w + 2 * (pc / 2);
+            auto d = noise((size_t)H * W, 25, 0.5f, 1.5f), u = noise((size_t)H * W, 26, 0.5f, 1.5f);
+            auto psf = noise((size_t)pr * pc, 27, 0.0f, 1.0f);
+            std::vector<float> t((size_t)H * W), un((size_t)H * W);
+            emu_rl_iteration(h, w, pr, pc, 0, psf.data(), d.data(), u.data(), 1, t.data(), un.data());
+        }
         std::printf("rl done\n");
     }
     if (want("dc")) {
