@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define THZGPU_ABI_VERSION 1
+#define THZGPU_ABI_VERSION 2
 
 typedef struct thz_ctx thz_ctx;
 
@@ -223,6 +223,35 @@ int thz_polar_ifft(thz_ctx *ctx, const float *amp, const float *phase, int zero_
 int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_pre_win,
                  const float *d_fd_mask, const float *d_post_win, float *d_fft, float *d_amp,
                  float *d_phase, float *d_data_out, float *d_img);
+
+/* The same launch with every optional input and output of the fused chain:
+ *   d_fd_cmask  (nf) interleaved complex per-bin multiplier or NULL — the build-defined
+ *               reference-pulse (Wiener) filter K13 (thz_host_wiener_filter) inside the
+ *               ONE pass over HBM: spectrum = X * (cmask * mask), imaginary parts of bin 0 and (even
+ *               nt) of the last bin forced to 0 (math_tools.rs:510-512), amplitudes = |X cmask mask|,
+ *               phases those of X (band_pass_fd.rs:184-212 does not touch them either).  Trace lengths
+ *               without a fused kernel for it run fft -> thz_apply_fd_cmask -> ifft internally.
+ *   d_sums      (2 nf) or NULL: sum over the npix traces of the stored amplitudes [0, nf) and of the
+ *               unwrapped phases [nf, 2 nf) — the numerators of the pixel means of the ifft stage
+ *               (math_tools.rs:427-440; divide by nx ny, or all-reduce the sums of the tiles first).
+ *               Accumulated inside the launch where the kernel can (nt = 1024 / 2048 / 4096), otherwise
+ *               by thz_pixel_sum passes over d_amp / d_phase.  Summation order differs from the
+ *               reference's sequential one (<= 1e-6 relative); thz_pixel_mean is the bit-exact form.
+ * d_fft, d_amp, d_phase and d_data_out are required here. */
+typedef struct thz_pipeline_io {
+    const float *d_raw;      /* (npix, nt) */
+    const float *d_pre_win;  /* (nt) or NULL */
+    const float *d_fd_mask;  /* (nf) real or NULL */
+    const float *d_fd_cmask; /* (nf) complex or NULL */
+    const float *d_post_win; /* (nt) or NULL */
+    float *d_fft;            /* (npix, nf) complex */
+    float *d_amp;            /* (npix, nf) */
+    float *d_phase;          /* (npix, nf) */
+    float *d_data_out;       /* (npix, nt) */
+    float *d_img;            /* (npix) or NULL */
+    float *d_sums;           /* (2 nf) or NULL */
+} thz_pipeline_io;
+int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io);
 
 /* Time multiplier alone (K6): out = in * win; in place allowed. */
 int thz_apply_td_window(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win,

@@ -32,7 +32,7 @@ def test_binding_covers_header():
 
 
 def test_abi_version():
-    assert pkg.load_library().thz_abi_version() == 1
+    assert pkg.load_library().thz_abi_version() == 2
 
 
 def test_no_cpu_fallback():

@@ -333,3 +333,71 @@ def test_filter_spectra_kernel(emu):
     assert emu.emu_dc_filter_spectra(_p(h), nb, taps, M, _p(H)) == 0
     ref = np.fft.rfft(h.astype(np.float64), M, axis=-1) / M
     assert np.abs((H[..., 0] + 1j * H[..., 1]) - ref).max() / np.abs(ref).max() < 2e-7
+
+
+def _wiener_cmask(time, nf):
+    """K13 multiplier from the synthetic reference pulse (the noise-free template of SURVEY §8d), in numpy fp64
+    -> f32: H = conj(R) / (|R|^2 + eps max|R|^2), R = rfft(window * reference)"""
+    z = ((time - time[0] - 11.0) / 0.35).astype(np.float64)
+    ref = -z * np.exp(-z * z)
+    w = ob.apply_window(0, np.ones(time.size, np.float32), time, 1.0, 7.0).astype(np.float64)
+    R = np.fft.rfft(ref * w)
+    H = np.conj(R) / (np.abs(R) ** 2 + 1e-2 * (np.abs(R) ** 2).max())
+    out = np.empty((nf, 2), np.float32)
+    out[:, 0] = H.real
+    out[:, 1] = H.imag
+    return out
+
+
+@pytest.mark.parametrize("bar", [0, 1, 3])
+@pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums"])
+@pytest.mark.parametrize("nt", [1024, 2048, 4096])
+def test_fused_pipeline_cmask_sums_barriers(emu, nt, mode, bar):
+    """k_f<pipe> with the complex per-bin multiplier (K13), the in-launch pixel sums and the store-phase
+    barriers: same results as the plain fused chain / a numpy fp64 model of it"""
+    emu.emu_allow_f(1)
+    emu.emu_set_f_bar(bar)
+    try:
+        nx, ny = 3, 7   # 21 traces: ragged last round in every block shape (8, 7 or 6 waves)
+        time, cube = synth.make_cube(nx, ny, nt)
+        chain = synth.default_chain(time, backend=None)
+        npix, nf = nx * ny, nt // 2 + 1
+        H = _wiener_cmask(time, nf) if "cmask" in mode else None
+        fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+        ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+        sums = np.zeros(2 * nf, np.float32) if "sums" in mode else None
+        rc = emu.emu_pipeline_ex(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                 _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img), _p(sums))
+        assert rc == 0
+        ref = ob.run_pipeline(cube, time, chain)
+        scale = np.abs(ref["fft"]).max()
+        if H is None:
+            assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+            assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+            assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / np.abs(ref["data"]).max() < 1e-5
+        else:
+            # fp64 model: Y = rfft(pre * x) * H * mask with real DC / Nyquist, irfft, post window
+            X = np.fft.rfft(cube.reshape(npix, nt).astype(np.float64) * chain["w_pre"].astype(np.float64), axis=1)
+            Hc = (H[:, 0].astype(np.float64) + 1j * H[:, 1]) * chain["fd_mask"]
+            Y = X * Hc
+            a_ref = np.abs(Y)
+            Y[:, 0] = Y[:, 0].real
+            Y[:, -1] = Y[:, -1].real
+            t_ref = np.fft.irfft(Y, n=nt, axis=1) * chain["w_post"]
+            got = fft[..., 0] + 1j * fft[..., 1]
+            assert np.abs(got - Y).max() / np.abs(Y).max() < 1e-5
+            assert np.all(fft[:, 0, 1] == 0) and np.all(fft[:, -1, 1] == 0)
+            assert np.abs(amp - a_ref).max() / a_ref.max() < 1e-5
+            assert np.abs(out - t_ref).max() / np.abs(t_ref).max() < 1e-5
+            assert np.abs(img - (t_ref ** 2).sum(1)).max() / (t_ref ** 2).sum(1).max() < 1e-5
+        # phases are those of X in every mode
+        d = ph.reshape(ref["phases"].shape) - ref["phases"]
+        strong = ref["amplitudes"] > 0.05 * ref["amplitudes"].max(axis=-1, keepdims=True)
+        d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+        assert np.abs(d[strong | (np.abs(d) < 1)]).max() < 3e-3
+        if sums is not None:
+            sa, sp = amp.astype(np.float64).sum(0), ph.astype(np.float64).sum(0)
+            assert np.abs(sums[:nf] - sa).max() <= 2e-6 * max(np.abs(sa).max(), 1e-30)
+            assert np.abs(sums[nf:] - sp).max() <= 2e-6 * max(np.abs(sp).max(), 1e-30)
+    finally:
+        emu.emu_set_f_bar(-1)

@@ -92,6 +92,11 @@ class ChainCfg(C.Structure):
                 ("td_after_width", C.c_double), ("want_means", C.c_int32), ("scale_factor", C.c_int32)]
 
 
+class PipelineIo(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_raw", "d_pre_win", "d_fd_mask", "d_fd_cmask", "d_post_win", "d_fft", "d_amp",
+                                          "d_phase", "d_data_out", "d_img", "d_sums")]
+
+
 class PlotOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("signal", "signal_fft", "phase_fft", "filtered_signal", "filtered_signal_fft",
                                   "filtered_phase_fft", "avg_signal", "avg_signal_fft", "avg_phase_fft")]
@@ -144,6 +149,7 @@ SYMBOLS = [
     ("thz_apply_fd_cmask", C.c_int, [_P, _SZ, _P, _P, _P]),
     ("thz_ifft", C.c_int, [_P, _SZ, _P, _P, _P, _P]),
     ("thz_pipeline", C.c_int, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("thz_pipeline_ex", C.c_int, [_P, _SZ, _P]),
     ("thz_apply_td_window", C.c_int, [_P, _SZ, _P, _P, _P]),
     ("thz_intensity", C.c_int, [_P, _SZ, _P, _P]),
     ("thz_subtract_bias", C.c_int, [_P, _SZ, _P, _P]),
@@ -584,6 +590,11 @@ class Engine:
 
     def ifft(self, npix, fft, td_win, data_out, img=None):
         self._check(self.lib.thz_ifft(self.ctx, npix, _dp(fft), _dp(td_win), _dp(data_out), _dp(img)))
+
+    def pipeline_ex(self, npix, raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img=None, sums=None):
+        """thz_pipeline_ex: the fused chain with a complex per-bin multiplier and / or in-launch pixel sums"""
+        io = PipelineIo(*[_dp(x) for x in (raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img, sums)])
+        self._check(self.lib.thz_pipeline_ex(self.ctx, npix, C.byref(io)))
 
     def pipeline(self, npix, raw, pre_win, fd_mask, post_win, fft, amp, phase, data_out, img):
         self._check(self.lib.thz_pipeline(self.ctx, npix, _dp(raw), _dp(pre_win), _dp(fd_mask),

@@ -137,6 +137,16 @@ __device__ __forceinline__ int nat(int k) { return k ^ ((k >> 5) & 3); }
 __device__ __forceinline__ cx2 ld2(const cx *p) { return *reinterpret_cast<const cx2 *>(p); }
 __device__ __forceinline__ void st2(cx *p, cx a, cx b) { *reinterpret_cast<cx2 *>(p) = cx2{a, b}; }
 
+// Compile-time configuration bits of k_f.  Runtime null checks inside the fully
+// unrolled passes turn into dozens of tiny basic blocks and make the register
+// allocator spill, so everything optional is a template flag instead.
+enum : int {
+    kCfgAmpPhase = 1,  // also write |X| and the unwrapped phase
+    kCfgCMask = 2,     // the per-bin multiplier is complex (K13, reference-pulse Wiener filter)
+    kCfgSums = 4,      // per-bin pixel sums of |X| m and of the unwrapped phase (math_tools.rs:427-440), needs kCfgAmpPhase
+    kCfgBar = 8        // the block's waves meet at a barrier before each store phase (FArgs::bar says which)
+};
+
 // ------------------------------------------------------------------- the plan
 template <int R1_, int R2_, int R3_>
 struct FPlan {
@@ -151,10 +161,14 @@ struct FPlan {
     static_assert(R3 == 8, "pass-2 lane map assumes R3 = 8");
     static_assert(C1 == 1 || C1 == 2, "C1");
     static_assert(C2 >= 1 && C3 >= 1, "lanes must all own a butterfly");
-    // LDS per block, in cx: [T1: R1*M1][T2: R2*R3][mask: nf floats][per wave: N + 2]
+    // LDS per block, in cx: [T1: R1*M1][T2: R2*R3][mask: nf floats, or nf cx][extra][sums][per wave: N + 2]
     static constexpr int T1_ENTRIES = R1 * M1;
     static constexpr int T2_ENTRIES = R2 * R3;
-    static constexpr int MASK_ENTRIES = (N + 4) / 2;  // N + 1 floats, padded to 16 bytes
+    // N + 1 floats (real multiplier) or N + 1 cx (complex multiplier), padded to 16 bytes; the two
+    // floats of padding behind a real mask / the last cx behind a complex one hold the window block bits
+    static constexpr int mask_entries(int cfg) { return (cfg & kCfgCMask) ? N + 2 : (N + 4) / 2; }
+    // block accumulators of kCfgSums: [amp: N floats][phase: N floats][Nyquist amp, phase]
+    static constexpr int sums_entries(int cfg) { return (cfg & kCfgSums) ? N + 2 : 0; }
     static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
     // Small trace-invariant tables the trace loop reads, staged once per block so that no
     // vector-memory load sits between the loop's stores (a load's result can only be waited
@@ -168,9 +182,10 @@ struct FPlan {
     static constexpr int WIN_SLOTS = (N >= 2048) ? 4 : 6;  // 160 KB LDS leaves room for 4 at nt = 4096
     static constexpr int EXTRA_ENTRIES = W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
     static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
-    static constexpr size_t lds_bytes(int waves)
+    static constexpr size_t lds_bytes(int waves, int cfg = 0)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + MASK_ENTRIES + EXTRA_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + sums_entries(cfg)
+                        + waves * WAVE_ENTRIES) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -404,6 +419,25 @@ __device__ __forceinline__ void load_f4(const float *p, float &a, float &b, floa
 }
 #endif
 
+// ds_add_f32 on a block accumulator (no return value: fire and forget on the LDS pipe)
+__device__ __forceinline__ void lds_add(float *p, float v)
+{
+#ifdef THZ_EMU
+    uint32_t *u = reinterpret_cast<uint32_t *>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        float f;
+        __builtin_memcpy(&f, &old, 4);
+        f += v;
+        uint32_t nw;
+        __builtin_memcpy(&nw, &f, 4);
+        if (__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+    }
+#else
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
 struct FArgs {
     size_t npix;
     const float *in;        // (npix, nt) raw traces            [fwd, pipeline]
@@ -412,20 +446,19 @@ struct FArgs {
     float *amp_out;         // (npix, nf), required when the kernel is built with AMP_PHASE
     float *ph_out;          // (npix, nf), required when the kernel is built with AMP_PHASE
     const float *mask;      // (nf), required (a vector of ones when no band-pass is wanted)
+    const cx *cmask;        // (nf) complex per-bin multiplier, required when the kernel is built with kCfgCMask;
+                            // the staged table is cmask[k] * mask[k]
+    float *sums;            // (gridDim.x, 2 nf) per-block partial sums [amp | phase], required with kCfgSums
+    int bar;                // block barriers in the trace loop: bit 0 before the spectrum stores, bit 1 before
+                            // the time stores, bit 2: with a workgroup fence (__syncthreads) instead of a bare s_barrier
     const cx *fft_in;      // (npix, nf)                        [inv only]
     const float *post_win;  // (nt); may be null only when post_blocks == 0
     float *data_out;        // (npix, nt) final trace            [inv, pipeline]
     float *img;             // (npix) or null
 };
 
-// Compile-time configuration bits of k_f.  Runtime null checks inside the fully
-// unrolled passes turn into dozens of tiny basic blocks and make the register
-// allocator spill, so everything optional is a template flag instead.
-enum : int {
-    kCfgAmpPhase = 1  // also write |X| and the unwrapped phase
-};
-
 enum : int { kFwd = 0, kInv = 1, kPipe = 2 };
+constexpr int kFBarDefault = 0;  // FArgs::bar of every launch unless THZ_F_BAR says otherwise
 
 // Loads one trace's samples for this lane: raw[j1][4] (C1 = 2) or raw[j1][2].
 template <class P>
@@ -513,11 +546,19 @@ __device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
 //   groups g >= NG/2: bins k = 256 g + 4 lane + c are read back as X and finished
 //   bin N           : lane 0, after the last group
 // so the unwrap scan always runs over ascending bins.
-template <class P, bool AMP_PHASE>
+//
+// CMASK: `mask` points to nf complex multipliers H[k]; the stored spectrum is X H (imaginary part of
+// bin 0 and of the Nyquist bin forced to 0: the C2R precondition, math_tools.rs:510-512), the stored
+// amplitude |X H| (taken before the forcing); phases are those of X, as with the real band pass
+// (band_pass_fd.rs:184-212 leaves them alone).  buf keeps the unmultiplied X.
+// SUMS: adds the stored amplitudes and unwrapped phases to the block's accumulators `sums`
+// ([amp: slot (4 g + c) 64 + lane <-> bin 256 g + 4 lane + c][phase: same, + N][Nyquist amp, phase]).
+template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
-                                                    const float *mask, size_t p, const FArgs &A,
+                                                    const float *mask, float *sums, size_t p, const FArgs &A,
                                                     int lane)
 {
+    static_assert(!SUMS || AMP_PHASE, "sums are those of the amplitude / phase outputs");
     constexpr int N = P::N, NG = P::NG;
     static_assert(NG % 2 == 0, "pair ownership splits the groups in halves");
     const int nf = N + 1;
@@ -567,18 +608,44 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) X[c] = zf[fb[c]];
         }
-        float m[4];
-        {
-            const float4 mv = *reinterpret_cast<const float4 *>(mask + k0);  // LDS copy
-            m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
-        }
-        if constexpr (AMP_PHASE) {
-            float a[4];
+        if constexpr (CMASK) {
+            cx Y[4];
+            {
+                const cx *hm = reinterpret_cast<const cx *>(mask) + k0;  // LDS copy
+                const cx2 h01 = ld2(hm), h23 = ld2(hm + 2);
+                Y[0] = cx_mul(X[0], h01.a); Y[1] = cx_mul(X[1], h01.b);
+                Y[2] = cx_mul(X[2], h23.a); Y[3] = cx_mul(X[3], h23.b);
+            }
+            if constexpr (AMP_PHASE) {
+                float a[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
-            store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
-        }
-        {
+                for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(Y[c].x, Y[c].x, Y[c].y * Y[c].y));
+                store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
+                if constexpr (SUMS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lds_add(sums + (4 * g + c) * kWave + lane, a[c]);
+                }
+            }
+            if (g == 0 && lane == 0) Y[0].y = 0.0f;  // bin 0
+            float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
+            store_f4(f, Y[0].x, Y[0].y, Y[1].x, Y[1].y);
+            store_f4(f + 4, Y[2].x, Y[2].y, Y[3].x, Y[3].y);
+        } else {
+            float m[4];
+            {
+                const float4 mv = *reinterpret_cast<const float4 *>(mask + k0);  // LDS copy
+                m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
+            }
+            if constexpr (AMP_PHASE) {
+                float a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+                store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
+                if constexpr (SUMS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lds_add(sums + (4 * g + c) * kWave + lane, a[c]);
+                }
+            }
             float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
             store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
             store_f4(f + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
@@ -614,6 +681,10 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = first + (base + s_[c]);
             store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
+            if constexpr (SUMS) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lds_add(sums + N + (4 * g + c) * kWave + lane, y[c]);
+            }
             carry += wave_bcast<kWave - 1>(incl);
             prev_tail = wave_bcast<kWave - 1>(ph[3]);
             if (g == NG - 1) {
@@ -624,15 +695,26 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
     }
     // Nyquist bin k = N (real): lane 0
     if (lane == 0) {
-        const float mN = mask[N];
         const float xr = buf[N].x;
-        A.fft_out[p * nf + N] = cx{xr * mN, 0.0f};
-        if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = fabsf(xr) * mN;
+        float aN;
+        if constexpr (CMASK) {
+            const cx hN = reinterpret_cast<const cx *>(mask)[N];
+            const cx yN = cx{xr * hN.x, xr * hN.y};
+            A.fft_out[p * nf + N] = cx{yN.x, 0.0f};
+            aN = fast_sqrt(fmaf(yN.x, yN.x, yN.y * yN.y));
+        } else {
+            const float mN = mask[N];
+            A.fft_out[p * nf + N] = cx{xr * mN, 0.0f};
+            aN = fabsf(xr) * mN;
+        }
+        if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = aN;
+        if constexpr (SUMS) lds_add(sums + 2 * N, aN);
         if constexpr (want_phase) {
             const float phn = fast_atan2f(0.0f, xr);
             float d = phn - last_raw;
             d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);
             A.ph_out[p * nf + N] = last_unwrapped + d;
+            if constexpr (SUMS) lds_add(sums + 2 * N + 1, last_unwrapped + d);
         }
     }
 }
@@ -642,7 +724,9 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 // held in buf in the nat() layout (X[N] real at buf[N]).  MASKED: multiply by
 // the band-pass mask on the way (fused chain; the stored copy is unmasked so
 // that the phases of the whole spectrum could be taken).
-template <class P, bool MASKED>
+// CMASK (with MASKED): the multiplier is complex, mask points to nf cx; X[0] H[0] and X[N] H[N] lose their
+// imaginary parts after the multiply.
+template <class P, bool MASKED, bool CMASK = false>
 __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, const cx *wg_s,
                                                 const float *__restrict__ mask, int lane,
                                                 cx (&r)[P::C1][P::R1])
@@ -674,7 +758,7 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
             const cx wc = j1 == 0 ? wlc[c] : cx_mul(wlc[c], wgc);
             cx xk = buf[fbase[j1 & 1][c] + M1 * j1];
             cx xn = buf[mbase[j1 & 1][c] - M1 * j1];
-            if (off == 0) {
+            if (off == 0 && !(MASKED && CMASK)) {
                 // n == 0 only in lane 0: X[0] and X[N] are real (realfft ignores /
                 // rejects their imaginary parts, SURVEY a'-4)
                 if (lane == 0) {
@@ -682,7 +766,15 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
                     xn.y = 0.0f;
                 }
             }
-            if constexpr (MASKED) {
+            if constexpr (MASKED && CMASK) {
+                const cx *hm = reinterpret_cast<const cx *>(mask);
+                xk = cx_mul(xk, hm[mk_f + off]);
+                xn = cx_mul(xn, hm[mk_r + (TOP - off)]);
+                if (off == 0 && lane == 0) {
+                    xk.y = 0.0f;
+                    xn.y = 0.0f;
+                }
+            } else if constexpr (MASKED) {
                 const float mk = mask[mk_f + off], mn = mask[mk_r + (TOP - off)];
                 xk = cx{xk.x * mk, xk.y * mk};
                 xn = cx{xn.x * mn, xn.y * mn};
@@ -780,6 +872,18 @@ __device__ __forceinline__ void f_land_prefetch(float (&raw)[P::R1][2 * P::C1])
         for (int i = 0; i < 2 * P::C1; ++i) raw[j][i] = launder_f(raw[j][i]);
 }
 
+// the waves of a block only align their store phases here; they share no data, so no fence is needed
+__device__ __forceinline__ void f_block_barrier(int mode)
+{
+#ifdef THZ_EMU
+    (void)mode;
+    __syncthreads();
+#else
+    if (mode & 4) __syncthreads();
+    else __builtin_amdgcn_s_barrier();
+#endif
+}
+
 struct FTrue { static constexpr bool value = true; };
 struct FFalse { static constexpr bool value = false; };
 
@@ -789,6 +893,9 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     THZ_DYN_LDS(lds);
     constexpr int N = P::N, NT = P::NT, R1 = P::R1, C1 = P::C1;
     constexpr bool AMP_PHASE = (CFG & kCfgAmpPhase) != 0;
+    constexpr bool CMASK = (CFG & kCfgCMask) != 0 && MODE != kInv;
+    constexpr bool SUMS = (CFG & kCfgSums) != 0 && MODE != kInv;
+    constexpr int ME = P::mask_entries(CFG);
     const int nf = N + 1;
     const int lane = lane_id();
     const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
@@ -796,18 +903,29 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     cx *t1 = reinterpret_cast<cx *>(lds);
     cx *t2 = t1 + P::T1_ENTRIES;
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES);
-    cx *w2n_s = t2 + P::T2_ENTRIES + P::MASK_ENTRIES;
+    cx *w2n_s = t2 + P::T2_ENTRIES + ME;
     cx *wg_s = w2n_s + P::W2N_HEAD;
     float *win_s = reinterpret_cast<float *>(wg_s + P::WG_ENTRIES);
-    cx *buf = t2 + P::T2_ENTRIES + P::MASK_ENTRIES + P::EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    float *sums_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES);
+    cx *buf = t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + P::sums_entries(CFG) + (size_t)wib * P::WAVE_ENTRIES;
     for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[P::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
-    if (MODE != kInv)
+    if constexpr (CMASK) {
+        cx *cm = reinterpret_cast<cx *>(mask_s);
+        for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) {
+            const float m = A.mask[i];
+            const cx h = A.cmask[i];
+            cm[i] = cx{h.x * m, h.y * m};
+        }
+    } else if (MODE != kInv) {
         for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
-    // window block bits (see f_edge_only), kept in the two pad floats behind the mask
-    unsigned int *bits = reinterpret_cast<unsigned int *>(mask_s + (2 * P::MASK_ENTRIES - 2));
+    }
+    if constexpr (SUMS)
+        for (int i = (int)threadIdx.x; i < 2 * P::sums_entries(CFG); i += (int)blockDim.x) sums_s[i] = 0.0f;
+    // window block bits (see f_edge_only), kept in the padding behind the mask
+    unsigned int *bits = reinterpret_cast<unsigned int *>(mask_s + (2 * ME - 2));
     if (threadIdx.x < 2) bits[threadIdx.x] = 0u;
     __syncthreads();
     {
@@ -879,14 +997,19 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // every trace — the back edge has this trace's 16+ stores behind the prefetch, which need
     // not have completed.
     f_land_prefetch<P>(raw);
-    auto trace_loop = [&](auto fast_tag) {
+    // BAR (kCfgBar): the block's waves meet at a barrier before each store phase, so that the
+    // eight adjacent rows a block owns in every output array are written within one short window
+    // (scripts/probe_shapes.hip, S8 / S9: the same bytes move 8 % faster that way).  The loop then has
+    // a block-uniform trip count; a wave without a trace in the last round only takes the barriers.
+    auto trace_loop = [&](auto fast_tag, auto bar_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
-    for (; p < A.npix; p += stride) {
+    constexpr bool BAR = decltype(bar_tag)::value;
+    const float *mask_l = launder_uniform((const float *)mask_s);
+    auto part_a = [&]() {
         cx r[C1][R1];
         ad.refresh();
         if constexpr (MODE != kInv) {
             const float *pre_w = launder_uniform(A.pre_win);
-            const float *mask_l = launder_uniform((const float *)mask_s);
             // window, then hand the samples to pass 1
             if (FAST || pre_edge) {
 #pragma unroll
@@ -920,23 +1043,6 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             if (MODE == kFwd && p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
             f_core_pass23<P>(buf, t2, ad, lane);
             if (MODE == kFwd) f_land_prefetch<P>(raw);
-            f_spectrum_epilogue<P, AMP_PHASE>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
-                                              mask_l, p, A, lane);
-            if constexpr (MODE == kPipe) {
-                f_inverse_input<P, true>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
-                                         lane, r);
-                wave_sync();  // every lane has read Z before the core overwrites buf
-                f_core_pass1<P>(r, buf, t1, ad, lane);
-                if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
-                f_core_pass23<P>(buf, t2, ad, lane);
-                f_land_prefetch<P>(raw);
-                if (FAST) f_time_epilogue<P, false, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
-                else if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
-                else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
-                wave_sync();
-            } else {
-                wave_sync();
-            }
         } else {
             // prefetched spectrum -> LDS in the nat() layout, X[N] at buf[N]
             {
@@ -965,12 +1071,53 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 x_nyq_next = A.fft_in[(p + stride) * nf + N].x;
             }
             f_core_pass23<P>(buf, t2, ad, lane);
+        }
+    };
+    // spectrum stores (+ the inverse transform of the fused chain)
+    auto part_b = [&]() {
+        if constexpr (MODE != kInv) {
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS>(buf, launder_uniform((const cx *)w2n_s),
+                                                           launder_uniform((const cx *)wg_s), mask_l,
+                                                           const_cast<float *>(launder_uniform((const float *)sums_s)), p, A, lane);
+            if constexpr (MODE == kPipe) {
+                cx r[C1][R1];
+                f_inverse_input<P, true, CMASK>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
+                                                lane, r);
+                wave_sync();  // every lane has read Z before the core overwrites buf
+                f_core_pass1<P>(r, buf, t1, ad, lane);
+                if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
+                f_core_pass23<P>(buf, t2, ad, lane);
+            }
+        }
+    };
+    // time-domain stores
+    auto part_c = [&]() {
+        if constexpr (MODE != kFwd) {
             f_land_prefetch<P>(raw);
-            x_nyq_next = launder_f(x_nyq_next);
+            if constexpr (MODE == kInv) x_nyq_next = launder_f(x_nyq_next);
             if (FAST) f_time_epilogue<P, false, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
-                else if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
+            else if (post_edge) f_time_epilogue<P, false>(buf, p, A, post_blocks, win_s, post_slots, lane);
             else f_time_epilogue<P, true>(buf, p, A, post_blocks, win_s, post_slots, lane);
-            wave_sync();
+        }
+        wave_sync();
+    };
+    if constexpr (!BAR) {
+        for (; p < A.npix; p += stride) {
+            part_a();
+            part_b();
+            part_c();
+        }
+    } else {
+        const size_t p_first = (size_t)blockIdx.x * wpb;  // the block's wave 0 has the most traces
+        const size_t iters = p_first < A.npix ? (A.npix - p_first + stride - 1) / stride : 0;
+        const int bar = THZ_UNIFORM(A.bar);
+        for (size_t it = 0; it < iters; ++it, p += stride) {
+            const bool on = p < A.npix;
+            if (on) part_a();
+            if (MODE != kInv && (bar & 1)) f_block_barrier(bar);
+            if (on) part_b();
+            if (MODE != kFwd && (bar & 2)) f_block_barrier(bar);
+            if (on) part_c();
         }
     }
     };
@@ -981,8 +1128,28 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
         if (MODE != kInv && ((pre_blocks >> j) & 1u) && ((pre_slots >> (4 * e)) & 15u) == 15u) all_staged = false;
         if (MODE != kFwd && ((post_blocks >> j) & 1u) && ((post_slots >> (4 * e)) & 15u) == 15u) all_staged = false;
     }
-    if (pre_edge && post_edge && all_staged) trace_loop(FTrue{});
-    else trace_loop(FFalse{});
+    if constexpr ((CFG & kCfgBar) != 0) {
+        if (pre_edge && post_edge && all_staged) trace_loop(FTrue{}, FTrue{});
+        else trace_loop(FFalse{}, FTrue{});
+    } else {
+        if (pre_edge && post_edge && all_staged) trace_loop(FTrue{}, FFalse{});
+        else trace_loop(FFalse{}, FFalse{});
+    }
+    if constexpr (SUMS) {
+        // every wave of the block has left its trace loop: hand the block's accumulators over, bins
+        // in natural order ([amp nf | phase nf] per block; the caller adds the gridDim.x rows)
+        __syncthreads();
+        float *dst = A.sums + (size_t)blockIdx.x * (size_t)(2 * nf);
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
+            const int k = 256 * (i >> 8) + 4 * (i & 63) + ((i >> 6) & 3);
+            dst[k] = sums_s[i];
+            dst[nf + k] = sums_s[N + i];
+        }
+        if (threadIdx.x == 0) {
+            dst[N] = sums_s[2 * N];
+            dst[nf + N] = sums_s[2 * N + 1];
+        }
+    }
 }
 
 }  // namespace thz

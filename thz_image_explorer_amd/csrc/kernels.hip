@@ -1473,9 +1473,11 @@ static inline void wave_launch_geometry(const PlanDev &P, size_t npix, unsigned 
 void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
                       float *out);
 
-// F family: 8 waves per block share the twiddle tables in LDS; persistent grid.
-template <class PL, int MODE, int CFG>
-static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
+// F family: 8 waves per block share the twiddle tables in LDS; persistent grid.  A configuration
+// whose tables do not leave room for eight wave buffers (nt = 4096 with a complex multiplier or with
+// block accumulators) runs with as many waves as fit.
+template <class PL, int CFG>
+static unsigned f_block_threads()
 {
     unsigned kBlock = 512;
 #ifndef THZ_EMU
@@ -1484,18 +1486,47 @@ static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
         if (v >= 64 && v <= 512 && v % 64 == 0) kBlock = (unsigned)v;
     }
 #endif
-    const unsigned kWpb = kBlock / kWave;
-    const size_t lds = PL::lds_bytes(kWpb);
+    while (kBlock > kWave && PL::lds_bytes((int)(kBlock / kWave), CFG) > kLdsBytesPerCU) kBlock -= kWave;
+    return kBlock;
+}
+
+// store-phase barriers of the F kernels (FArgs::bar); THZ_F_BAR overrides for A/B measurements
+int g_f_bar_override = -1;  // tests (the emulation harness) select a barrier mode here
+static int f_bar_mode()
+{
+    if (g_f_bar_override >= 0) return g_f_bar_override & 7;
+#ifndef THZ_EMU
+    if (const char *e = getenv("THZ_F_BAR")) return atoi(e) & 7;
+#endif
+    return kFBarDefault;
+}
+
+template <class PL, int MODE, int CFG>
+static size_t f_grid(size_t npix)
+{
+    const unsigned kWpb = f_block_threads<PL, CFG>() / kWave;
+    const size_t lds = PL::lds_bytes((int)kWpb, CFG);
     size_t per_cu = kLdsBytesPerCU / lds;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
-    size_t g = (A.npix + kWpb - 1) / kWpb;
+    size_t g = (npix + kWpb - 1) / kWpb;
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
     if (g < 1) g = 1;
+    return g;
+}
+
+template <class PL, int MODE, int CFG>
+static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
+{
+    const unsigned kBlock = f_block_threads<PL, CFG>();
+    const size_t lds = PL::lds_bytes((int)(kBlock / kWave), CFG);
+    const size_t g = f_grid<PL, MODE, CFG>(A.npix);
     FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
               reinterpret_cast<const cx *>(P.f_w2n)};
     allow_dynamic_lds(k_f<PL, MODE, CFG>, lds);
-    THZ_LAUNCH((k_f<PL, MODE, CFG>), (unsigned)g, kBlock, lds, st, A, T);
+    FArgs B = A;
+    B.bar = (CFG & kCfgBar) ? f_bar_mode() : 0;
+    THZ_LAUNCH((k_f<PL, MODE, CFG>), (unsigned)g, kBlock, lds, st, B, T);
 }
 
 template <int MODE, int CFG>
@@ -1511,8 +1542,47 @@ static void dispatch_f_size(hipStream_t st, const PlanDev &P, const FArgs &A)
 template <int MODE>
 static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool amp_phase)
 {
-    if (MODE == kInv || !amp_phase) dispatch_f_size<MODE, 0>(st, P, A);
-    else dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A);
+    if constexpr (MODE == kInv) {
+        dispatch_f_size<MODE, 0>(st, P, A);
+    } else if constexpr (MODE == kPipe) {  // always with amplitudes and phases
+        const int cfg = kCfgAmpPhase | (A.cmask ? kCfgCMask : 0) | (A.sums ? kCfgSums : 0) | (f_bar_mode() ? kCfgBar : 0);
+        switch (cfg) {
+        case kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A); break;
+        case kCfgBar | kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask>(st, P, A); break;
+        case kCfgBar | kCfgAmpPhase | kCfgSums: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgSums>(st, P, A); break;
+        case kCfgBar | kCfgAmpPhase: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase>(st, P, A); break;
+        case kCfgAmpPhase | kCfgCMask | kCfgSums: dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A); break;
+        case kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask>(st, P, A); break;
+        case kCfgAmpPhase | kCfgSums: dispatch_f_size<MODE, kCfgAmpPhase | kCfgSums>(st, P, A); break;
+        default: dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A); break;
+        }
+    } else {
+        if (!amp_phase) {
+            if (A.cmask) dispatch_f_size<MODE, kCfgCMask>(st, P, A);
+            else dispatch_f_size<MODE, 0>(st, P, A);
+        } else {
+            if (A.cmask) dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask>(st, P, A);
+            else dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A);
+        }
+    }
+}
+
+// rows of per-block partial sums the fused chain writes when asked for pixel sums (0: this plan has
+// no such kernel and the caller sums the stored arrays instead)
+size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
+{
+    if (P.family != kFamilyF) return 0;
+    switch (P.nt) {
+    case 4096:
+        return cmask ? f_grid<FPlan4096, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
+                     : f_grid<FPlan4096, kPipe, kCfgAmpPhase | kCfgSums>(npix);
+    case 2048:
+        return cmask ? f_grid<FPlan2048, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
+                     : f_grid<FPlan2048, kPipe, kCfgAmpPhase | kCfgSums>(npix);
+    default:
+        return cmask ? f_grid<FPlan1024, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
+                     : f_grid<FPlan1024, kPipe, kCfgAmpPhase | kCfgSums>(npix);
+    }
 }
 
 template <class PL, int MODE>
@@ -1582,8 +1652,15 @@ static void dispatch_fbc(hipStream_t st, const PlanDev &P, FB2Args &B)
 
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
-                    float *amp_out, float *ph_out, const float *mask)
+                    float *amp_out, float *ph_out, const float *mask, const c32 *cmask)
 {
+    // A complex multiplier is fused only by the F kernels; every other family multiplies in a second
+    // (elementwise) launch over the stored spectrum and amplitudes.
+    if (cmask && !(P.family == kFamilyF && fft_out && ((amp_out != nullptr) == (ph_out != nullptr)))) {
+        launch_fft_fwd(st, P, npix, in, wa, wb, data_out, fft_out, amp_out, ph_out, mask, nullptr);
+        launch_fd_cmask(st, npix, P.nf, P.nt, fft_out, amp_out, cmask);
+        return;
+    }
     // F kernels: one window, spectrum required, |X| and phase both or neither,
     // no windowed-trace output.  When the stage's `data` output is wanted the
     // multiply runs as its own elementwise launch first (bit-identical: the
@@ -1591,7 +1668,7 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
     if (P.family == kFamilyF && data_out && wa && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
         launch_td_window(st, npix, P.nt, in, wa, data_out);
         if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
-        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask, cmask);
         return;
     }
     // FB kernels (chirp-z lengths): same split — the windowed-trace output is its own launch
@@ -1626,7 +1703,7 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
     if (P.family == kFamilyF && !wb && !data_out && fft_out && ((amp_out != nullptr) == (ph_out != nullptr))) {
         FArgs A{};
         A.npix = npix; A.in = in; A.pre_win = wa; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
-        A.ph_out = ph_out; A.mask = mask ? mask : P.ones;
+        A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.cmask = reinterpret_cast<const cx *>(cmask);
         dispatch_f<kFwd>(st, P, A, amp_out != nullptr);
         return;
     }
@@ -1670,8 +1747,26 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
-                     float *amp_out, float *ph_out, float *data_out, float *img)
+                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask,
+                     float *sum_rows)
 {
+    // sum_rows: pipeline_sum_rows() x 2 nf floats of per-block partial sums — only the fused F kernel
+    // takes it (the caller checked pipeline_sum_rows() != 0)
+    if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
+        FArgs A{};
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
+        A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.post_win = post_win;
+        A.cmask = reinterpret_cast<const cx *>(cmask); A.sums = sum_rows;
+        A.data_out = data_out; A.img = img;
+        dispatch_f<kPipe>(st, P, A, true);
+        return;
+    }
+    if (cmask) {
+        // every other family: the complex multiply is its own pass over the stored spectrum
+        launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask, cmask);
+        launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
+        return;
+    }
     if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && fft_out && data_out) {
         // S regions per pair leave no room to carry the pair's spectra from the forward to the inverse
         // transform inside one kernel: two launches, the inverse reads the masked spectra back (the
@@ -1686,14 +1781,6 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
         A.data_out = data_out; A.img = img;
         dispatch_fb<kPipe>(st, P, A);
-        return;
-    }
-    if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
-        FArgs A{};
-        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
-        A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.post_win = post_win;
-        A.data_out = data_out; A.img = img;
-        dispatch_f<kPipe>(st, P, A, true);
         return;
     }
     unsigned grid, block;

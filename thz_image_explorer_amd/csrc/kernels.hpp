@@ -81,12 +81,16 @@ void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t n
 
 void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *in,
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
-                    float *amp_out, float *ph_out, const float *mask);
+                    float *amp_out, float *ph_out, const float *mask, const c32 *cmask = nullptr);
 void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *fft_in,
                     const float *win, float *out, float *img);
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
-                     float *amp_out, float *ph_out, float *data_out, float *img);
+                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr,
+                     float *sum_rows = nullptr);
+// number of (2 nf)-float rows of per-block partial sums launch_pipeline writes into sum_rows for this
+// plan and trace count; 0 when the plan's fused kernel cannot accumulate them
+size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask);
 void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask);
 void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
                      const c32 *cmask);
