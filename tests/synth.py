@@ -105,6 +105,42 @@ def default_chain(time, backend=None):
                 window_type=0, fft_window=(1.0, 7.0), fd_mask=fd, w_post=w_post, w_pre=pre)
 
 
+class OracleBackend:
+    """default_chain backend built from the oracle's own functions (oracle/thz_oracle.c): the reference side
+    of a parity test gets its multiplier vectors from here, the product side from the product's host_*
+    functions — neither side's inputs depend on the other"""
+
+    @staticmethod
+    def host_frequency_axis(time):
+        import oracle_binding as ob
+        return ob.frequency_axis(time)
+
+    @staticmethod
+    def host_adapted_blackman(axis, lo, hi):
+        import oracle_binding as ob
+        return ob.apply_adapted_blackman(np.ones(len(axis), np.float32), axis, lo, hi)
+
+    @staticmethod
+    def host_td_bandpass(time, low, high, width):
+        import oracle_binding as ob
+        return ob.td_bandpass_window(time, low, high, width)
+
+    @staticmethod
+    def host_fft_window(time, wtype, lo, hi):
+        import oracle_binding as ob
+        return ob.apply_window(wtype, np.ones(len(time), np.float32), time, lo, hi)
+
+    @staticmethod
+    def host_fd_bandpass(freq, low, high, width):
+        import oracle_binding as ob
+        return ob.fd_bandpass_window(freq, low, high, width)
+
+
+def oracle_chain(time):
+    """the default chain's multiplier vectors computed by the oracle"""
+    return default_chain(time, backend=OracleBackend)
+
+
 def run_gpu_pipeline(eng, cube, chain, want=("fft", "amplitudes", "phases", "data", "img")):
     """Fused chain through the C ABI (thz_pipeline); returns host arrays."""
     nx, ny, nt = cube.shape

@@ -149,13 +149,14 @@ def test_stagewise_chain_vs_oracle(engine, nt):
         b.free()
 
 
-@pytest.mark.parametrize("shape", [(8, 16, 1024), (2, 3, 4096), (5, 5, 256), (4, 4, 1001), (1, 1, 128)])
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (2, 3, 4096), (3, 7, 2048), (5, 5, 256), (4, 4, 1001), (1, 1, 128)])
 def test_fused_pipeline_vs_oracle(engine, shape):
     nx, ny, nt = shape
     time, cube = synth.make_cube(nx, ny, nt)
     engine.set_time_axis(time)
-    chain = synth.default_chain(time)
-    got = synth.run_gpu_pipeline(engine, cube, chain)
+    # the product computes its own multiplier vectors, the oracle its own: neither side's inputs come from the other
+    got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+    chain = synth.oracle_chain(time)
     ref = ob.run_pipeline(cube, time, chain)
     scale = np.abs(ref["fft"]).max()
     assert rel(got["fft"], ref["fft"], scale) < TOL
@@ -174,8 +175,8 @@ def test_knife_edge_real_traces(engine):
     cube = ob.subtract_bias(k["traces"].reshape(4, 4, 1001))
     engine.set_time_axis(time)
     assert "bluestein" in engine.kernel_variant()
-    chain = synth.default_chain(time)
-    got = synth.run_gpu_pipeline(engine, cube, chain)
+    got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+    chain = synth.oracle_chain(time)
     ref = ob.run_pipeline(cube, time, chain)
     assert rel(got["fft"], ref["fft"], np.abs(ref["fft"]).max()) < TOL
     assert rel(got["data"], ref["data"]) < TOL
@@ -475,6 +476,79 @@ def test_wiener_and_water_lines_chain(engine):
     assert np.all(F[:, 0, 1] == 0) and np.all(F[:, -1, 1] == 0)  # C2R precondition (SURVEY a'-4)
     for b in (d_ref, d_w, d_rf, d_x, d_fft, d_amp, d_ph, d_H, d_n, d_out):
         b.free()
+
+
+def _wiener_from_template(time, eps=1e-2):
+    """K13 multiplier of BASELINE config 5, built without the product: the synthetic reference pulse (noise-free
+    template) through the fft window, H = conj(R) / (|R|^2 + eps max|R|^2), numpy fp64 -> f32"""
+    z = ((time - time[0] - 11.0) / 0.35).astype(np.float64)
+    ref = -z * np.exp(-z * z)
+    w = ob.apply_window(0, np.ones(time.size, np.float32), time, 1.0, 7.0).astype(np.float64)
+    R = np.fft.rfft(ref * w)
+    H = np.conj(R) / (np.abs(R) ** 2 + eps * (np.abs(R) ** 2).max())
+    out = np.empty((R.size, 2), np.float32)
+    out[:, 0] = H.real
+    out[:, 1] = H.imag
+    return out
+
+
+@pytest.mark.parametrize("bar", [0, 3])
+@pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums"])
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (5, 5, 256)])
+def test_fused_pipeline_ex(engine, shape, mode, bar, monkeypatch):
+    """thz_pipeline_ex: complex per-bin multiplier (K13) inside the fused launch, in-launch pixel sums, store-phase
+    barriers — vs the oracle (plain chain) / a numpy fp64 model of the definition in DESIGN.md §7 (K13 is
+    build-defined: the reference has no such filter).  Lengths without a fused kernel take the staged fallback."""
+    nx, ny, nt = shape
+    monkeypatch.setenv("THZ_F_BAR", str(bar))
+    time, cube = synth.make_cube(nx, ny, nt)
+    e = engine
+    e.set_time_axis(time)
+    chain_p, chain = synth.default_chain(time), synth.oracle_chain(time)
+    npix, nf = nx * ny, nt // 2 + 1
+    H = _wiener_from_template(time) if "cmask" in mode else None
+    d_raw = e.to_device(cube); d_pre = e.to_device(chain_p["w_pre"]); d_fd = e.to_device(chain_p["fd_mask"])
+    d_post = e.to_device(chain_p["w_post"]); d_H = e.to_device(H) if H is not None else None
+    d_fft = e.empty((npix, nf, 2)); d_amp = e.empty((npix, nf)); d_ph = e.empty((npix, nf))
+    d_out = e.empty((npix, nt)); d_img = e.empty((npix,))
+    d_sums = e.empty((2 * nf,)) if "sums" in mode else None
+    e.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums)
+    fft = d_fft.download((npix, nf, 2), np.float32); amp = d_amp.download((npix, nf), np.float32)
+    ph = d_ph.download((npix, nf), np.float32); out = d_out.download((npix, nt), np.float32)
+    img = d_img.download((npix,), np.float32)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    if H is None:
+        assert rel(fft, ref["fft"].reshape(npix, nf, 2), scale) < TOL
+        assert rel(amp, ref["amplitudes"].reshape(npix, nf), scale) < TOL
+        assert rel(out, ref["data"].reshape(npix, nt)) < TOL
+        assert rel(img, ref["img"].ravel()) < TOL
+    else:
+        pre = chain["w_tilt"].astype(np.float64) * chain["w_td_before"] * chain["w_fft"]
+        X = np.fft.rfft(cube.reshape(npix, nt).astype(np.float64) * pre, axis=1)
+        Hc = (H[:, 0].astype(np.float64) + 1j * H[:, 1]) * chain["fd_mask"]
+        Y = X * Hc
+        a_ref = np.abs(Y)
+        Y[:, 0] = Y[:, 0].real
+        if nt % 2 == 0:
+            Y[:, -1] = Y[:, -1].real
+        t_ref = np.fft.irfft(Y, n=nt, axis=1) * chain["w_post"]
+        got = fft[..., 0] + 1j * fft[..., 1]
+        assert np.abs(got - Y).max() / np.abs(Y).max() < TOL
+        assert np.all(fft[:, 0, 1] == 0) and (nt % 2 == 1 or np.all(fft[:, -1, 1] == 0))  # C2R precondition
+        assert np.abs(amp - a_ref).max() / a_ref.max() < TOL
+        assert np.abs(out - t_ref).max() / np.abs(t_ref).max() < TOL
+        assert np.abs(img - (t_ref ** 2).sum(1)).max() / (t_ref ** 2).sum(1).max() < TOL
+    st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(ph.reshape(nx, ny, nf), ref["phases"], st["amplitudes"])   # phases are those of X in every mode
+    if d_sums is not None:
+        sums = d_sums.download((2 * nf,), np.float32)
+        sa, sp = amp.astype(np.float64).sum(0), ph.astype(np.float64).sum(0)
+        assert np.abs(sums[:nf] - sa).max() <= 2e-6 * np.abs(sa).max()   # f32 sums in another order than the reference's
+        assert np.abs(sums[nf:] - sp).max() <= 2e-6 * np.abs(sp).max()
+    for b in (d_raw, d_pre, d_fd, d_post, d_H, d_fft, d_amp, d_ph, d_out, d_img, d_sums):
+        if b is not None:
+            b.free()
 
 
 # ---- reference pulse ingestion (ConfigCommand::OpenRef, data_thread.rs:372-588) -------------

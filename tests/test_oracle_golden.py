@@ -100,7 +100,7 @@ def test_knife_edge_traces_default_chain():
     time, traces = k["time"], k["traces"]
     assert traces.shape == (16, 1001)
     cube = ob.subtract_bias(traces.reshape(4, 4, 1001))
-    chain = synth.default_chain(time, backend=_OracleBackend)
+    chain = synth.oracle_chain(time)
     res = ob.run_pipeline(cube, time, chain)
     pre = chain["w_tilt"].astype(np.float64) * chain["w_td_before"] * chain["w_fft"]
     X = np.fft.rfft(cube.astype(np.float64) * pre, axis=-1)
@@ -110,27 +110,3 @@ def test_knife_edge_traces_default_chain():
     back = np.fft.irfft(Xb, n=1001, axis=-1) * chain["w_post"]
     assert np.abs(res["data"] - back).max() / np.abs(back).max() < TOL
     assert np.abs(res["img"] - (back ** 2).sum(-1)).max() / (back ** 2).sum(-1).max() < 1e-5
-
-
-class _OracleBackend:
-    """synth.default_chain backend built from the oracle's own functions"""
-
-    @staticmethod
-    def host_frequency_axis(time):
-        return ob.frequency_axis(time)
-
-    @staticmethod
-    def host_adapted_blackman(axis, lo, hi):
-        return ob.apply_adapted_blackman(np.ones(len(axis), np.float32), axis, lo, hi)
-
-    @staticmethod
-    def host_td_bandpass(time, low, high, width):
-        return ob.td_bandpass_window(time, low, high, width)
-
-    @staticmethod
-    def host_fft_window(time, wtype, lo, hi):
-        return ob.apply_window(wtype, np.ones(len(time), np.float32), time, lo, hi)
-
-    @staticmethod
-    def host_fd_bandpass(freq, low, high, width):
-        return ob.fd_bandpass_window(freq, low, high, width)
