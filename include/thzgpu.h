@@ -233,10 +233,9 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
  *               without a fused kernel for it run fft -> thz_apply_fd_cmask -> ifft internally.
  *   d_sums      (2 nf) or NULL: sum over the npix traces of the stored amplitudes [0, nf) and of the
  *               unwrapped phases [nf, 2 nf) — the numerators of the pixel means of the ifft stage
- *               (math_tools.rs:427-440; divide by nx ny, or all-reduce the sums of the tiles first).
- *               Accumulated inside the launch where the kernel can (nt = 1024 / 2048 / 4096), otherwise
- *               by thz_pixel_sum passes over d_amp / d_phase.  Summation order differs from the
- *               reference's sequential one (<= 1e-6 relative); thz_pixel_mean is the bit-exact form.
+ *               (math_tools.rs:427-440; divide by nx ny, or all-reduce the sums of the tiles first) — by
+ *               thz_pixel_sum passes over d_amp / d_phase behind the launch.  Summation order differs from
+ *               the reference's sequential one (<= 1e-6 relative); thz_pixel_mean is the bit-exact form.
  * d_fft, d_amp, d_phase and d_data_out are required here. */
 typedef struct thz_pipeline_io {
     const float *d_raw;      /* (npix, nt) */
@@ -408,7 +407,10 @@ typedef struct thz_chain_cfg {
     /* Time Band Pass after the inverse FFT (band_pass_td_after_fft.rs) */
     int32_t td_after_active;
     double td_after_low, td_after_high, td_after_width;
-    /* pixel means of the ifft stage (math_tools.rs:421-440) */
+    /* pixel means of the ifft stage (math_tools.rs:421-440): 0 none; 1 amplitude / phase sums taken
+     * inside the fused launch and avg_fft by linearity from the mean trace (<= 1e-5 of the reference's
+     * values, no extra pass over the outputs); 2 the reference's summation order bit for bit (three
+     * passes over the outputs; also what 1 falls back to for a tilted cube) */
     int32_t want_means;
     /* ConfigContainer.scale_factor: the chain's first stage, math_tools::scaling
      * (math_tools.rs:242-310).  s > 1 replaces the raw cube by its s x s block
@@ -444,8 +446,27 @@ void thz_session_destroy(thz_session *s);
  * memory (nx, ny, nt) C-order, or NULL when the caller fills the raw buffer
  * itself through thz_session_buffer(). */
 int thz_session_upload(thz_session *s, const float *cube, int subtract_bias);
-/* UpdateType::Filter(start_idx) for any start_idx: recomputes every output. */
+/* UpdateType::Filter(1) (ConfigCommand::UpdateFilters, SetDownScaling: data_thread.rs:836-838, 903-905):
+ * recomputes every output. */
 int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg);
+/* UpdateType::Filter(start_idx), data_thread.rs:1090-1105: the stage walk starts at chain position
+ * start_stage of the reference's filter_chain (main.rs:182-247; "initial" is 0):
+ *   1 scaling  2 Tilt Compensation  3 Time Band Pass  4 fft  5 Frequency Band Pass (+ the plugins of
+ *   thz_session_set_fd_filters)  6 ifft  7 Time Band Pass (after)  8 Deconvolution
+ * (UpdateFilter(uuid) sends the filter's own position, :907-921; the fft window commands send fft_index =
+ * 3, one in front of the fft stage, :813-836.)  Positions 1-5 run the one-pass chain from the raw cube:
+ * the resident spectrum is the band-passed one, so nothing in front of position 6 can restart from an
+ * intermediate.  Positions 6 and 7 re-run only C2R -> Time Band Pass -> image on the resident spectrum
+ * (a third of the full chain's traffic) — provided the last full recompute used the same settings in
+ * front of position 6, else they fall back to the full chain.  Position 8 is thz_session_deconvolve's;
+ * here it is a no-op. */
+int thz_session_recompute_from(thz_session *s, const thz_chain_cfg *cfg, int start_stage);
+/* Further Frequency-domain plugins of the chain (FilterDomain::Frequency, behind "Frequency Band Pass"),
+ * as per-bin multipliers for the chain's nf bins (host vectors, copied; NULL removes one): a real one —
+ * the water-line notch K14, thz_host_water_line_mask — and a complex one — the reference-pulse Wiener
+ * filter K13, thz_host_wiener_filter.  Both ride in the fused launch.  A later recompute whose spectra
+ * have another length (tilted cube) returns THZ_ERR_INVALID. */
+int thz_session_set_fd_filters(thz_session *s, const float *real_mask, const float *cmask, size_t nf);
 /* Grid of the last recompute's outputs (the raw grid until then): every buffer
  * except THZ_BUF_RAW has nx * ny pixels of this grid.  Any pointer may be NULL. */
 int thz_session_grid(const thz_session *s, size_t *nx, size_t *ny, float *dx, float *dy);
@@ -465,11 +486,13 @@ int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_
 /* trace length of the final cube (nt, or nt + 2*steps after a tilt) and its axis */
 size_t thz_session_nt_out(const thz_session *s);
 int thz_session_time_out(const thz_session *s, float *time /* nt_out */);
-/* device pointer of a resident buffer (NULL if absent) */
+/* device pointer of a resident buffer; NULL if absent — every output buffer (everything but THZ_BUF_RAW
+ * and THZ_BUF_IMG) is absent until a recompute has run after the latest upload */
 void *thz_session_buffer(thz_session *s, int which);
 /* copies pixels [pix0, pix0+npix) of a per-pixel buffer (or the whole vector for
  * the AVG_* ones, pix0 = 0, npix = 1) to the host: the selected-pixel trace, a
- * tile, or everything */
+ * tile, or everything.  THZ_ERR_NOT_READY for an absent buffer, THZ_ERR_INVALID for a
+ * pixel range beyond the grid of the recompute that filled it. */
 int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst);
 
 /* Plot copy-out of UpdateType::Plot (data_thread.rs:1337-1432): everything the

@@ -60,28 +60,15 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 
 void emu_set_f_bar(int mode) { thz::g_f_bar_override = mode; }
 
-// fused chain with a complex multiplier and / or block sums (F family only); sums = [amp nf | phase nf],
-// bar = FArgs::bar (store-phase barriers)
+// fused chain with a complex multiplier (F family only); FArgs::bar via emu_set_f_bar
 int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
-                    const float *post, float *fft, float *amp, float *ph, float *out, float *img, float *sums)
+                    const float *post, float *fft, float *amp, float *ph, float *out, float *img)
 {
     PlanHost H;
     if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
     if (H.family != kFamilyF) return -2;
     PlanDev D = make_plan(H);
-    const size_t nf = (size_t)nt / 2 + 1;
-    const size_t rows = sums ? pipeline_sum_rows(D, npix, cmask != nullptr) : 0;
-    std::vector<float> part(rows * 2 * nf, -1.0f);
-    launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask,
-                    rows ? part.data() : nullptr);
-    if (sums) {
-        if (!rows) return -3;
-        for (size_t k = 0; k < 2 * nf; ++k) {
-            float a = 0.0f;
-            for (size_t r = 0; r < rows; ++r) a += part[r * 2 * nf + k];
-            sums[k] = a;
-        }
-    }
+    launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask);
     return 0;
 }
 

@@ -298,3 +298,36 @@ def test_session_download_bounds_and_missing_means(engine):
             sess.download(pkg.BUF_DATA, 3, 2)
     finally:
         sess.close()
+
+
+def test_session_outputs_absent_until_recomputed(engine):
+    """after a scaled recompute the output buffers are sized for the block grid; an upload resets
+    the session's grid to the raw one — the outputs must then read as absent (THZ_ERR_NOT_READY), not be copied
+    past their end; a pixel range beyond the recompute's grid is THZ_ERR_INVALID"""
+    nx, ny, nt = 8, 6, 256
+    time, cube = synth.make_cube(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time)
+    try:
+        outputs = (pkg.BUF_FFT, pkg.BUF_AMPLITUDES, pkg.BUF_PHASES, pkg.BUF_DATA, pkg.BUF_AVG_FFT)
+        sess.upload(cube, subtract_bias=False)
+        for which in outputs:   # nothing computed yet
+            with pytest.raises(pkg.ThzError) as e:
+                sess.download(which)
+            assert e.value.code == -4
+        assert sess.download(pkg.BUF_IMG).size == nx * ny    # the upload's image of the raw grid
+        cfg = pkg.chain_cfg_default(time)
+        cfg.scale_factor = 2
+        sess.recompute(cfg)
+        gx, gy, _, _ = sess.grid()
+        assert (gx, gy) == (nx // 2, ny // 2)
+        assert sess.download(pkg.BUF_DATA).size == gx * gy * nt
+        with pytest.raises(pkg.ThzError) as e:   # the raw grid's pixel count no longer fits
+            sess.download(pkg.BUF_DATA, 0, nx * ny)
+        assert e.value.code == -1
+        sess.upload(cube, subtract_bias=False)   # grid is the raw one again, outputs are void
+        for which in outputs:
+            with pytest.raises(pkg.ThzError) as e:
+                sess.download(which, 0, nx * ny) if which != pkg.BUF_AVG_FFT else sess.download(which)
+            assert e.value.code == -4
+    finally:
+        sess.close()

@@ -171,6 +171,8 @@ SYMBOLS = [
     ("thz_session_destroy", None, [_P]),
     ("thz_session_upload", C.c_int, [_P, _P, C.c_int]),
     ("thz_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg)]),
+    ("thz_session_recompute_from", C.c_int, [_P, C.POINTER(ChainCfg), C.c_int]),
+    ("thz_session_set_fd_filters", C.c_int, [_P, _P, _P, _SZ]),
     ("thz_session_grid", C.c_int, [_P, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("thz_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_session_nt_out", _SZ, [_P]),
@@ -396,8 +398,17 @@ class Session:
         c = np.ascontiguousarray(cube, np.float32)
         self.eng._check(self.eng.lib.thz_session_upload(self.h, c.ctypes.data, int(subtract_bias)))
 
-    def recompute(self, cfg: ChainCfg):
-        self.eng._check(self.eng.lib.thz_session_recompute(self.h, C.byref(cfg)))
+    def recompute(self, cfg: ChainCfg, start_stage: int = 1):
+        """UpdateType::Filter(start_stage): 1 = everything, 6 / 7 = from the resident spectrum"""
+        self.eng._check(self.eng.lib.thz_session_recompute_from(self.h, C.byref(cfg), int(start_stage)))
+
+    def set_fd_filters(self, real_mask=None, cmask=None):
+        """further Frequency-domain plugins: K14 (real, nf) and K13 (complex, (nf, 2))"""
+        r = None if real_mask is None else np.ascontiguousarray(real_mask, np.float32)
+        c = None if cmask is None else np.ascontiguousarray(cmask, np.float32)
+        nf = r.size if r is not None else (c.size // 2 if c is not None else 0)
+        self.eng._check(self.eng.lib.thz_session_set_fd_filters(self.h, r.ctypes.data if r is not None else None,
+                                                                c.ctypes.data if c is not None else None, nf))
 
     def deconvolve(self, psf, cfg, abort=None, progress=None):
         """the chain's Deconvolution stage on the last recompute's output -> status (0 applied, 1 skipped)"""

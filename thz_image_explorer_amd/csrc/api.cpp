@@ -404,48 +404,27 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
     return check_launch(ctx);
 }
 
-// sum over `rows` rows of L floats (the per-block partials of the fused kernel, or any small matrix)
-static int sum_rows(thz_ctx *ctx, const float *d_rows, size_t rows, size_t L, float *d_out, float *scratch /* 32 L */)
-{
-    const size_t mid_groups = 32;
-    const float *src = d_rows;
-    if (rows > 4 * mid_groups) {
-        const size_t g = launch_colsum_partial(ctx->stream, d_rows, rows, L, scratch, mid_groups);
-        if (g) { src = scratch; rows = g; }
-    }
-    launch_sum_axis0(ctx->stream, src, rows, L, 0.0f, d_out);
-    return check_launch(ctx);
-}
-
 int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
 {
     if (int rc = need_plan(ctx)) return rc;
     if (!io || !io->d_raw || !io->d_data_out || !io->d_fft || !io->d_amp || !io->d_phase)
         return fail(ctx, THZ_ERR_INVALID, "thz_pipeline_ex: d_raw, d_fft, d_amp, d_phase and d_data_out are required");
+    const size_t nf = (size_t)ctx->plan_d.nf;
     if (npix == 0) {
-        if (io->d_sums) HIP_TRY(ctx, hipMemsetAsync(io->d_sums, 0, 2 * ctx->plan_d.nf * sizeof(float), ctx->stream));
+        if (io->d_sums) HIP_TRY(ctx, hipMemsetAsync(io->d_sums, 0, 2 * nf * sizeof(float), ctx->stream));
         return THZ_OK;
-    }
-    const size_t nf = (size_t)ctx->plan_d.nf, L = 2 * nf;
-    const c32 *cmask = reinterpret_cast<const c32 *>(io->d_fd_cmask);
-    const size_t rows = io->d_sums ? pipeline_sum_rows(ctx->plan_d, npix, cmask != nullptr) : 0;
-    float *d_rows = nullptr;
-    if (rows) {
-        if (int rc = ensure_ws(ctx, (rows + 32) * L * sizeof(float))) return rc;
-        d_rows = reinterpret_cast<float *>(ctx->ws);
     }
     {
         StageTimer t(ctx, THZ_STAGE_PIPELINE);
         launch_pipeline(ctx->stream, ctx->plan_d, npix, io->d_raw, io->d_pre_win, io->d_fd_mask, io->d_post_win,
-                        reinterpret_cast<c32 *>(io->d_fft), io->d_amp, io->d_phase, io->d_data_out, io->d_img, cmask,
-                        d_rows);
+                        reinterpret_cast<c32 *>(io->d_fft), io->d_amp, io->d_phase, io->d_data_out, io->d_img,
+                        reinterpret_cast<const c32 *>(io->d_fd_cmask));
         if (int rc = check_launch(ctx)) return rc;
     }
     if (!io->d_sums) return THZ_OK;
-    if (rows) {
-        StageTimer t(ctx, THZ_STAGE_MEAN);
-        return sum_rows(ctx, d_rows, rows, L, io->d_sums, d_rows + rows * L);
-    }
+    // The sums are a second pass over the two arrays just written (8 nf bytes per trace): block accumulators
+    // inside the fused launch were built and measured — 2 nf LDS float atomics per trace doubled the launch's
+    // time at nt = 4096 — and per-lane register accumulators do not fit beside the transform.
     if (int rc = thz_pixel_sum(ctx, npix, nf, 1, io->d_amp, io->d_sums)) return rc;
     return thz_pixel_sum(ctx, npix, nf, 1, io->d_phase, io->d_sums + nf);
 }

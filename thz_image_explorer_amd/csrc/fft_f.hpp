@@ -143,7 +143,6 @@ __device__ __forceinline__ void st2(cx *p, cx a, cx b) { *reinterpret_cast<cx2 *
 enum : int {
     kCfgAmpPhase = 1,  // also write |X| and the unwrapped phase
     kCfgCMask = 2,     // the per-bin multiplier is complex (K13, reference-pulse Wiener filter)
-    kCfgSums = 4,      // per-bin pixel sums of |X| m and of the unwrapped phase (math_tools.rs:427-440), needs kCfgAmpPhase
     kCfgBar = 8        // the block's waves meet at a barrier before each store phase (FArgs::bar says which)
 };
 
@@ -161,14 +160,12 @@ struct FPlan {
     static_assert(R3 == 8, "pass-2 lane map assumes R3 = 8");
     static_assert(C1 == 1 || C1 == 2, "C1");
     static_assert(C2 >= 1 && C3 >= 1, "lanes must all own a butterfly");
-    // LDS per block, in cx: [T1: R1*M1][T2: R2*R3][mask: nf floats, or nf cx][extra][sums][per wave: N + 2]
+    // LDS per block, in cx: [T1: R1*M1][T2: R2*R3][mask: nf floats, or nf cx][extra][per wave: N + 2]
     static constexpr int T1_ENTRIES = R1 * M1;
     static constexpr int T2_ENTRIES = R2 * R3;
     // N + 1 floats (real multiplier) or N + 1 cx (complex multiplier), padded to 16 bytes; the two
     // floats of padding behind a real mask / the last cx behind a complex one hold the window block bits
     static constexpr int mask_entries(int cfg) { return (cfg & kCfgCMask) ? N + 2 : (N + 4) / 2; }
-    // block accumulators of kCfgSums: [amp: N floats][phase: N floats][Nyquist amp, phase]
-    static constexpr int sums_entries(int cfg) { return (cfg & kCfgSums) ? N + 2 : 0; }
     static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
     // Small trace-invariant tables the trace loop reads, staged once per block so that no
     // vector-memory load sits between the loop's stores (a load's result can only be waited
@@ -184,8 +181,7 @@ struct FPlan {
     static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
     static constexpr size_t lds_bytes(int waves, int cfg = 0)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + sums_entries(cfg)
-                        + waves * WAVE_ENTRIES) * sizeof(cx);
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -419,25 +415,6 @@ __device__ __forceinline__ void load_f4(const float *p, float &a, float &b, floa
 }
 #endif
 
-// ds_add_f32 on a block accumulator (no return value: fire and forget on the LDS pipe)
-__device__ __forceinline__ void lds_add(float *p, float v)
-{
-#ifdef THZ_EMU
-    uint32_t *u = reinterpret_cast<uint32_t *>(p);
-    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
-    for (;;) {
-        float f;
-        __builtin_memcpy(&f, &old, 4);
-        f += v;
-        uint32_t nw;
-        __builtin_memcpy(&nw, &f, 4);
-        if (__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
-    }
-#else
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-
 struct FArgs {
     size_t npix;
     const float *in;        // (npix, nt) raw traces            [fwd, pipeline]
@@ -448,7 +425,6 @@ struct FArgs {
     const float *mask;      // (nf), required (a vector of ones when no band-pass is wanted)
     const cx *cmask;        // (nf) complex per-bin multiplier, required when the kernel is built with kCfgCMask;
                             // the staged table is cmask[k] * mask[k]
-    float *sums;            // (gridDim.x, 2 nf) per-block partial sums [amp | phase], required with kCfgSums
     int bar;                // block barriers in the trace loop: bit 0 before the spectrum stores, bit 1 before
                             // the time stores, bit 2: with a workgroup fence (__syncthreads) instead of a bare s_barrier
     const cx *fft_in;      // (npix, nf)                        [inv only]
@@ -551,14 +527,11 @@ __device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
 // bin 0 and of the Nyquist bin forced to 0: the C2R precondition, math_tools.rs:510-512), the stored
 // amplitude |X H| (taken before the forcing); phases are those of X, as with the real band pass
 // (band_pass_fd.rs:184-212 leaves them alone).  buf keeps the unmultiplied X.
-// SUMS: adds the stored amplitudes and unwrapped phases to the block's accumulators `sums`
-// ([amp: slot (4 g + c) 64 + lane <-> bin 256 g + 4 lane + c][phase: same, + N][Nyquist amp, phase]).
-template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false>
+template <class P, bool AMP_PHASE, bool CMASK = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
-                                                    const float *mask, float *sums, size_t p, const FArgs &A,
+                                                    const float *mask, size_t p, const FArgs &A,
                                                     int lane)
 {
-    static_assert(!SUMS || AMP_PHASE, "sums are those of the amplitude / phase outputs");
     constexpr int N = P::N, NG = P::NG;
     static_assert(NG % 2 == 0, "pair ownership splits the groups in halves");
     const int nf = N + 1;
@@ -621,10 +594,6 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(Y[c].x, Y[c].x, Y[c].y * Y[c].y));
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
-                if constexpr (SUMS) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) lds_add(sums + (4 * g + c) * kWave + lane, a[c]);
-                }
             }
             if (g == 0 && lane == 0) Y[0].y = 0.0f;  // bin 0
             float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
@@ -641,10 +610,6 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
-                if constexpr (SUMS) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) lds_add(sums + (4 * g + c) * kWave + lane, a[c]);
-                }
             }
             float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
             store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
@@ -681,10 +646,6 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = first + (base + s_[c]);
             store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
-            if constexpr (SUMS) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) lds_add(sums + N + (4 * g + c) * kWave + lane, y[c]);
-            }
             carry += wave_bcast<kWave - 1>(incl);
             prev_tail = wave_bcast<kWave - 1>(ph[3]);
             if (g == NG - 1) {
@@ -708,13 +669,11 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
             aN = fabsf(xr) * mN;
         }
         if constexpr (AMP_PHASE) A.amp_out[p * nf + N] = aN;
-        if constexpr (SUMS) lds_add(sums + 2 * N, aN);
         if constexpr (want_phase) {
             const float phn = fast_atan2f(0.0f, xr);
             float d = phn - last_raw;
             d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);
             A.ph_out[p * nf + N] = last_unwrapped + d;
-            if constexpr (SUMS) lds_add(sums + 2 * N + 1, last_unwrapped + d);
         }
     }
 }
@@ -894,7 +853,6 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     constexpr int N = P::N, NT = P::NT, R1 = P::R1, C1 = P::C1;
     constexpr bool AMP_PHASE = (CFG & kCfgAmpPhase) != 0;
     constexpr bool CMASK = (CFG & kCfgCMask) != 0 && MODE != kInv;
-    constexpr bool SUMS = (CFG & kCfgSums) != 0 && MODE != kInv;
     constexpr int ME = P::mask_entries(CFG);
     const int nf = N + 1;
     const int lane = lane_id();
@@ -906,8 +864,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     cx *w2n_s = t2 + P::T2_ENTRIES + ME;
     cx *wg_s = w2n_s + P::W2N_HEAD;
     float *win_s = reinterpret_cast<float *>(wg_s + P::WG_ENTRIES);
-    float *sums_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES);
-    cx *buf = t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + P::sums_entries(CFG) + (size_t)wib * P::WAVE_ENTRIES;
+    cx *buf = t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
     for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[P::M1 * (int)threadIdx.x];
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
@@ -922,8 +879,6 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     } else if (MODE != kInv) {
         for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
     }
-    if constexpr (SUMS)
-        for (int i = (int)threadIdx.x; i < 2 * P::sums_entries(CFG); i += (int)blockDim.x) sums_s[i] = 0.0f;
     // window block bits (see f_edge_only), kept in the padding behind the mask
     unsigned int *bits = reinterpret_cast<unsigned int *>(mask_s + (2 * ME - 2));
     if (threadIdx.x < 2) bits[threadIdx.x] = 0u;
@@ -1076,9 +1031,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // spectrum stores (+ the inverse transform of the fused chain)
     auto part_b = [&]() {
         if constexpr (MODE != kInv) {
-            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS>(buf, launder_uniform((const cx *)w2n_s),
-                                                           launder_uniform((const cx *)wg_s), mask_l,
-                                                           const_cast<float *>(launder_uniform((const float *)sums_s)), p, A, lane);
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK>(buf, launder_uniform((const cx *)w2n_s),
+                                                     launder_uniform((const cx *)wg_s), mask_l, p, A, lane);
             if constexpr (MODE == kPipe) {
                 cx r[C1][R1];
                 f_inverse_input<P, true, CMASK>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
@@ -1134,21 +1088,6 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     } else {
         if (pre_edge && post_edge && all_staged) trace_loop(FTrue{}, FFalse{});
         else trace_loop(FFalse{}, FFalse{});
-    }
-    if constexpr (SUMS) {
-        // every wave of the block has left its trace loop: hand the block's accumulators over, bins
-        // in natural order ([amp nf | phase nf] per block; the caller adds the gridDim.x rows)
-        __syncthreads();
-        float *dst = A.sums + (size_t)blockIdx.x * (size_t)(2 * nf);
-        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
-            const int k = 256 * (i >> 8) + 4 * (i & 63) + ((i >> 6) & 3);
-            dst[k] = sums_s[i];
-            dst[nf + k] = sums_s[N + i];
-        }
-        if (threadIdx.x == 0) {
-            dst[N] = sums_s[2 * N];
-            dst[nf + N] = sums_s[2 * N + 1];
-        }
     }
 }
 

@@ -453,6 +453,20 @@ __global__ __launch_bounds__(256) void k_fd_cmask(size_t npix, int nf, int nt,
     }
 }
 
+// small vectors: out = in * f; dst += src (pixel-mean finalisation, same-device all-reduce of group_api.cpp)
+__global__ __launch_bounds__(256) void k_scale_vec(const float *__restrict__ in, float f, size_t n, float *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] * f;
+}
+__global__ __launch_bounds__(256) void k_add_vec(float *__restrict__ dst, const float *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+__global__ __launch_bounds__(256) void k_add_u64(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
 // out = in * win.  One wave per trace, 16-byte accesses when the rows allow it; no per-element
 // index division (the earlier flat grid-stride form spent its time in a 64-bit modulo).
 template <bool VEC>
@@ -1542,46 +1556,29 @@ static void dispatch_f_size(hipStream_t st, const PlanDev &P, const FArgs &A)
 template <int MODE>
 static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool amp_phase)
 {
+    const int bar = f_bar_mode() ? kCfgBar : 0;
     if constexpr (MODE == kInv) {
-        dispatch_f_size<MODE, 0>(st, P, A);
-    } else if constexpr (MODE == kPipe) {  // always with amplitudes and phases
-        const int cfg = kCfgAmpPhase | (A.cmask ? kCfgCMask : 0) | (A.sums ? kCfgSums : 0) | (f_bar_mode() ? kCfgBar : 0);
-        switch (cfg) {
-        case kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A); break;
-        case kCfgBar | kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask>(st, P, A); break;
-        case kCfgBar | kCfgAmpPhase | kCfgSums: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgSums>(st, P, A); break;
-        case kCfgBar | kCfgAmpPhase: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase>(st, P, A); break;
-        case kCfgAmpPhase | kCfgCMask | kCfgSums: dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A); break;
-        case kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask>(st, P, A); break;
-        case kCfgAmpPhase | kCfgSums: dispatch_f_size<MODE, kCfgAmpPhase | kCfgSums>(st, P, A); break;
-        default: dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A); break;
-        }
+        if (bar) dispatch_f_size<MODE, kCfgBar>(st, P, A);
+        else dispatch_f_size<MODE, 0>(st, P, A);
     } else {
-        if (!amp_phase) {
-            if (A.cmask) dispatch_f_size<MODE, kCfgCMask>(st, P, A);
-            else dispatch_f_size<MODE, 0>(st, P, A);
-        } else {
-            if (A.cmask) dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask>(st, P, A);
-            else dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A);
+        // the fused chain always writes amplitudes and phases
+        const int cfg = ((MODE == kPipe || amp_phase) ? kCfgAmpPhase : 0) | (A.cmask ? kCfgCMask : 0) | bar;
+        switch (cfg) {
+        case kCfgBar | kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask>(st, P, A); break;
+        case kCfgBar | kCfgAmpPhase: dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase>(st, P, A); break;
+        case kCfgAmpPhase | kCfgCMask: dispatch_f_size<MODE, kCfgAmpPhase | kCfgCMask>(st, P, A); break;
+        case kCfgAmpPhase: dispatch_f_size<MODE, kCfgAmpPhase>(st, P, A); break;
+        default:
+            if constexpr (MODE == kFwd) {
+                switch (cfg) {
+                case kCfgBar | kCfgCMask: dispatch_f_size<MODE, kCfgBar | kCfgCMask>(st, P, A); break;
+                case kCfgBar: dispatch_f_size<MODE, kCfgBar>(st, P, A); break;
+                case kCfgCMask: dispatch_f_size<MODE, kCfgCMask>(st, P, A); break;
+                default: dispatch_f_size<MODE, 0>(st, P, A); break;
+                }
+            }
+            break;
         }
-    }
-}
-
-// rows of per-block partial sums the fused chain writes when asked for pixel sums (0: this plan has
-// no such kernel and the caller sums the stored arrays instead)
-size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
-{
-    if (P.family != kFamilyF) return 0;
-    switch (P.nt) {
-    case 4096:
-        return cmask ? f_grid<FPlan4096, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
-                     : f_grid<FPlan4096, kPipe, kCfgAmpPhase | kCfgSums>(npix);
-    case 2048:
-        return cmask ? f_grid<FPlan2048, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
-                     : f_grid<FPlan2048, kPipe, kCfgAmpPhase | kCfgSums>(npix);
-    default:
-        return cmask ? f_grid<FPlan1024, kPipe, kCfgAmpPhase | kCfgCMask | kCfgSums>(npix)
-                     : f_grid<FPlan1024, kPipe, kCfgAmpPhase | kCfgSums>(npix);
     }
 }
 
@@ -1747,16 +1744,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
-                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask,
-                     float *sum_rows)
+                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask)
 {
-    // sum_rows: pipeline_sum_rows() x 2 nf floats of per-block partial sums — only the fused F kernel
-    // takes it (the caller checked pipeline_sum_rows() != 0)
     if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
         FArgs A{};
         A.npix = npix; A.in = raw; A.pre_win = pre_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out;
         A.ph_out = ph_out; A.mask = mask ? mask : P.ones; A.post_win = post_win;
-        A.cmask = reinterpret_cast<const cx *>(cmask); A.sums = sum_rows;
+        A.cmask = reinterpret_cast<const cx *>(cmask);
         A.data_out = data_out; A.img = img;
         dispatch_f<kPipe>(st, P, A, true);
         return;
@@ -1802,6 +1796,19 @@ void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, floa
 {
     THZ_LAUNCH(k_fd_cmask, grid_1d(npix * nf, 256, kNumCU * 8), 256, 0, st, npix, nf, nt, fft, amp,
                cmask);
+}
+
+void launch_scale_vec(hipStream_t st, const float *in, float f, size_t n, float *out)
+{
+    THZ_LAUNCH(k_scale_vec, grid_1d(n, 256, kNumCU * 8), 256, 0, st, in, f, n, out);
+}
+void launch_add_vec(hipStream_t st, float *dst, const float *src, size_t n)
+{
+    THZ_LAUNCH(k_add_vec, grid_1d(n, 256, kNumCU * 8), 256, 0, st, dst, src, n);
+}
+void launch_add_u64(hipStream_t st, unsigned long long *dst, const unsigned long long *src, size_t n)
+{
+    THZ_LAUNCH(k_add_u64, grid_1d(n, 256, kNumCU * 8), 256, 0, st, dst, src, n);
 }
 
 void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,

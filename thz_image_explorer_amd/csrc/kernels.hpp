@@ -86,16 +86,15 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
                     const float *win, float *out, float *img);
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
-                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr,
-                     float *sum_rows = nullptr);
-// number of (2 nf)-float rows of per-block partial sums launch_pipeline writes into sum_rows for this
-// plan and trace count; 0 when the plan's fused kernel cannot accumulate them
-size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask);
+                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr);
 void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask);
 void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
                      const c32 *cmask);
 void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, const float *win,
                       float *out);
+void launch_scale_vec(hipStream_t st, const float *in, float f, size_t n, float *out);          // out = in * f
+void launch_add_vec(hipStream_t st, float *dst, const float *src, size_t n);                    // dst += src
+void launch_add_u64(hipStream_t st, unsigned long long *dst, const unsigned long long *src, size_t n);
 void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *img,
                       int subtract_bias);
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,

@@ -21,13 +21,21 @@ struct thz_session {
     float *d_raw = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr, *d_data = nullptr,
           *d_img = nullptr, *d_avg = nullptr;  // d_avg: [2 nf | nf | nf]
     float *d_vec = nullptr;                    // pre | mask | post multipliers (+ tilt scratch)
-    float *d_tilt = nullptr;                   // extended cube when tilt != 0
+    float *d_tilt = nullptr;                   // extended cube when tilt != 0 (kept while its size stays the same)
+    size_t tilt_floats = 0, ins_count = 0;
+    std::vector<float> fd_real, fd_cmask;      // further Frequency-domain plugins: K14 real (nf), K13 complex (2 nf)
+    thz_chain_cfg last_cfg{};                  // configuration of the last full recompute (decides whether a
+    bool have_last_cfg = false;                // start position >= 6 may reuse the resident spectrum)
     float *d_deconv = nullptr, *d_deconv_img = nullptr;  // output of the Deconvolution stage (thz_session_deconvolve)
     size_t deconv_floats = 0;
     bool deconv_current = false;               // ... and whether it is the chain's final output right now
     float *d_opacity = nullptr;                // voxel opacities of the final cube (thz_session_voxels)
     size_t opacity_floats = 0;
     int32_t *d_ins = nullptr;
+    float *d_rawsum = nullptr;   // (nt) sum over the pixels of the raw (bias-subtracted) traces, taken at upload
+    float *d_msum = nullptr;     // [Σ source trace: nt_out | Σ amplitudes: nf | Σ phases: nf] of the last recompute, undivided
+    size_t msum_floats = 0;
+    bool msum_fast = false;      // the last recompute left its undivided sums in d_msum (want_means == 1)
     bool have_means = false;
     bool have_outputs = false;   // a recompute has run
     const float *d_src = nullptr;  // what the fft stage read: d_raw, d_scaled or d_tilt (extended axis)
@@ -58,7 +66,7 @@ int alloc_outputs(thz_session *s, size_t nt_out)
     if (int rc = dev_alloc(ctx, &s->d_ph, npix * nf)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_data, npix * nt_out)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_avg, 4 * nf)) return rc;
-    if (int rc = dev_alloc(ctx, &s->d_vec, 3 * nt_out + nf + 8)) return rc;
+    if (int rc = dev_alloc(ctx, &s->d_vec, 3 * nt_out + 3 * nf + 16)) return rc;  // pre | post | mask | cmask (+ tilt scratch)
     s->nt_out = nt_out;
     s->nf_out = nf;
     s->out_pix = npix;
@@ -103,6 +111,7 @@ int thz_session_create(thz_ctx *ctx, size_t nx, size_t ny, size_t nt, const floa
     s->time_out = s->time;
     int rc = dev_alloc(ctx, &s->d_raw, nx * ny * nt);
     if (!rc) rc = dev_alloc(ctx, &s->d_img, nx * ny);
+    if (!rc) rc = dev_alloc(ctx, &s->d_rawsum, nt);
     if (!rc) rc = alloc_outputs(s, nt);
     if (rc) { thz_session_destroy(s); return rc; }
     *out = s;
@@ -116,7 +125,8 @@ void thz_session_destroy(thz_session *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
                     (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins,
-                    (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img, (void *)s->d_scaled})
+                    (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img, (void *)s->d_scaled,
+                    (void *)s->d_rawsum, (void *)s->d_msum})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -134,30 +144,107 @@ int thz_session_upload(thz_session *s, const float *cube, int subtract_bias)
     if (cube) HIP_TRY(ctx, hipMemcpyAsync(s->d_raw, cube, npix * s->nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     launch_intensity(ctx->stream, npix, (int)s->nt, s->d_raw, s->d_img, subtract_bias ? 1 : 0);
     if (int rc = check_launch(ctx)) return rc;
+    // Σ over the pixels of the raw traces, once per file: every recompute's avg_fft follows from it by
+    // linearity (see session_means) instead of from a pass over the spectra it has just written
+    if (int rc = thz_pixel_sum(ctx, npix, s->nt, 1, s->d_raw, s->d_rawsum)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return THZ_OK;
 }
 
-int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The recompute, in two halves so that a group of sessions (group_api.cpp: one x-slab per GPU) can put
+// its exchange step between them:
+//   session_enqueue  everything up to and including the fused launch, on the context's stream; leaves
+//                    the slab's undivided sums in d_msum when the fast means are possible
+//   session_means    pixel means from (possibly all-reduced) sums
+// Chain positions (filter_chain of main.rs:182-247, "initial" = 0):
+//   1 scaling  2 Tilt Compensation  3 Time Band Pass  4 fft  5 Frequency Band Pass [+ K14 / K13]
+//   6 ifft  7 Time Band Pass (after)  8 Deconvolution
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// fields of a chain configuration that decide everything in front of chain position 6
+bool same_front(const thz_chain_cfg &a, const thz_chain_cfg &b)
 {
-    if (!s || !cfg) return THZ_ERR_INVALID;
+    return a.tilt_active == b.tilt_active && a.tilt_x_deg == b.tilt_x_deg && a.tilt_y_deg == b.tilt_y_deg
+           && a.td_before_active == b.td_before_active && a.td_before_low == b.td_before_low
+           && a.td_before_high == b.td_before_high && a.td_before_width == b.td_before_width
+           && a.fft_window.type == b.fft_window.type && a.fft_window.lower == b.fft_window.lower
+           && a.fft_window.upper == b.fft_window.upper && a.fd_active == b.fd_active && a.fd_low == b.fd_low
+           && a.fd_high == b.fd_high && a.fd_width == b.fd_width && a.scale_factor == b.scale_factor
+           && a.want_means == b.want_means;
+}
+
+void post_multiplier(const thz_chain_cfg *cfg, const std::vector<float> &time, std::vector<float> &post)
+{
+    post.assign(time.size(), 1.0f);
+    if (cfg->td_after_active) {
+        double lo = cfg->td_after_low, hi = cfg->td_after_high;
+        td_bandpass(time.data(), time.size(), &lo, &hi, cfg->td_after_width, post.data(), nullptr, nullptr);
+    }
+}
+
+}  // namespace
+
+// chain positions >= 6 on the resident band-passed spectrum: C2R, the new Time Band Pass, image
+static int session_tail(thz_session *s, const thz_chain_cfg *cfg)
+{
+    thz_ctx *ctx = s->ctx;
+    const size_t nt = s->nt_out, npix = s->nx_cur * s->ny_cur;
+    if (ctx->time.size() != nt || std::memcmp(ctx->time.data(), s->time_out.data(), nt * sizeof(float)) != 0)
+        if (int rc = thz_set_time_axis(ctx, s->time_out.data(), nt)) return rc;
+    std::vector<float> post;
+    post_multiplier(cfg, s->time_out, post);
+    float *d_post = s->d_vec + nt;
+    HIP_TRY(ctx, hipMemcpyAsync(d_post, post.data(), nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `post` dies at return
+    s->deconv_current = false;
+    return thz_ifft(ctx, npix, s->d_fft, d_post, s->d_data, s->d_img);
+}
+
+int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, bool *tail_only)
+{
     thz_ctx *ctx = s->ctx;
     if (int rc = use_device(ctx)) return rc;
+    *tail_only = false;
+    if (start_stage >= 6 && s->have_outputs && s->have_last_cfg && same_front(s->last_cfg, *cfg)) {
+        *tail_only = true;
+        if (int rc = session_tail(s, cfg)) return rc;
+        s->last_cfg = *cfg;
+        return THZ_OK;
+    }
     const float *src = s->d_raw;
     std::vector<float> time = s->time;
     std::vector<float> tilt_taper;
     size_t nt_cur = s->nt;
-    bool tilt_as_multiplier = false;
+    bool tilt_as_multiplier = false, tilted = false;
 
     // ---- scaling (math_tools.rs:242-310): s x s block means of the raw cube, / s^2 also on ragged
     // edges; dx, dy grow by s; identity when s <= 1 or when a side would vanish (:244-256)
     size_t sf = cfg->scale_factor > 1 ? (size_t)cfg->scale_factor : 1;
     if (s->nx / sf == 0 || s->ny / sf == 0) sf = 1;
+    // ---- Tilt Compensation, planned before any buffer is touched: a length no transform exists for
+    // leaves the session as it was (the reference re-plans for any length)
+    const size_t nx_c = s->nx / sf, ny_c = s->ny / sf;
+    const float dx_c = s->dx * (float)sf, dy_c = s->dy * (float)sf;
+    size_t steps = 0;
+    if (cfg->tilt_active)
+        steps = tilt_plan(time.data(), nt_cur, nx_c, ny_c, cfg->tilt_x_deg, cfg->tilt_y_deg, dx_c, dy_c, nullptr, nullptr);
+    if (steps) {
+        PlanHost probe;
+        if (!build_plan(nt_cur + 2 * steps, probe, ctx->allow_f))
+            return fail(ctx, THZ_ERR_UNSUPPORTED,
+                        "tilt compensation extends the traces to " + std::to_string(nt_cur + 2 * steps)
+                            + " samples: no transform of that length (powers of two up to 16384, other lengths up to 8191)");
+    }
     s->have_outputs = false;  // the grid may change under the buffers below
+    s->have_last_cfg = false;
     s->deconv_current = false;
     s->scale = sf;
-    s->nx_cur = s->nx / sf; s->ny_cur = s->ny / sf;
-    s->dx_cur = s->dx * (float)sf; s->dy_cur = s->dy * (float)sf;
+    s->nx_cur = nx_c; s->ny_cur = ny_c;
+    s->dx_cur = dx_c; s->dy_cur = dy_c;
     const size_t npix = s->nx_cur * s->ny_cur;
     if (sf > 1) {
         if (s->scaled_floats != npix * s->nt) {
@@ -172,8 +259,6 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     // ---- Tilt Compensation: zero tilt is just its tail taper (a multiplier); otherwise the
     // cube is re-laid out on an extended axis and the chain continues at the new length
     if (cfg->tilt_active) {
-        const size_t steps = tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg,
-                                       s->dx_cur, s->dy_cur, nullptr, nullptr);
         tilt_taper.resize(nt_cur);
         adapted_blackman(time.data(), nt_cur, 0.0f, 7.0f, tilt_taper.data());
         if (steps == 0) {
@@ -184,8 +269,16 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
             std::vector<int32_t> ins(npix);
             tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx_cur, s->dy_cur,
                       new_time.data(), ins.data());
-            if (int rc = dev_alloc(ctx, &s->d_tilt, npix * nt2)) return rc;
-            if (int rc = dev_alloc(ctx, &s->d_ins, npix)) return rc;
+            if (s->tilt_floats != npix * nt2) {
+                s->tilt_floats = 0;
+                if (int rc = dev_alloc(ctx, &s->d_tilt, npix * nt2)) return rc;
+                s->tilt_floats = npix * nt2;
+            }
+            if (s->ins_count != npix) {
+                s->ins_count = 0;
+                if (int rc = dev_alloc(ctx, &s->d_ins, npix)) return rc;
+                s->ins_count = npix;
+            }
             if (int rc = alloc_outputs(s, nt2)) return rc;
             HIP_TRY(ctx, hipMemcpyAsync(s->d_ins, ins.data(), npix * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(s->d_vec, tilt_taper.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -195,15 +288,19 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
             src = s->d_tilt;
             time = new_time;
             nt_cur = nt2;
+            tilted = true;
         }
     }
     if (int rc = alloc_outputs(s, nt_cur)) return rc;
     if (int rc = thz_set_time_axis(ctx, time.data(), nt_cur)) return rc;  // (re)plan, data_thread.rs:1194-1227
     s->time_out = time;
     const size_t nf = nt_cur / 2 + 1;
+    if ((!s->fd_real.empty() && s->fd_real.size() != nf) || (!s->fd_cmask.empty() && s->fd_cmask.size() != 2 * nf))
+        return fail(ctx, THZ_ERR_INVALID, "thz_session_set_fd_filters: the multipliers were given for " + std::to_string(s->fd_real.empty() ? s->fd_cmask.size() / 2 : s->fd_real.size())
+                                              + " bins, this chain's spectra have " + std::to_string(nf));
 
     // ---- multipliers in the reference's f32 order: ((tilt * td_before) * fft_window)
-    std::vector<float> pre(nt_cur, 1.0f), w(nt_cur), post(nt_cur, 1.0f), mask(nf, 1.0f);
+    std::vector<float> pre(nt_cur, 1.0f), w(nt_cur), post, mask(nf, 1.0f);
     if (tilt_as_multiplier) pre = tilt_taper;
     if (cfg->td_before_active) {
         double lo = cfg->td_before_low, hi = cfg->td_before_high;
@@ -214,33 +311,113 @@ int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg)
     for (size_t i = 0; i < nt_cur; ++i) pre[i] = pre[i] * w[i];
     if (cfg->fd_active)
         fd_bandpass(ctx->freq.data(), nf, cfg->fd_low, cfg->fd_high, cfg->fd_width, mask.data(), nullptr, nullptr);
-    if (cfg->td_after_active) {
-        double lo = cfg->td_after_low, hi = cfg->td_after_high;
-        td_bandpass(time.data(), nt_cur, &lo, &hi, cfg->td_after_width, post.data(), nullptr, nullptr);
-    }
-    float *d_pre = s->d_vec, *d_post = s->d_vec + nt_cur, *d_mask = s->d_vec + 2 * nt_cur;
-    // keep the mask 16-byte aligned for the kernels' vector reads
-    d_mask = s->d_vec + ((2 * nt_cur + 3) & ~(size_t)3);
+    // further Frequency-domain plugins behind the band pass (K14: a real multiplier, one f32 multiply per
+    // plugin like the band pass itself)
+    if (!s->fd_real.empty())
+        for (size_t k = 0; k < nf; ++k) mask[k] = mask[k] * s->fd_real[k];
+    post_multiplier(cfg, time, post);
+    float *d_pre = s->d_vec, *d_post = s->d_vec + nt_cur;
+    // keep the masks 16-byte aligned for the kernels' vector reads
+    float *d_mask = s->d_vec + ((2 * nt_cur + 3) & ~(size_t)3);
+    float *d_cmask = d_mask + ((nf + 3) & ~(size_t)3);
     HIP_TRY(ctx, hipMemcpyAsync(d_pre, pre.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_post, post.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_mask, mask.data(), nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!s->fd_cmask.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(d_cmask, s->fd_cmask.data(), 2 * nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die at return
 
-    if (int rc = thz_pipeline(ctx, npix, src, d_pre, d_mask, d_post, s->d_fft, s->d_amp, s->d_ph, s->d_data, s->d_img))
-        return rc;
+    // ---- pixel means.  want_means == 1: amplitude / phase sums accumulated inside the fused launch, and
+    // avg_fft by linearity — every multiplier in front of the transform is the same for all pixels unless
+    // the cube was tilted, so mean_p(H FFT(w x_p)) = H FFT(w mean_p(x_p)): ONE extra transform instead of a
+    // pass over the spectra.  want_means == 2 (and any tilted cube): the reference's summation order
+    // (ndarray mean_axis twice, math_tools.rs:421-440), bit for bit, as three passes over the outputs.
+    s->msum_fast = cfg->want_means == 1 && !tilted;
+    if (s->msum_fast) {
+        if (s->msum_floats != nt_cur + 2 * nf) {
+            s->msum_floats = 0;
+            if (int rc = dev_alloc(ctx, &s->d_msum, nt_cur + 2 * nf)) return rc;
+            s->msum_floats = nt_cur + 2 * nf;
+        }
+        // Σ of the source traces: cached at upload for the raw cube, one small pass for a block-averaged one
+        if (src == s->d_raw) HIP_TRY(ctx, hipMemcpyAsync(s->d_msum, s->d_rawsum, nt_cur * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        else if (int rc = thz_pixel_sum(ctx, npix, nt_cur, 1, src, s->d_msum)) return rc;
+    }
+    thz_pipeline_io io{};
+    io.d_raw = src; io.d_pre_win = d_pre; io.d_fd_mask = d_mask; io.d_fd_cmask = s->fd_cmask.empty() ? nullptr : d_cmask;
+    io.d_post_win = d_post; io.d_fft = s->d_fft; io.d_amp = s->d_amp; io.d_phase = s->d_ph; io.d_data_out = s->d_data;
+    io.d_img = s->d_img; io.d_sums = s->msum_fast ? s->d_msum + nt_cur : nullptr;
+    if (int rc = thz_pipeline_ex(ctx, npix, &io)) return rc;
     s->have_means = false;
     s->have_outputs = true;
     s->deconv_current = false;  // the stage passes its input through unless it is the one updated
     s->d_src = src;
-    if (cfg->want_means) {
+    s->last_cfg = *cfg;
+    s->have_last_cfg = true;
+    return THZ_OK;
+}
+
+// Pixel means of the ifft stage.  total_pix: pixels of the WHOLE grid the sums in d_msum now cover (the
+// slab's own, or — after the group's all-reduce — all slabs').
+int session_means(thz_session *s, const thz_chain_cfg *cfg, size_t total_pix)
+{
+    thz_ctx *ctx = s->ctx;
+    if (int rc = use_device(ctx)) return rc;
+    const size_t nt = s->nt_out, nf = s->nf_out;
+    if (!cfg->want_means) return THZ_OK;
+    if (s->msum_fast) {
+        const float inv = 1.0f / (float)total_pix;
+        // amplitudes and phases: sums / pixels; mean source trace in place
+        launch_scale_vec(ctx->stream, s->d_msum + nt, inv, 2 * nf, s->d_avg + 2 * nf);
+        launch_scale_vec(ctx->stream, s->d_msum, inv, nt, s->d_msum);
+        if (int rc = check_launch(ctx)) return rc;
+        // avg_fft = (cmask mask) FFT(pre * mean trace): the same kernels as the cube's own transform
+        float *d_pre = s->d_vec;
+        float *d_mask = s->d_vec + ((2 * nt + 3) & ~(size_t)3);
+        float *d_cmask = d_mask + ((nf + 3) & ~(size_t)3);
+        if (int rc = thz_fft(ctx, 1, s->d_msum, d_pre, nullptr, nullptr, s->d_avg, nullptr, nullptr, d_mask)) return rc;
+        if (!s->fd_cmask.empty())
+            if (int rc = thz_apply_fd_cmask(ctx, 1, s->d_avg, nullptr, d_cmask)) return rc;
+    } else {
         if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 2, s->d_fft, s->d_avg)) return rc;
         if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 1, s->d_amp, s->d_avg + 2 * nf)) return rc;
         if (int rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nf, 1, s->d_ph, s->d_avg + 3 * nf)) return rc;
-        s->have_means = true;
     }
+    s->have_means = true;
+    return THZ_OK;
+}
+
+extern "C" {
+
+int thz_session_recompute_from(thz_session *s, const thz_chain_cfg *cfg, int start_stage)
+{
+    if (!s || !cfg) return THZ_ERR_INVALID;
+    thz_ctx *ctx = s->ctx;
+    if (start_stage < 0 || start_stage > 8) return fail(ctx, THZ_ERR_INVALID, "thz_session_recompute_from: chain positions are 1..8");
+    if (start_stage == 8) return THZ_OK;  // only the Deconvolution stage is re-run: thz_session_deconvolve
+    bool tail_only = false;
+    if (int rc = session_enqueue(s, cfg, start_stage, &tail_only)) return rc;
+    if (!tail_only)
+        if (int rc = session_means(s, cfg, s->nx_cur * s->ny_cur)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return THZ_OK;
 }
+
+int thz_session_recompute(thz_session *s, const thz_chain_cfg *cfg) { return thz_session_recompute_from(s, cfg, 1); }
+
+int thz_session_set_fd_filters(thz_session *s, const float *real_mask, const float *cmask, size_t nf)
+{
+    if (!s) return THZ_ERR_INVALID;
+    if ((real_mask || cmask) && nf == 0) return fail(s->ctx, THZ_ERR_INVALID, "thz_session_set_fd_filters: nf is 0");
+    s->fd_real.assign(real_mask ? real_mask : nullptr, real_mask ? real_mask + nf : nullptr);
+    s->fd_cmask.assign(cmask ? cmask : nullptr, cmask ? cmask + 2 * nf : nullptr);
+    s->have_last_cfg = false;  // the next recompute starts at the front whatever its start position says
+    return THZ_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_cfg *cfg,
                            volatile const int *abort_flag, float *progress)
@@ -294,6 +471,11 @@ void *thz_session_buffer(thz_session *s, int which)
 {
     if (!s) return nullptr;
     const size_t nf = s->nf_out;
+    // Before the first recompute (and between an upload and the next recompute) the output buffers hold
+    // nothing a caller may read — and after a scaled recompute they are sized for the smaller grid while
+    // the session's grid is the raw one again: absent (NULL / THZ_ERR_NOT_READY) until a recompute has run.
+    // The image is the exception: thz_session_upload fills it for the raw grid (io.rs:588-594).
+    if (!s->have_outputs && which != THZ_BUF_RAW && which != THZ_BUF_IMG) return nullptr;
     switch (which) {
     case THZ_BUF_RAW: return s->d_raw;
     case THZ_BUF_FFT: return s->d_fft;
@@ -316,7 +498,11 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     const float *base = static_cast<const float *>(thz_session_buffer(s, which));
     if (!base) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_download: buffer not available");
     size_t per = 0;  // floats per pixel
-    const size_t total_pix = which == THZ_BUF_RAW ? s->nx * s->ny : s->nx_cur * s->ny_cur;
+    // per-pixel outputs were allocated for out_pix pixels by the recompute that filled them; the image has
+    // nx * ny entries (allocated once) of which the current grid's are valid
+    const size_t total_pix = which == THZ_BUF_RAW ? s->nx * s->ny
+                             : which == THZ_BUF_IMG ? s->nx_cur * s->ny_cur
+                                                    : (s->out_pix < s->nx_cur * s->ny_cur ? s->out_pix : s->nx_cur * s->ny_cur);
     switch (which) {
     case THZ_BUF_RAW: per = s->nt; break;
     case THZ_BUF_FFT: per = 2 * s->nf_out; break;
@@ -327,7 +513,7 @@ int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, vo
     case THZ_BUF_AVG_AMPLITUDES: case THZ_BUF_AVG_PHASES: return thz_memcpy_d2h(ctx, dst, base, s->nf_out * sizeof(float));
     default: return THZ_ERR_INVALID;
     }
-    if (pix0 + npix > total_pix) return fail(ctx, THZ_ERR_INVALID, "thz_session_download: pixel range out of bounds");
+    if (pix0 > total_pix || npix > total_pix - pix0) return fail(ctx, THZ_ERR_INVALID, "thz_session_download: pixel range out of bounds");
     return thz_memcpy_d2h(ctx, dst, base + pix0 * per, npix * per * sizeof(float));
 }
 

@@ -26,6 +26,10 @@ struct Dataset {
     std::string name;
     int ndim = 0;
     hsize_t dims[3] = {0, 0, 0};
+    // hdf5-rust's read_1d::<f32>() / read_dyn::<f32>() (io.rs:523-566) succeed for every dataset HDF5 can
+    // convert to a native float — integers and floats of any width (Conversion::Soft, the reader's default)
+    // — and fail for strings, compounds, references ...: the reference's role loop then tries the next dataset
+    bool numeric = false;
 };
 
 // Rust's f64::to_string: integers without a fraction, otherwise the shortest digits that round-trip
@@ -199,6 +203,12 @@ int thz_io_open(const char *path, thz_io_file **out)
         ds.ndim = H5Sget_simple_extent_ndims(sp);
         if (ds.ndim >= 1 && ds.ndim <= 3) H5Sget_simple_extent_dims(sp, ds.dims, nullptr);
         H5Sclose(sp);
+        const hid_t ty = H5Dget_type(d);
+        if (ty >= 0) {
+            const H5T_class_t cls = H5Tget_class(ty);
+            ds.numeric = cls == H5T_FLOAT || cls == H5T_INTEGER;
+            H5Tclose(ty);
+        }
         H5Dclose(d);
         f->datasets.push_back(ds);
     }
@@ -213,9 +223,18 @@ int thz_io_open(const char *path, thz_io_file **out)
     }
     // dataset roles, io.rs:523-566
     for (size_t i = 0; i < f->datasets.size(); ++i)
-        if (f->datasets[i].ndim == 1) { f->time_ds = (int)i; break; }
+        if (f->datasets[i].ndim == 1 && f->datasets[i].numeric) { f->time_ds = (int)i; break; }
     for (size_t i = 0; i < f->datasets.size(); ++i)
-        if (f->datasets[i].ndim == 3) { f->cube_ds = (int)i; break; }
+        if (f->datasets[i].ndim == 3 && f->datasets[i].numeric) { f->cube_ds = (int)i; break; }
+    // A time axis that is not as long as the cube's traces is not a scan any stage could process (the
+    // reference would hand mismatched arrays to ndarray's Zip and panic); callers size their time buffer
+    // from the cube's last dimension, so such a file is refused here rather than read past that buffer.
+    if (f->time_ds >= 0 && f->cube_ds >= 0 && f->datasets[f->time_ds].dims[0] != f->datasets[f->cube_ds].dims[2]) {
+        const std::string msg = "group " + f->group_name + ": time axis has " + std::to_string(f->datasets[f->time_ds].dims[0])
+                                + " samples, the cube's traces " + std::to_string(f->datasets[f->cube_ds].dims[2]);
+        thz_io_close(f);
+        return fail(THZ_IO_ERR_FORMAT, msg);
+    }
     if (f->time_ds >= 0 || f->cube_ds >= 0) {
         f->kind = 0;
         if (f->cube_ds >= 0) {
@@ -224,7 +243,7 @@ int thz_io_open(const char *path, thz_io_file **out)
             f->nt = f->datasets[f->cube_ds].dims[2];
         }
         if (f->time_ds >= 0 && f->cube_ds < 0) f->nt = f->datasets[f->time_ds].dims[0];
-    } else if (!f->datasets.empty() && f->datasets[0].ndim == 2 && f->datasets[0].dims[1] >= 2) {
+    } else if (!f->datasets.empty() && f->datasets[0].ndim == 2 && f->datasets[0].dims[1] >= 2 && f->datasets[0].numeric) {
         f->kind = 1;
         f->nx = f->ny = 1;
         f->nt = f->datasets[0].dims[0];
@@ -261,7 +280,19 @@ int thz_io_read_time(thz_io_file *f, float *time)
     if (f->kind == 0) {
         if (f->time_ds < 0) return fail(THZ_IO_ERR_FORMAT, "no 1-D time dataset");
         hid_t d = H5Dopen2(f->group, f->datasets[f->time_ds].name.c_str(), H5P_DEFAULT);
-        const herr_t rc = H5Dread(d, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, time);
+        if (d < 0) return fail(THZ_IO_ERR_HDF5, "cannot open the time dataset");
+        // exactly f->nt elements, whatever the dataset's extent says now: the caller's buffer has that many
+        const hsize_t start[1] = {0}, count[1] = {(hsize_t)f->nt};
+        hid_t fs = H5Dget_space(d);
+        herr_t rc = -1;
+        if (fs >= 0 && H5Sget_simple_extent_ndims(fs) == 1 && H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, nullptr, count, nullptr) >= 0) {
+            hid_t ms = H5Screate_simple(1, count, nullptr);
+            if (ms >= 0) {
+                rc = H5Dread(d, H5T_NATIVE_FLOAT, ms, fs, H5P_DEFAULT, time);
+                H5Sclose(ms);
+            }
+        }
+        if (fs >= 0) H5Sclose(fs);
         H5Dclose(d);
         return rc < 0 ? fail(THZ_IO_ERR_HDF5, "reading the time dataset failed") : THZ_IO_OK;
     }
@@ -269,6 +300,7 @@ int thz_io_read_time(thz_io_file *f, float *time)
         const Dataset &ds = f->datasets[0];
         std::vector<float> buf((size_t)ds.dims[0] * ds.dims[1]);
         hid_t d = H5Dopen2(f->group, ds.name.c_str(), H5P_DEFAULT);
+        if (d < 0) return fail(THZ_IO_ERR_HDF5, "cannot open the pulse dataset");
         const herr_t rc = H5Dread(d, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data());
         H5Dclose(d);
         if (rc < 0) return fail(THZ_IO_ERR_HDF5, "reading the pulse dataset failed");
@@ -287,6 +319,7 @@ int thz_io_read_cube(thz_io_file *f, size_t x0, size_t n, float *dst)
         const Dataset &ds = f->datasets[0];
         std::vector<float> buf((size_t)ds.dims[0] * ds.dims[1]);
         hid_t d = H5Dopen2(f->group, ds.name.c_str(), H5P_DEFAULT);
+        if (d < 0) return fail(THZ_IO_ERR_HDF5, "cannot open the pulse dataset");
         const herr_t rc = H5Dread(d, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data());
         H5Dclose(d);
         if (rc < 0) return fail(THZ_IO_ERR_HDF5, "reading the pulse dataset failed");
@@ -295,6 +328,7 @@ int thz_io_read_cube(thz_io_file *f, size_t x0, size_t n, float *dst)
     }
     if (f->kind != 0 || f->cube_ds < 0) return fail(THZ_IO_ERR_FORMAT, "no 3-D dataset");
     hid_t d = H5Dopen2(f->group, f->datasets[f->cube_ds].name.c_str(), H5P_DEFAULT);
+    if (d < 0) return fail(THZ_IO_ERR_HDF5, "cannot open the cube dataset");
     hid_t fs = H5Dget_space(d);
     const hsize_t start[3] = {x0, 0, 0}, count[3] = {n, f->ny, f->nt};
     H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, nullptr, count, nullptr);
