@@ -2,19 +2,22 @@
 """bench.py — traces/s of the full default recompute chain on the synthetic
 1024x1024x4096 fp32 cube (BASELINE.json metric), one process per GPU.
 
-A step = one pass of the hot path over the rank's x-slab of the cube, cube
-already resident in HBM:
-    thz_pipeline   (window -> R2C -> |.|/arg/unwrap -> band-pass -> C2R/nt -> taper -> image)
-    thz_pixel_sum  x3 (avg_fft, avg_signal_fft, avg_phase_fft partials, math_tools.rs:421-440)
-    N > 1: RCCL all-reduce of the partial sums + gather of the image slabs to rank 0
-The cube is fixed as N grows (strong scaling: BASELINE.json asks for the same
-cube at 1, 2, 4 and 8 GPUs); use --scaling weak for a fixed slab per GPU.
+A step = one UpdateType::Filter(1) of the reference's data thread (data_thread.rs:1023-1334) served by the
+library, cube already resident in HBM:  thz_group_session_recompute =
+    on every rank's x-slab:  the fused launch (window -> R2C -> |.|/arg/unwrap -> band-pass -> C2R/nt ->
+                             taper -> image) + the pixel-sum passes over amplitudes and phases + avg_fft by
+                             linearity from the cached mean trace (one nt-point transform)
+    C2  ncclAllReduce of the pixel sums, C1 gather of per-pixel results to rank 0 (--gather small|time|all)
+Everything between "step starts" and "results on rank 0" happens inside libthzgpu.so (RCCL called by the
+library on its own streams); Python parses arguments, launches, and times.  torch.distributed (gloo) is used
+for the launch plumbing only: shipping the RCCL unique id, the barrier and the max over ranks of the timing
+contract.  The cube is fixed as N grows (strong scaling: BASELINE.json asks for the same cube at 1, 2, 4 and
+8 GPUs); --scaling weak keeps a fixed slab per GPU.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel
-(k_pipeline) from hipEvents recorded on the engine's own stream around every
-timed launch; `cpu_baseline` times the CPU oracle (port of the reference
-algorithm, OpenMP over x rows like the reference's rayon split) on a bounded
-sample on rank 0 at N=1.
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the fused launch) from hipEvents
+recorded on the engine's own stream around every timed launch; `cpu_baseline` times the CPU oracle (port of
+the reference algorithm, OpenMP over x rows like the reference's rayon split) on a bounded sample on rank 0
+at N = 1.
 """
 import argparse
 import json
@@ -37,7 +40,7 @@ def algorithmic_bytes_per_trace(nt):
     return 4 * nt + 16 * nf + 4 * nt + 4
 
 
-def measured_traffic(nt, traces_per_launch):
+def measured_traffic(nt, traces_per_launch, wiener=False):
     """HBM bytes per launch of the fused kernel from the committed PMC passes
     (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their
     own runs, gfx950 x2 correction on FETCH_SIZE).  Counters cannot be read from
@@ -50,7 +53,7 @@ def measured_traffic(nt, traces_per_launch):
             d = json.load(open(f))
         except Exception:
             continue
-        if "16,16,8" in d.get("kernel", "") and nt == 4096:
+        if "16,16,8" in d.get("kernel", "") and nt == 4096 and bool(d.get("wiener", False)) == wiener:
             best = d
     if best is None:
         return None
@@ -67,7 +70,7 @@ def cpu_baseline(nt, ny, budget_s):
     # one x row per task like rayon's split over Axis(0): give every thread rows
     nx_s, ny = max(2 * cores, 16), 64
     tm, cube = synth.make_cube(nx_s, ny, nt)
-    chain = synth.default_chain(tm)
+    chain = synth.oracle_chain(tm)
     ob.run_pipeline(cube[:1], tm, chain)  # warm (plans, page faults)
     done, t_used, passes = 0, 0.0, 0
     while t_used < budget_s and passes < 64:
@@ -108,6 +111,23 @@ def cpu_baseline(nt, ny, budget_s):
     return out
 
 
+def wiener_multiplier(eng, tm):
+    """K13 of BASELINE config 5 from the synthetic reference pulse (the noise-free template of the cube's traces,
+    SURVEY §8d): R through the engine's own window + transform, H by thz_host_wiener_filter"""
+    import thz_image_explorer_amd as pkg
+    nt = tm.size
+    nf = nt // 2 + 1
+    z = ((tm - tm[0] - 11.0) / 0.35).astype(np.float32)
+    ref = (-z * np.exp(-z * z)).astype(np.float32)
+    w = pkg.host_fft_window(tm, 0, 1.0, 7.0)
+    d_ref = eng.to_device(ref); d_w = eng.to_device(w); d_rf = eng.empty((nf, 2))
+    eng.fft(1, d_ref, d_w, None, None, d_rf, None, None, None)
+    R = d_rf.download((nf, 2), np.float32)
+    for b in (d_ref, d_w, d_rf):
+        b.free()
+    return pkg.host_wiener_filter(R, 1e-2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,86 +137,69 @@ def main():
     ap.add_argument("--ny", type=int, default=1024)
     ap.add_argument("--nt", type=int, default=4096)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--gather", choices=["small", "time", "all"], default="small",
+                    help="what C1 brings to rank 0 (SURVEY 8e): image + means / + final trace cube / every output")
+    ap.add_argument("--wiener", action="store_true",
+                    help="BASELINE config 5: the reference-pulse Wiener multiplier (complex, K13) in the fused launch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-means", action="store_true", help="time thz_pipeline alone")
-    ap.add_argument("--dist-backend", default="nccl",
-                    help="nccl (= RCCL, the default) or gloo to rehearse the N>1 path on a one-GPU box "
-                         "(ranks then share device LOCAL_RANK %% device_count)")
+    ap.add_argument("--no-means", action="store_true", help="no pixel means: the fused launch alone")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} "
-                             f"(got WORLD_SIZE={world})")
+    if args.gpus != world and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got WORLD_SIZE={world})")
     import torch
 
-    from thz_image_explorer_amd import Engine, binding, shard
+    import thz_image_explorer_amd as pkg
+    from thz_image_explorer_amd import binding
     import synth
 
+    # launch plumbing: the id of the library's RCCL communicator travels over a gloo broadcast
     dist = None
-    force_dist = os.environ.get("THZ_BENCH_FORCE_DIST") == "1"  # rehearse RCCL with a single rank
-    if world > 1 or force_dist:
+    uid = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [pkg.group_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     nx, ny, nt = args.nx, args.ny, args.nt
     nf = nt // 2 + 1
-    if args.scaling == "strong":
-        x0, nx_loc = shard.slab(nx, world, rank)  # contiguous x rows, like rayon over Axis(0)
-        nx_tot = nx
-    else:
-        nx_loc, x0 = nx, rank * nx
-        nx_tot = nx * world
+    nx_tot = nx if args.scaling == "strong" else nx * world
+    x0, nx_loc = pkg.host_slab(nx_tot, world, rank)   # contiguous x rows, like rayon over Axis(0)
     npix = nx_loc * ny
 
-    eng = Engine(local_rank)  # raises if libthzgpu.so or the GPU is missing: no fallback
+    # raises if libthzgpu.so, the GPU or (N > 1) librccl is missing: no fallback
+    group = pkg.Group(device=local_rank, rank=rank, world=world, uid=uid)
+    eng = group.engine(0)
     tm = synth.make_time(nt)
-    eng.set_time_axis(tm)
-    chain = synth.default_chain(tm)
+    gs = pkg.GroupSession(group, nx_tot, ny, tm)
+    sess = gs.member(0)
     d_time = eng.to_device(tm)
-    d_raw = eng.empty((npix, nt))
-    eng.synth_cube(d_raw, npix, x0 * ny, d_time)
-    d_pre = eng.to_device(chain["w_pre"]); d_fd = eng.to_device(chain["fd_mask"]); d_post = eng.to_device(chain["w_post"])
-    d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf))
-    d_out = eng.empty((npix, nt))
-    # small products live in torch tensors so RCCL can move them
-    t_img = torch.empty((nx_loc, ny), dtype=torch.float32, device=dev)
-    t_sums = torch.empty(4 * nf, dtype=torch.float32, device=dev)  # [fft re/im interleaved | amp | phase]
-    ext = torch.cuda.ExternalStream(eng.stream, device=dev)
-    p_img, p_sums = t_img.data_ptr(), t_sums.data_ptr()
+    eng.set_time_axis(tm)
+    eng.synth_cube(gs.member_buffer(0, pkg.BUF_RAW), npix, x0 * ny, d_time)   # this rank's rows of the one synthetic cube
+    gs.upload(None, subtract_bias=False)   # image of the raw cube, raw pixel sums (+ their all-reduce): once per file
+    cfg = pkg.chain_cfg_default(tm)
+    cfg.want_means = 0 if args.no_means else 1
+    if args.wiener:
+        sess.set_fd_filters(None, wiener_multiplier(eng, tm))
+    gather = {"small": pkg.GATHER_SMALL, "time": pkg.GATHER_TIME, "all": pkg.GATHER_ALL}[args.gather]
 
     def step():
-        eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, p_img)
-        if not args.no_means:
-            eng.pixel_sum(npix, nf, 2, d_fft, p_sums)
-            eng.pixel_sum(npix, nf, 1, d_amp, p_sums + 8 * nf)
-            eng.pixel_sum(npix, nf, 1, d_ph, p_sums + 12 * nf)
-        if dist is not None:
-            with torch.cuda.stream(ext):  # collectives ordered after the kernels, no host sync
-                if not args.no_means:
-                    shard.all_reduce_sums(t_sums, dist)      # C2
-                shard.gather_image(t_img, nx_tot, dist)      # C1
+        gs.recompute(cfg, 1, gather)
 
     def fence():
-        eng.sync()
+        group.sync()
         torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local_rank]) if args.dist_backend == "nccl" else dist.barrier()
+            dist.barrier()
             torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -209,33 +212,55 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pipe_ns, pipe_calls = eng.timing_collect(binding.STAGE_PIPELINE)
+    mean_ns, mean_calls = eng.timing_collect(binding.STAGE_MEAN)
+    eng.timing_collect(binding.STAGE_FFT)
     eng.enable_timing(0)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # The north star's 60 % target is quoted on the fused window + FFT + band-pass kernel (spectrum only,
-    # M_fwd = 8 nt + 8 bytes per trace): measured beside the headline, outside the timed region,
-    # with the same HIP-event timing on the kernel's own stream.
-    fwd = None
+    # Beside the headline, outside the timed region, same HIP-event timing on the kernel's own stream:
+    #  - the north star's 60 % target is quoted on the fused window + FFT + band-pass kernel (spectrum only,
+    #    M_fwd = 8 nt + 8 bytes per trace);
+    #  - BASELINE config 5's chain: the complex reference-pulse multiplier inside the same ONE launch.
+    fwd = wleg = None
     if rank == 0:
+        d_raw = gs.member_buffer(0, pkg.BUF_RAW)
+        d_fft = gs.member_buffer(0, pkg.BUF_FFT); d_amp = gs.member_buffer(0, pkg.BUF_AMPLITUDES)
+        d_ph = gs.member_buffer(0, pkg.BUF_PHASES); d_out = gs.member_buffer(0, pkg.BUF_DATA)
+        chain = synth.default_chain(tm)
+        d_pre = eng.to_device(chain["w_pre"]); d_fd = eng.to_device(chain["fd_mask"]); d_post = eng.to_device(chain["w_post"])
         eng.enable_timing(2)
         for _ in range(10):
             eng.fft(npix, d_raw, d_pre, None, None, d_fft, None, None, d_fd)
         eng.sync()
         fwd_ns, fwd_calls = eng.timing_collect(binding.STAGE_FFT)
-        eng.enable_timing(0)
         if fwd_calls:
             fwd_s = fwd_ns / fwd_calls * 1e-9
             fwd_gbs = npix * (8 * nt + 8) / fwd_s / 1e9
             fwd = {"kernel": "k_f<fwd> (window + R2C + band-pass, spectrum only)", "bytes_per_trace": 8 * nt + 8,
                    "avg_launch_ms": fwd_s * 1e3, "achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBPS,
                    "launches_timed": fwd_calls}
+        if not args.wiener:
+            d_H = eng.to_device(wiener_multiplier(eng, tm))
+            for _ in range(6):
+                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, None, None)
+            eng.sync()
+            w_ns, w_calls = eng.timing_collect(binding.STAGE_PIPELINE)
+            if w_calls:
+                w_s = w_ns / w_calls * 1e-9
+                w_gbs = npix * algorithmic_bytes_per_trace(nt) / w_s / 1e9
+                wleg = {"kernel": "k_f<pipe, complex multiplier> (BASELINE config 5: reference-pulse Wiener filter in the fused launch)",
+                        "bytes_per_trace": algorithmic_bytes_per_trace(nt), "avg_launch_ms": w_s * 1e3, "achieved": w_gbs,
+                        "frac": w_gbs / HBM_PEAK_GBPS, "launches_timed": w_calls,
+                        "traffic": measured_traffic(nt, npix, wiener=True)}
+        eng.enable_timing(0)
 
     # sanity: the run produced finite, non-trivial output (checked outside the timed region)
-    img_h = t_img.cpu().numpy()
-    assert np.isfinite(img_h).all() and img_h.max() > 0, "pipeline produced no output"
+    if rank == 0:
+        img_h = gs.download(pkg.BUF_IMG)
+        assert np.isfinite(img_h).all() and img_h.max() > 0, "pipeline produced no output"
 
     if rank == 0:
         total_traces = nx_tot * ny
@@ -250,23 +275,29 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{nx_tot}x{ny}x{nt} fp32 synthetic cube (Philox seed 0x7A3D2026), default chain: "
                                    "tilt taper + Time Band Pass + fft window -> R2C -> amplitude/phase/unwrap -> "
-                                   "Frequency Band Pass 0.2-5 THz -> C2R/nt -> Time Band Pass -> intensity image"
+                                   "Frequency Band Pass 0.2-5 THz"
+                                   + (" x reference-pulse Wiener multiplier (complex)" if args.wiener else "")
+                                   + " -> C2R/nt -> Time Band Pass -> intensity image"
                                    + ("" if args.no_means else " + pixel-mean spectra"),
                        "parallelism": f"x-slab tiles, {world} rank(s), {nx_loc}x{ny} traces per GPU"
-                                      + ("; RCCL all-reduce of mean partials + image gather" if world > 1 else ""),
+                                      + (f"; in-library RCCL: all-reduce of pixel sums + gather '{args.gather}' to rank 0"
+                                         if world > 1 else ""),
+                       "gather": args.gather, "step": "thz_group_session_recompute (UpdateType::Filter(1))",
                        "kernel_variant": eng.kernel_variant(),
                        "achieved_hbm_pct_whole_step": 100.0 * value / world * m_full / 1e9 / HBM_PEAK_GBPS},
-            "roofline": {"bound": "hbm", "kernel": "k_pipeline", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_f<pipe> (fused default chain)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(nt, npix),
+                         "traffic": measured_traffic(nt, npix, wiener=args.wiener),
                          "bytes_per_trace": m_full, "traces_per_launch": npix,
                          "avg_launch_ms": k_avg_s * 1e3, "launches_timed": pipe_calls,
-                         "fused_forward_kernel": fwd},
+                         "pixel_sum_passes_ms_per_step": (mean_ns / max(args.steps, 1)) * 1e-6 if mean_calls else None,
+                         "fused_forward_kernel": fwd, "wiener_leg": wleg},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nt, ny, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    eng.close()
+    gs.close()
+    group.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -495,6 +495,77 @@ void *thz_session_buffer(thz_session *s, int which);
  * pixel range beyond the grid of the recompute that filled it. */
 int thz_session_download(thz_session *s, int which, size_t pix0, size_t npix, void *dst);
 
+/* ------------------------------------------------------------------ */
+/* Multi-GPU: x-slab tiles of one cube over the GPUs of a node          */
+/* ------------------------------------------------------------------ */
+/* Every (x, y) trace is independent, so a cube is split into contiguous slabs of x rows,
+ * one per GPU — the split rayon makes over Axis(0) in the reference's pixel loops (math_tools.rs:333-339,
+ * 545-568).  The data path needs no collective; per recompute there are two exchange steps, both RCCL calls
+ * made by this library on the members' own streams (no host sync between kernels and collectives):
+ *   C2  ncclAllReduce(sum) of the slabs' pixel-sum vectors (2 nf floats) -> pixel means on every member
+ *   C1  grouped ncclSend / ncclRecv gather of per-pixel results to rank 0: the image always, the final
+ *       trace cube / every output on request (thz_gather)
+ * A group is either ONE process driving n devices — the shape of the reference, whose single data thread
+ * (data_thread.rs:162-174) would own all of them — or one member of a one-process-per-GPU launch
+ * (torchrun-style); the calls below are the same in both.  librccl is opened on first use of a group with
+ * more than one device, not at library load. */
+typedef struct thz_group thz_group;
+#define THZ_GROUP_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* rows [*x0, *x0 + *n) of `rank`: nx / world rows each, the remainder spread over the first ranks */
+int thz_host_slab(size_t nx, int world, int rank, size_t *x0, size_t *n);
+
+/* one process, n devices (ncclCommInitAll).  Members that all name the SAME device form a group without a
+ * fabric — collectives become device-local copies on that device — which is how a one-GPU box exercises
+ * the slab logic; a mix of repeated and distinct devices is THZ_ERR_INVALID. */
+int thz_group_create(const int *devices, int n, thz_group **out);
+/* one process per GPU: rank 0 calls thz_group_unique_id and ships the THZ_GROUP_ID_BYTES to every other
+ * rank by any means (a file, MPI, torch.distributed ...); every rank then calls thz_group_create_rank
+ * (ncclCommInitRank; collective: returns when all `world` ranks have called it). */
+int thz_group_unique_id(void *id);
+int thz_group_create_rank(int device, int rank, int world, const void *id, thz_group **out);
+void thz_group_destroy(thz_group *g);
+const char *thz_group_last_error(const thz_group *g);
+int thz_group_world(const thz_group *g);        /* ranks in the group */
+int thz_group_local_count(const thz_group *g);  /* members this process drives */
+int thz_group_rank(const thz_group *g, int i);  /* rank of local member i */
+thz_ctx *thz_group_ctx(thz_group *g, int i);    /* context of local member i (owned by the group) */
+/* C2 / C1 as stand-alone calls, for callers that drive the stage entry points themselves: d_bufs / d_send
+ * hold one device pointer per LOCAL member (on that member's device); counts has one entry per RANK;
+ * d_recv_root (on rank 0's device; ignored in processes that do not drive rank 0) receives the rows in
+ * rank order.  Enqueued on the members' streams. */
+int thz_group_all_reduce_sum(thz_group *g, float *const *d_bufs, size_t count);
+int thz_group_all_reduce_u64(thz_group *g, uint64_t *const *d_bufs, size_t count);
+int thz_group_gather(thz_group *g, const float *const *d_send, const size_t *counts, float *d_recv_root);
+int thz_group_sync(thz_group *g); /* waits for every local member's stream */
+
+/* what C1 brings to rank 0 (gathering everything is xGMI-bound — 6 GiB per peer at
+ * 1024 x 1024 x 4096 against 14 ms of compute — the GUI reads only the small products) */
+typedef enum thz_gather {
+    THZ_GATHER_SMALL = 0, /* image + pixel means (what img_lock / PlotDataContainer readers need) */
+    THZ_GATHER_TIME = 1,  /* + the final trace cube (the 3-D tab's input) */
+    THZ_GATHER_ALL = 2    /* + spectrum, amplitudes, phases: a complete ScannedImageFilterData on rank 0 */
+} thz_gather;
+
+/* A session over a group: member i keeps slab i of the raw cube and of every output resident.  Restricted to
+ * what shards without a halo: scale_factor 1, zero tilt, want_means 0 or 1 (others: THZ_ERR_UNSUPPORTED). */
+typedef struct thz_group_session thz_group_session;
+int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, const float *time, float dx, float dy,
+                             thz_group_session **out);
+void thz_group_session_destroy(thz_group_session *gs);
+/* the slab session of local member i (its buffers, plot copy-out, voxels ...); rows via thz_host_slab */
+thz_session *thz_group_session_member(thz_group_session *gs, int i);
+/* `cube`: the WHOLE (nx, ny, nt) host cube — each member uploads its rows — or NULL when the caller filled
+ * the members' THZ_BUF_RAW itself.  Collective (C2 of the raw pixel sums). */
+int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtract_bias);
+/* UpdateType::Filter(start_stage) on every slab + C2 + C1.  Collective; blocking. */
+int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg, int start_stage, int gather);
+/* gathered results on rank 0's device after a recompute: THZ_BUF_IMG (nx, ny) always; THZ_BUF_DATA with
+ * THZ_GATHER_TIME / ALL; THZ_BUF_FFT / AMPLITUDES / PHASES with ALL; THZ_BUF_AVG_* (on every member these
+ * are also in its slab session).  NULL when absent or when this process does not drive rank 0. */
+void *thz_group_session_result(thz_group_session *gs, int which);
+int thz_group_session_download(thz_group_session *gs, int which, size_t pix0, size_t npix, void *dst);
+
 /* Plot copy-out of UpdateType::Plot (data_thread.rs:1337-1432): everything the
  * right-hand panel plots for the selected pixel, in one call.  Host pointers, any
  * may be NULL.  px, py index the (nx, ny) grid (pixel_selected / scaling). */

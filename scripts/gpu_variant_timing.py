@@ -21,12 +21,13 @@ d_pre = eng.to_device(chain["w_pre"]); d_fd = eng.to_device(chain["fd_mask"]); d
 H = np.zeros((nf, 2), np.float32); H[:, 0] = 0.7; H[:, 1] = 0.3
 d_H = eng.to_device(H)
 d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
-d_sums = eng.empty((2 * nf,))
+m_full, m_fwd, m_inv = 16 * nt + 20, 8 * nt + 8, 8 * nf + 4 * nt + 4
 variants = {
-    "plain": lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img),
-    "sums": lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums),
-    "cmask": lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, None),
-    "cmask+sums": lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums),
+    "plain": (lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img), binding.STAGE_PIPELINE, m_full),
+    "cmask": (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, None), binding.STAGE_PIPELINE, m_full),
+    "fwd": (lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, None, None, d_fd), binding.STAGE_FFT, m_fwd),
+    "fwd+ap": (lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, d_amp, d_ph, d_fd), binding.STAGE_FFT, 4 * nt + 16 * nf),
+    "inv": (lambda: eng.ifft(npix, d_fft, d_post, d_out, d_img), binding.STAGE_IFFT, m_inv),
 }
 only = os.environ.get("THZ_VT_ONLY")
 if only:
@@ -34,19 +35,17 @@ if only:
 res = {}
 eng.enable_timing(2)
 for r in range(rounds + 1):
-    for name, fn in variants.items():
+    for name, (fn, stage, _) in variants.items():
         for bar in bars:
             os.environ["THZ_F_BAR"] = str(bar)
             for _ in range(3):
                 fn()
             eng.sync()
-            ns, calls = eng.timing_collect(binding.STAGE_PIPELINE)
-            eng.timing_collect(binding.STAGE_MEAN)
+            ns, calls = eng.timing_collect(stage)
             if r:
                 res.setdefault((name, bar), []).append(ns / calls * 1e-6)
-m_full = 16 * nt + 20
-print(f"{nx}x{ny}x{nt}  {eng.kernel_variant()}  M_full = {m_full} B/trace; kernel time only (hipEvents around the launch)")
+print(f"{nx}x{ny}x{nt}  {eng.kernel_variant()}  kernel time only (hipEvents around the launch); bytes = algorithmic bytes of each variant")
 for (name, bar), v in res.items():
-    v = np.array(v); med = float(np.median(v))
-    print(f"{name:11s} bar={bar}  median {med:7.3f} ms  min {v.min():7.3f}  {npix * m_full / med / 1e6:7.1f} GB/s  frac {npix * m_full / med / 1e6 / 8000:.4f}", flush=True)
+    v = np.array(v); med = float(np.median(v)); mb = variants[name][2]
+    print(f"{name:8s} bar={bar}  median {med:7.3f} ms  min {v.min():7.3f}  {npix * mb / med / 1e6:7.1f} GB/s  frac {npix * mb / med / 1e6 / 8000:.4f}", flush=True)
 eng.close()

@@ -1,0 +1,111 @@
+"""thz_group / thz_group_session (include/thzgpu.h, "Multi-GPU"): x-slab tiles inside the library.
+
+A one-GPU box cannot hold two RCCL ranks (RCCL refuses two ranks on one device), so these tests run the
+group in its same-device form — n members on device 0, collectives as device-local copies — which exercises
+everything except the fabric: the slab rule, per-slab sessions, C2 (sum of the slabs' pixel sums), C1 (gather
+in rank order), the three gather levels.  The RCCL calls themselves are covered by the driver's multi-GPU
+bench (bench.py --gpus N goes through the same entry points)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+import thz_image_explorer_amd as pkg
+from test_gpu_parity import TOL, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("members", [1, 2, 3])
+def test_group_collectives_same_device(members):
+    with pkg.Group(devices=[0] * members) as g:
+        assert g.world == members and g.ranks == list(range(members))
+        engs = [g.engine(i) for i in range(members)]
+        rng = np.random.default_rng(members)
+        vals = [rng.standard_normal(1000).astype(np.float32) for _ in range(members)]
+        bufs = [e.to_device(v) for e, v in zip(engs, vals)]
+        g.all_reduce_sum(bufs, 1000)
+        g.sync()
+        want = vals[0].copy()
+        for v in vals[1:]:
+            want = want + v          # the same left-to-right f32 adds
+        for b in bufs:
+            assert np.array_equal(b.download((1000,), np.float32), want)
+        h = [np.arange(16, dtype=np.uint64) * (i + 1) + (1 << 40) for i in range(members)]
+        hb = [e.to_device(v) for e, v in zip(engs, h)]
+        g.all_reduce_u64(hb, 16)
+        g.sync()
+        assert np.array_equal(hb[-1].download((16,), np.uint64), sum(h))
+        counts = [5 + 3 * i for i in range(members)]
+        send = [e.to_device(np.full(c, i + 1, np.float32)) for i, (e, c) in enumerate(zip(engs, counts))]
+        recv = engs[0].empty((sum(counts),))
+        g.gather(send, counts, recv)
+        g.sync()
+        assert np.array_equal(recv.download((sum(counts),), np.float32),
+                              np.concatenate([np.full(c, i + 1, np.float32) for i, c in enumerate(counts)]))
+        for b in bufs + hb + send + [recv]:
+            b.free()
+
+
+@pytest.mark.parametrize("shape,members", [((7, 6, 1024), 2), ((9, 4, 4096), 3), ((5, 8, 1001), 2), ((4, 4, 256), 1)])
+def test_group_session_matches_single_session(engine, shape, members):
+    """slabs recomputed side by side + C2 + C1 == one session over the whole cube: per-pixel outputs bit for bit
+    (the same kernels on the same traces), pixel means to 1e-6 (sums associate differently), all gather levels"""
+    nx, ny, nt = shape
+    time, cube = synth.make_cube(nx, ny, nt)
+    cfg = pkg.chain_cfg_default(time)
+    single = pkg.Session(engine, nx, ny, time)
+    try:
+        single.upload(cube, subtract_bias=False)
+        single.recompute(cfg)
+        want = {w: single.download(w) for w in (pkg.BUF_IMG, pkg.BUF_DATA, pkg.BUF_FFT, pkg.BUF_AMPLITUDES, pkg.BUF_PHASES,
+                                                pkg.BUF_AVG_FFT, pkg.BUF_AVG_AMPLITUDES, pkg.BUF_AVG_PHASES)}
+    finally:
+        single.close()
+    with pkg.Group(devices=[0] * members) as g:
+        for q in range(members):
+            assert pkg.host_slab(nx, members, q) == __import__("thz_image_explorer_amd.shard", fromlist=["slab"]).slab(nx, members, q)
+        gs = pkg.GroupSession(g, nx, ny, time)
+        try:
+            gs.upload(cube, subtract_bias=False)
+            for level, bufs in ((pkg.GATHER_SMALL, (pkg.BUF_IMG,)), (pkg.GATHER_TIME, (pkg.BUF_IMG, pkg.BUF_DATA)),
+                                (pkg.GATHER_ALL, (pkg.BUF_IMG, pkg.BUF_DATA, pkg.BUF_FFT, pkg.BUF_AMPLITUDES, pkg.BUF_PHASES))):
+                gs.recompute(cfg, 1, level)
+                for w in bufs:
+                    assert np.array_equal(gs.download(w), want[w]), f"gather level {level}, buffer {w}"
+                for w in (pkg.BUF_DATA, pkg.BUF_FFT):
+                    if w not in bufs:
+                        with pytest.raises(pkg.ThzError):
+                            gs.download(w)
+                for w in (pkg.BUF_AVG_FFT, pkg.BUF_AVG_AMPLITUDES, pkg.BUF_AVG_PHASES):
+                    assert rel(gs.download(w), want[w]) < 2e-6
+            # a Time Band Pass (after) slider: chain position 7 only re-runs the tail on every slab
+            cfg2 = pkg.chain_cfg_default(time)
+            cfg2.td_after_low = float(time[0]) + 3.0
+            gs.recompute(cfg2, 7, pkg.GATHER_TIME)
+            ref = ob.run_pipeline(cube, time, synth.oracle_chain(time))
+            w2 = ob.td_bandpass_window(time, cfg2.td_after_low, cfg2.td_after_high, cfg2.td_after_width)[0]
+            w1 = synth.oracle_chain(time)["w_post"]
+            sel = w1 == 1.0       # where the default taper is 1 the new result is ref * w2
+            got = gs.download(pkg.BUF_DATA).reshape(nx, ny, nt)
+            assert rel(got[..., sel], (ref["data"] * w2)[..., sel], np.abs(ref["data"]).max()) < TOL
+        finally:
+            gs.close()
+
+
+def test_group_session_refuses_what_does_not_shard():
+    time, cube = synth.make_cube(4, 4, 256)
+    with pkg.Group(devices=[0, 0]) as g:
+        gs = pkg.GroupSession(g, 4, 4, time)
+        try:
+            gs.upload(cube, subtract_bias=False)
+            for field, val in (("scale_factor", 2), ("tilt_x_deg", 3.0), ("want_means", 2)):
+                cfg = pkg.chain_cfg_default(time)
+                setattr(cfg, field, val)
+                with pytest.raises(pkg.ThzError) as e:
+                    gs.recompute(cfg)
+                assert e.value.code == -2
+        finally:
+            gs.close()
+    with pytest.raises(pkg.ThzError):
+        pkg.Group(devices=[0, 0, 1])   # neither all the same nor all distinct

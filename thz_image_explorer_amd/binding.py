@@ -179,6 +179,27 @@ SYMBOLS = [
     ("thz_session_time_out", C.c_int, [_P, _P]),
     ("thz_session_buffer", _P, [_P, C.c_int]),
     ("thz_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
+    ("thz_host_slab", C.c_int, [_SZ, C.c_int, C.c_int, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    ("thz_group_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    ("thz_group_unique_id", C.c_int, [_P]),
+    ("thz_group_create_rank", C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    ("thz_group_destroy", None, [_P]),
+    ("thz_group_last_error", C.c_char_p, [_P]),
+    ("thz_group_world", C.c_int, [_P]),
+    ("thz_group_local_count", C.c_int, [_P]),
+    ("thz_group_rank", C.c_int, [_P, C.c_int]),
+    ("thz_group_ctx", _P, [_P, C.c_int]),
+    ("thz_group_all_reduce_sum", C.c_int, [_P, C.POINTER(_P), _SZ]),
+    ("thz_group_all_reduce_u64", C.c_int, [_P, C.POINTER(_P), _SZ]),
+    ("thz_group_gather", C.c_int, [_P, C.POINTER(_P), C.POINTER(_SZ), _P]),
+    ("thz_group_sync", C.c_int, [_P]),
+    ("thz_group_session_create", C.c_int, [_P, _SZ, _SZ, _SZ, _P, C.c_float, C.c_float, C.POINTER(_P)]),
+    ("thz_group_session_destroy", None, [_P]),
+    ("thz_group_session_member", _P, [_P, C.c_int]),
+    ("thz_group_session_upload", C.c_int, [_P, _P, C.c_int]),
+    ("thz_group_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg), C.c_int, C.c_int]),
+    ("thz_group_session_result", _P, [_P, C.c_int]),
+    ("thz_group_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
     ("thz_session_voxels", C.c_int, [_P, C.POINTER(VoxelCfg), C.c_uint64, C.c_int, _SZ, _SZ, _SZ, _P, C.c_uint64,
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_float), _P]),
@@ -476,6 +497,126 @@ class Session:
             pix0, npix = 0, 1
         self.eng._check(self.eng.lib.thz_session_download(self.h, which, pix0, npix, out.ctypes.data))
         return out
+
+
+GATHER_SMALL, GATHER_TIME, GATHER_ALL = range(3)
+GROUP_ID_BYTES = 128
+
+
+def host_slab(nx: int, world: int, rank: int):
+    """(x0, n) rows of `rank`: the x-slab partition of include/thzgpu.h (thz_host_slab)"""
+    x0, n = _SZ(), _SZ()
+    _rc(load_library().thz_host_slab(nx, world, rank, C.byref(x0), C.byref(n)), "host_slab")
+    return x0.value, n.value
+
+
+def group_unique_id() -> bytes:
+    buf = C.create_string_buffer(GROUP_ID_BYTES)
+    _rc(load_library().thz_group_unique_id(buf), "group_unique_id")
+    return buf.raw
+
+
+class Group:
+    """thz_group: the members of a multi-GPU tiling driven by this process.  Group(devices=[0, 1, ...]) is one
+    process over n devices; Group(device=d, rank=r, world=w, uid=...) one member of a process-per-GPU launch."""
+
+    def __init__(self, devices=None, device=None, rank=0, world=1, uid=None):
+        self.lib = load_library()
+        self.h = _P()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.thz_group_create(arr, len(devices), C.byref(self.h))
+        else:
+            rc = self.lib.thz_group_create_rank(device, rank, world, uid, C.byref(self.h))
+        if rc != THZ_OK:
+            raise ThzError(rc, "thz_group_create failed (no HIP device, RCCL missing, or a bad device list)")
+        self.world = self.lib.thz_group_world(self.h)
+        self.ranks = [self.lib.thz_group_rank(self.h, i) for i in range(self.lib.thz_group_local_count(self.h))]
+
+    def _check(self, rc):
+        if rc != THZ_OK:
+            raise ThzError(rc, self.lib.thz_group_last_error(self.h).decode())
+
+    def engine(self, i: int) -> "Engine":
+        """Engine view of local member i's context (owned by the group: do not close it)"""
+        e = Engine.__new__(Engine)
+        e.lib, e.ctx, e._bufs = self.lib, _P(self.lib.thz_group_ctx(self.h, i)), []
+        return e
+
+    def all_reduce_sum(self, bufs, count):
+        arr = (_P * len(bufs))(*[_dp(b) for b in bufs])
+        self._check(self.lib.thz_group_all_reduce_sum(self.h, arr, count))
+
+    def all_reduce_u64(self, bufs, count):
+        arr = (_P * len(bufs))(*[_dp(b) for b in bufs])
+        self._check(self.lib.thz_group_all_reduce_u64(self.h, arr, count))
+
+    def gather(self, send, counts, recv_root):
+        arr = (_P * len(send))(*[_dp(b) for b in send])
+        cnt = (_SZ * len(counts))(*counts)
+        self._check(self.lib.thz_group_gather(self.h, arr, cnt, _dp(recv_root)))
+
+    def sync(self):
+        self._check(self.lib.thz_group_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.thz_group_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class GroupSession:
+    """thz_group_session: one x-slab session per member, C2 / C1 inside the library"""
+
+    def __init__(self, group: Group, nx, ny, time, dx=1.0, dy=1.0):
+        self.g, self.nx, self.ny = group, nx, ny
+        t = np.ascontiguousarray(time, np.float32)
+        self.nt = t.size
+        self.h = _P()
+        group._check(group.lib.thz_group_session_create(group.h, nx, ny, t.size, t.ctypes.data, dx, dy, C.byref(self.h)))
+
+    def member(self, i) -> "Session":
+        """Session view of local member i's slab session (owned by the group session: do not close it)"""
+        s = Session.__new__(Session)
+        x0, n = host_slab(self.nx, self.g.world, self.g.ranks[i])
+        s.eng, s.nx, s.ny, s.nt = self.g.engine(i), n, self.ny, self.nt
+        s.h = _P(self.g.lib.thz_group_session_member(self.h, i))
+        return s
+
+    def member_buffer(self, i, which) -> int:
+        """device pointer of a buffer of local member i's slab session"""
+        return self.g.lib.thz_session_buffer(_P(self.g.lib.thz_group_session_member(self.h, i)), which) or 0
+
+    def upload(self, cube=None, subtract_bias=True):
+        c = None if cube is None else np.ascontiguousarray(cube, np.float32)
+        self.g._check(self.g.lib.thz_group_session_upload(self.h, c.ctypes.data if c is not None else None, int(subtract_bias)))
+
+    def recompute(self, cfg: ChainCfg, start_stage=1, gather=GATHER_SMALL):
+        self.g._check(self.g.lib.thz_group_session_recompute(self.h, C.byref(cfg), int(start_stage), int(gather)))
+
+    def download(self, which, nt_out=None):
+        """gathered buffer of rank 0 (whole grid) or a pixel-mean vector"""
+        nto = self.nt if nt_out is None else nt_out
+        nf = nto // 2 + 1
+        per = {BUF_FFT: (nf, 2), BUF_AMPLITUDES: (nf,), BUF_PHASES: (nf,), BUF_DATA: (nto,), BUF_IMG: ()}
+        if which in per:
+            out = np.empty((self.nx * self.ny,) + per[which], np.float32)
+            self.g._check(self.g.lib.thz_group_session_download(self.h, which, 0, self.nx * self.ny, out.ctypes.data))
+        else:
+            out = np.empty((nf, 2) if which == BUF_AVG_FFT else (nf,), np.float32)
+            self.g._check(self.g.lib.thz_group_session_download(self.h, which, 0, 1, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h:
+            self.g.lib.thz_group_session_destroy(self.h)
+            self.h = None
 
 
 class DevBuf:

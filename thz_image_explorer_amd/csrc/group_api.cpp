@@ -1,0 +1,519 @@
+// group_api.cpp — x-slab tiles of one cube over the GPUs of a node (include/thzgpu.h, "Multi-GPU"
+// section): member contexts, the two exchange steps of the path as RCCL calls on the members' own
+// streams, and a session whose slabs are recomputed side by side.
+//
+// librccl is opened with dlopen when a group with more than one device is created, so the library
+// has no load-time dependency on it (a single-GPU user never maps its 570 MB).  The function
+// prototypes come from <rccl/rccl.h>; only the symbols are looked up at run time.
+#include "session.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace thz;
+
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    std::string err;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    return r;
+}
+
+bool rccl_load()
+{
+    Rccl &r = rccl();
+    if (r.h) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.h) break;
+    }
+    if (!r.h) {
+        r.err = std::string("cannot open librccl: ") + dlerror();
+        return false;
+    }
+#define THZ_SYM(field, sym)                                                  \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, #sym));         \
+    if (!r.field) {                                                          \
+        r.err = "librccl lacks " #sym;                                       \
+        dlclose(r.h);                                                        \
+        r.h = nullptr;                                                       \
+        return false;                                                        \
+    }
+    THZ_SYM(GetUniqueId, ncclGetUniqueId)
+    THZ_SYM(CommInitRank, ncclCommInitRank)
+    THZ_SYM(CommInitAll, ncclCommInitAll)
+    THZ_SYM(CommDestroy, ncclCommDestroy)
+    THZ_SYM(GetErrorString, ncclGetErrorString)
+    THZ_SYM(AllReduce, ncclAllReduce)
+    THZ_SYM(Send, ncclSend)
+    THZ_SYM(Recv, ncclRecv)
+    THZ_SYM(GroupStart, ncclGroupStart)
+    THZ_SYM(GroupEnd, ncclGroupEnd)
+#undef THZ_SYM
+    return true;
+}
+
+}  // namespace
+
+struct thz_group {
+    struct Member {
+        thz_ctx *ctx = nullptr;
+        int rank = 0;
+        ncclComm_t comm = nullptr;
+        hipEvent_t ev = nullptr;  // same-device groups: orders the members' streams around a collective
+    };
+    std::vector<Member> m;
+    int world = 0;
+    bool same_device = false;  // one process, every member on one device: no fabric, device-local copies
+    std::string err;
+};
+
+struct thz_group_session {
+    thz_group *g = nullptr;
+    size_t nx = 0, ny = 0, nt = 0;
+    std::vector<thz_session *> sess;   // one per local member
+    std::vector<size_t> x0, rows;      // one per rank
+    int root_local = -1;               // index of rank 0 among the local members, -1: another process has it
+    // gathered copies on rank 0's device, allocated when first asked for
+    float *d_img = nullptr, *d_data = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr;
+    size_t nt_out = 0;
+    int gathered = -1;  // thz_gather level of the last recompute
+};
+
+namespace {
+
+int gfail(thz_group *g, int code, const std::string &msg)
+{
+    if (g) g->err = msg;
+    return code;
+}
+
+#define NCCL_TRY(g, expr)                                                                            \
+    do {                                                                                             \
+        ncclResult_t r_ = (expr);                                                                    \
+        if (r_ != ncclSuccess) return gfail(g, THZ_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+#define GHIP_TRY(g, expr)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return gfail(g, THZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// same-device groups: stream 0 waits for everything the other members have enqueued ...
+int join_on_first(thz_group *g)
+{
+    for (size_t i = 1; i < g->m.size(); ++i) {
+        GHIP_TRY(g, hipEventRecord(g->m[i].ev, g->m[i].ctx->stream));
+        GHIP_TRY(g, hipStreamWaitEvent(g->m[0].ctx->stream, g->m[i].ev, 0));
+    }
+    return THZ_OK;
+}
+// ... and the others wait for what stream 0 did meanwhile
+int fan_out_from_first(thz_group *g)
+{
+    GHIP_TRY(g, hipEventRecord(g->m[0].ev, g->m[0].ctx->stream));
+    for (size_t i = 1; i < g->m.size(); ++i) GHIP_TRY(g, hipStreamWaitEvent(g->m[i].ctx->stream, g->m[0].ev, 0));
+    return THZ_OK;
+}
+
+template <class T>
+int all_reduce(thz_group *g, T *const *d_bufs, size_t count, ncclDataType_t type)
+{
+    if (!g || !d_bufs) return THZ_ERR_INVALID;
+    if (count == 0 || g->world == 1) return THZ_OK;
+    for (size_t i = 0; i < g->m.size(); ++i)
+        if (!d_bufs[i]) return gfail(g, THZ_ERR_INVALID, "all-reduce: null buffer");
+    if (g->same_device) {
+        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
+        if (int rc = join_on_first(g)) return rc;
+        hipStream_t st = g->m[0].ctx->stream;
+        for (size_t i = 1; i < g->m.size(); ++i) {
+            if constexpr (sizeof(T) == 4) launch_add_vec(st, (float *)d_bufs[0], (const float *)d_bufs[i], count);
+            else launch_add_u64(st, (unsigned long long *)d_bufs[0], (const unsigned long long *)d_bufs[i], count);
+        }
+        GHIP_TRY(g, hipGetLastError());
+        for (size_t i = 1; i < g->m.size(); ++i)
+            GHIP_TRY(g, hipMemcpyAsync(d_bufs[i], d_bufs[0], count * sizeof(T), hipMemcpyDeviceToDevice, st));
+        return fan_out_from_first(g);
+    }
+    Rccl &r = rccl();
+    NCCL_TRY(g, r.GroupStart());
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        ncclResult_t rc = r.AllReduce(d_bufs[i], d_bufs[i], count, type, ncclSum, g->m[i].comm, g->m[i].ctx->stream);
+        if (rc != ncclSuccess) {
+            (void)r.GroupEnd();
+            return gfail(g, THZ_ERR_HIP, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+        }
+    }
+    NCCL_TRY(g, r.GroupEnd());
+    return THZ_OK;
+}
+
+int make_member(thz_group *g, int device, int rank)
+{
+    thz_group::Member mb;
+    if (int rc = thz_create(device, &mb.ctx)) return gfail(g, rc, "thz_create(" + std::to_string(device) + ") failed");
+    mb.rank = rank;
+    if (hipEventCreateWithFlags(&mb.ev, hipEventDisableTiming) != hipSuccess) {
+        thz_destroy(mb.ctx);
+        return gfail(g, THZ_ERR_HIP, "hipEventCreate failed");
+    }
+    g->m.push_back(mb);
+    return THZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thz_host_slab(size_t nx, int world, int rank, size_t *x0, size_t *n)
+{
+    if (world < 1 || rank < 0 || rank >= world) return THZ_ERR_INVALID;
+    const size_t base = nx / (size_t)world, rem = nx % (size_t)world, r = (size_t)rank;
+    if (n) *n = base + (r < rem ? 1 : 0);
+    if (x0) *x0 = r * base + (r < rem ? r : rem);
+    return THZ_OK;
+}
+
+const char *thz_group_last_error(const thz_group *g) { return g ? g->err.c_str() : "null group"; }
+int thz_group_world(const thz_group *g) { return g ? g->world : 0; }
+int thz_group_local_count(const thz_group *g) { return g ? (int)g->m.size() : 0; }
+int thz_group_rank(const thz_group *g, int i) { return (g && i >= 0 && i < (int)g->m.size()) ? g->m[i].rank : -1; }
+thz_ctx *thz_group_ctx(thz_group *g, int i) { return (g && i >= 0 && i < (int)g->m.size()) ? g->m[i].ctx : nullptr; }
+
+void thz_group_destroy(thz_group *g)
+{
+    if (!g) return;
+    for (auto &mb : g->m) {
+        if (mb.ctx) {
+            (void)hipSetDevice(mb.ctx->device);
+            (void)hipStreamSynchronize(mb.ctx->stream);
+        }
+        if (mb.comm) (void)rccl().CommDestroy(mb.comm);
+        if (mb.ev) (void)hipEventDestroy(mb.ev);
+        if (mb.ctx) thz_destroy(mb.ctx);
+    }
+    delete g;
+}
+
+int thz_group_create(const int *devices, int n, thz_group **out)
+{
+    if (!out || !devices || n < 1) return THZ_ERR_INVALID;
+    *out = nullptr;
+    bool all_same = true, distinct = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            if (devices[i] == devices[j]) distinct = false;
+            else all_same = false;
+        }
+    if (n > 1 && !all_same && !distinct) return THZ_ERR_INVALID;
+    thz_group *g = new thz_group();
+    g->world = n;
+    g->same_device = n > 1 && all_same;
+    for (int i = 0; i < n; ++i)
+        if (int rc = make_member(g, devices[i], i)) {
+            thz_group_destroy(g);
+            return rc;
+        }
+    if (n > 1 && distinct) {
+        if (!rccl_load()) {
+            thz_group_destroy(g);
+            return THZ_ERR_HIP;
+        }
+        std::vector<ncclComm_t> comms((size_t)n);
+        const ncclResult_t rc = rccl().CommInitAll(comms.data(), n, devices);
+        if (rc != ncclSuccess) {
+            thz_group_destroy(g);
+            return THZ_ERR_HIP;
+        }
+        for (int i = 0; i < n; ++i) g->m[(size_t)i].comm = comms[(size_t)i];
+    }
+    *out = g;
+    return THZ_OK;
+}
+
+int thz_group_unique_id(void *id)
+{
+    if (!id) return THZ_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == THZ_GROUP_ID_BYTES, "THZ_GROUP_ID_BYTES");
+    if (!rccl_load()) return THZ_ERR_HIP;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return THZ_ERR_HIP;
+    std::memcpy(id, &u, sizeof u);
+    return THZ_OK;
+}
+
+int thz_group_create_rank(int device, int rank, int world, const void *id, thz_group **out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return THZ_ERR_INVALID;
+    *out = nullptr;
+    thz_group *g = new thz_group();
+    g->world = world;
+    if (int rc = make_member(g, device, rank)) {
+        thz_group_destroy(g);
+        return rc;
+    }
+    if (world > 1) {
+        if (!rccl_load()) {
+            thz_group_destroy(g);
+            return THZ_ERR_HIP;
+        }
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof u);
+        if (hipSetDevice(device) != hipSuccess || rccl().CommInitRank(&g->m[0].comm, world, u, rank) != ncclSuccess) {
+            g->m[0].comm = nullptr;
+            thz_group_destroy(g);
+            return THZ_ERR_HIP;
+        }
+    }
+    *out = g;
+    return THZ_OK;
+}
+
+int thz_group_all_reduce_sum(thz_group *g, float *const *d_bufs, size_t count) { return all_reduce<float>(g, d_bufs, count, ncclFloat); }
+int thz_group_all_reduce_u64(thz_group *g, uint64_t *const *d_bufs, size_t count) { return all_reduce<uint64_t>(g, d_bufs, count, ncclUint64); }
+
+int thz_group_gather(thz_group *g, const float *const *d_send, const size_t *counts, float *d_recv_root)
+{
+    if (!g || !d_send || !counts) return THZ_ERR_INVALID;
+    std::vector<size_t> off((size_t)g->world + 1, 0);
+    for (int q = 0; q < g->world; ++q) off[(size_t)q + 1] = off[(size_t)q] + counts[q];
+    int root = -1;
+    for (size_t i = 0; i < g->m.size(); ++i)
+        if (g->m[i].rank == 0) root = (int)i;
+    if (root >= 0 && !d_recv_root) return gfail(g, THZ_ERR_INVALID, "gather: rank 0 needs a receive buffer");
+    if (g->same_device) {
+        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
+        if (int rc = join_on_first(g)) return rc;
+        for (size_t i = 0; i < g->m.size(); ++i) {
+            const size_t q = (size_t)g->m[i].rank;
+            if (counts[q] && d_recv_root + off[q] != d_send[i])
+                GHIP_TRY(g, hipMemcpyAsync(d_recv_root + off[q], d_send[i], counts[q] * sizeof(float), hipMemcpyDeviceToDevice,
+                                           g->m[0].ctx->stream));
+        }
+        return fan_out_from_first(g);
+    }
+    if (root >= 0 && counts[0] && d_recv_root != d_send[root]) {  // rank 0's own rows: a device-local copy
+        GHIP_TRY(g, hipSetDevice(g->m[(size_t)root].ctx->device));
+        GHIP_TRY(g, hipMemcpyAsync(d_recv_root, d_send[root], counts[0] * sizeof(float), hipMemcpyDeviceToDevice,
+                                   g->m[(size_t)root].ctx->stream));
+    }
+    if (g->world == 1) return THZ_OK;
+    Rccl &r = rccl();
+    NCCL_TRY(g, r.GroupStart());
+    ncclResult_t rc = ncclSuccess;
+    for (size_t i = 0; i < g->m.size() && rc == ncclSuccess; ++i) {
+        const size_t q = (size_t)g->m[i].rank;
+        if (q != 0 && counts[q]) rc = r.Send(d_send[i], counts[q], ncclFloat, 0, g->m[i].comm, g->m[i].ctx->stream);
+    }
+    if (root >= 0)
+        for (int q = 1; q < g->world && rc == ncclSuccess; ++q)
+            if (counts[q])
+                rc = r.Recv(d_recv_root + off[(size_t)q], counts[q], ncclFloat, q, g->m[(size_t)root].comm, g->m[(size_t)root].ctx->stream);
+    if (rc != ncclSuccess) {
+        (void)r.GroupEnd();
+        return gfail(g, THZ_ERR_HIP, std::string("ncclSend / ncclRecv: ") + r.GetErrorString(rc));
+    }
+    NCCL_TRY(g, r.GroupEnd());
+    return THZ_OK;
+}
+
+int thz_group_sync(thz_group *g)
+{
+    if (!g) return THZ_ERR_INVALID;
+    for (auto &mb : g->m) {
+        GHIP_TRY(g, hipSetDevice(mb.ctx->device));
+        GHIP_TRY(g, hipStreamSynchronize(mb.ctx->stream));
+    }
+    return THZ_OK;
+}
+
+/* ------------------------------------------------------------------ group session */
+
+void thz_group_session_destroy(thz_group_session *gs)
+{
+    if (!gs) return;
+    for (thz_session *s : gs->sess) thz_session_destroy(s);
+    if (gs->root_local >= 0) {
+        (void)hipSetDevice(gs->g->m[(size_t)gs->root_local].ctx->device);
+        for (float *p : {gs->d_img, gs->d_data, gs->d_fft, gs->d_amp, gs->d_ph})
+            if (p) (void)hipFree(p);
+    }
+    delete gs;
+}
+
+int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, const float *time, float dx, float dy,
+                             thz_group_session **out)
+{
+    if (!g || !out || !time || ny == 0 || nt < 2) return THZ_ERR_INVALID;
+    *out = nullptr;
+    if (nx < (size_t)g->world) return gfail(g, THZ_ERR_INVALID, "fewer x rows than ranks: every slab needs at least one row");
+    thz_group_session *gs = new thz_group_session();
+    gs->g = g; gs->nx = nx; gs->ny = ny; gs->nt = nt; gs->nt_out = nt;
+    gs->x0.resize((size_t)g->world);
+    gs->rows.resize((size_t)g->world);
+    for (int q = 0; q < g->world; ++q) (void)thz_host_slab(nx, g->world, q, &gs->x0[(size_t)q], &gs->rows[(size_t)q]);
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        thz_session *s = nullptr;
+        const int rc = thz_session_create(g->m[i].ctx, gs->rows[(size_t)g->m[i].rank], ny, nt, time, dx, dy, &s);
+        if (rc) {
+            gfail(g, rc, std::string("slab session: ") + thz_last_error(g->m[i].ctx));
+            thz_group_session_destroy(gs);
+            return rc;
+        }
+        gs->sess.push_back(s);
+        if (g->m[i].rank == 0) gs->root_local = (int)i;
+    }
+    if (gs->root_local >= 0) {
+        if (hipSetDevice(g->m[(size_t)gs->root_local].ctx->device) != hipSuccess
+            || hipMalloc((void **)&gs->d_img, nx * ny * sizeof(float)) != hipSuccess) {
+            gfail(g, THZ_ERR_HIP, "gathered image: allocation failed");
+            thz_group_session_destroy(gs);
+            return THZ_ERR_HIP;
+        }
+    }
+    *out = gs;
+    return THZ_OK;
+}
+
+thz_session *thz_group_session_member(thz_group_session *gs, int i)
+{
+    return (gs && i >= 0 && i < (int)gs->sess.size()) ? gs->sess[(size_t)i] : nullptr;
+}
+
+int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtract_bias)
+{
+    if (!gs) return THZ_ERR_INVALID;
+    thz_group *g = gs->g;
+    std::vector<float *> sums;
+    for (size_t i = 0; i < gs->sess.size(); ++i) {
+        const size_t q = (size_t)g->m[i].rank;
+        const int rc = thz_session_upload(gs->sess[i], cube ? cube + gs->x0[q] * gs->ny * gs->nt : nullptr, subtract_bias);
+        if (rc) return gfail(g, rc, std::string("slab upload: ") + thz_last_error(g->m[i].ctx));
+        sums.push_back(gs->sess[i]->d_rawsum);
+    }
+    // the slabs' raw pixel sums become the cube's: avg_fft of every later recompute follows from them
+    if (int rc = thz_group_all_reduce_sum(g, sums.data(), gs->nt)) return rc;
+    gs->gathered = -1;
+    return thz_group_sync(g);
+}
+
+int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg, int start_stage, int gather)
+{
+    if (!gs || !cfg) return THZ_ERR_INVALID;
+    thz_group *g = gs->g;
+    if (gather < THZ_GATHER_SMALL || gather > THZ_GATHER_ALL || start_stage < 0 || start_stage > 8)
+        return gfail(g, THZ_ERR_INVALID, "thz_group_session_recompute: bad gather level or chain position");
+    if (cfg->scale_factor > 1 || (cfg->tilt_active && (cfg->tilt_x_deg != 0.0 || cfg->tilt_y_deg != 0.0)) || cfg->want_means > 1)
+        return gfail(g, THZ_ERR_UNSUPPORTED,
+                     "a group session shards without a halo only: scale_factor 1, zero tilt, want_means 0 or 1 "
+                     "(block means and the tilt's per-pixel shift depend on the position in the whole grid; "
+                     "the reference-order means are sequential over all x rows)");
+    if (start_stage == 8) return THZ_OK;
+    // every slab's chain, enqueued side by side on the members' streams
+    std::vector<char> tail(gs->sess.size(), 0);
+    for (size_t i = 0; i < gs->sess.size(); ++i) {
+        bool t = false;
+        const int rc = session_enqueue(gs->sess[i], cfg, start_stage, &t);
+        if (rc) return gfail(g, rc, std::string("slab recompute: ") + thz_last_error(g->m[i].ctx));
+        tail[i] = t ? 1 : 0;
+    }
+    const size_t nt_out = gs->sess.empty() ? gs->nt : gs->sess[0]->nt_out, nf = nt_out / 2 + 1;
+    gs->nt_out = nt_out;
+    // C2: the slabs' undivided amplitude / phase sums -> the cube's, on every member
+    if (cfg->want_means && !(tail.size() && tail[0])) {
+        std::vector<float *> bufs;
+        for (thz_session *s : gs->sess) {
+            if (!s->msum_fast) return gfail(g, THZ_ERR_UNSUPPORTED, "slab means are not additive for this configuration");
+            bufs.push_back(s->d_msum + nt_out);
+        }
+        if (int rc = thz_group_all_reduce_sum(g, bufs.data(), 2 * nf)) return rc;
+        for (size_t i = 0; i < gs->sess.size(); ++i) {
+            // Σ of the raw traces was all-reduced at upload; the copy in d_msum[0, nt) is already the cube's
+            const int rc = session_means(gs->sess[i], cfg, gs->nx * gs->ny);
+            if (rc) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[i].ctx));
+        }
+    }
+    // C1: per-pixel results to rank 0
+    auto gather_buf = [&](int which, size_t per_pix, float **d_dst) -> int {
+        std::vector<const float *> send;
+        std::vector<size_t> counts((size_t)g->world);
+        for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->rows[(size_t)q] * gs->ny * per_pix;
+        for (thz_session *s : gs->sess) send.push_back(static_cast<const float *>(thz_session_buffer(s, which)));
+        if (gs->root_local >= 0 && !*d_dst) {
+            GHIP_TRY(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
+            GHIP_TRY(g, hipMalloc((void **)d_dst, gs->nx * gs->ny * per_pix * sizeof(float)));
+        }
+        return thz_group_gather(g, send.data(), counts.data(), *d_dst);
+    };
+    if (int rc = gather_buf(THZ_BUF_IMG, 1, &gs->d_img)) return rc;
+    if (gather >= THZ_GATHER_TIME)
+        if (int rc = gather_buf(THZ_BUF_DATA, nt_out, &gs->d_data)) return rc;
+    if (gather >= THZ_GATHER_ALL) {
+        if (int rc = gather_buf(THZ_BUF_FFT, 2 * nf, &gs->d_fft)) return rc;
+        if (int rc = gather_buf(THZ_BUF_AMPLITUDES, nf, &gs->d_amp)) return rc;
+        if (int rc = gather_buf(THZ_BUF_PHASES, nf, &gs->d_ph)) return rc;
+    }
+    gs->gathered = gather;
+    return thz_group_sync(g);
+}
+
+void *thz_group_session_result(thz_group_session *gs, int which)
+{
+    if (!gs || gs->root_local < 0 || gs->gathered < 0) return nullptr;
+    switch (which) {
+    case THZ_BUF_IMG: return gs->d_img;
+    case THZ_BUF_DATA: return gs->gathered >= THZ_GATHER_TIME ? gs->d_data : nullptr;
+    case THZ_BUF_FFT: return gs->gathered >= THZ_GATHER_ALL ? gs->d_fft : nullptr;
+    case THZ_BUF_AMPLITUDES: return gs->gathered >= THZ_GATHER_ALL ? gs->d_amp : nullptr;
+    case THZ_BUF_PHASES: return gs->gathered >= THZ_GATHER_ALL ? gs->d_ph : nullptr;
+    case THZ_BUF_AVG_FFT: case THZ_BUF_AVG_AMPLITUDES: case THZ_BUF_AVG_PHASES:
+        return thz_session_buffer(gs->sess[(size_t)gs->root_local], which);
+    default: return nullptr;
+    }
+}
+
+int thz_group_session_download(thz_group_session *gs, int which, size_t pix0, size_t npix, void *dst)
+{
+    if (!gs || !dst) return THZ_ERR_INVALID;
+    thz_group *g = gs->g;
+    if (gs->root_local < 0) return gfail(g, THZ_ERR_NOT_READY, "this process does not drive rank 0");
+    thz_session *rs = gs->sess[(size_t)gs->root_local];
+    if (which == THZ_BUF_AVG_FFT || which == THZ_BUF_AVG_AMPLITUDES || which == THZ_BUF_AVG_PHASES)
+        return thz_session_download(rs, which, 0, 1, dst);
+    const float *base = static_cast<const float *>(thz_group_session_result(gs, which));
+    if (!base) return gfail(g, THZ_ERR_NOT_READY, "buffer was not gathered by the last recompute");
+    const size_t nf = gs->nt_out / 2 + 1;
+    size_t per = 0;
+    switch (which) {
+    case THZ_BUF_IMG: per = 1; break;
+    case THZ_BUF_DATA: per = gs->nt_out; break;
+    case THZ_BUF_FFT: per = 2 * nf; break;
+    case THZ_BUF_AMPLITUDES: case THZ_BUF_PHASES: per = nf; break;
+    default: return THZ_ERR_INVALID;
+    }
+    if (pix0 > gs->nx * gs->ny || npix > gs->nx * gs->ny - pix0) return gfail(g, THZ_ERR_INVALID, "pixel range out of bounds");
+    return thz_memcpy_d2h(g->m[(size_t)gs->root_local].ctx, dst, base + pix0 * per, npix * per * sizeof(float));
+}
+
+}  // extern "C"
