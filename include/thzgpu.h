@@ -98,10 +98,12 @@ int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes);
  * with the G kernels forced — thz_set_kernel_family(1) — any other 2..4096). */
 int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
 /* Kernel family selection: 0 = automatic (register-resident three-pass "F"
- * kernels for nt = 1024/2048/4096, chirp-z over the same core — "FB" kernels —
- * for the lengths that are not a power of two, LDS Stockham "G" kernels for the
- * remaining powers of two), 1 = G kernels (Stockham / Bluestein in LDS) for
- * every length (A/B measurements, tests).
+ * kernels for nt = 1024/2048/4096; mixed-radix "P" kernels for the lengths that
+ * factor into three small radices — nt = 1001 = 7 x 11 x 13, the length of the
+ * reference's real scans, and 1000; chirp-z over the F core — "FB" kernels —
+ * for the other lengths that are not a power of two; LDS Stockham "G" kernels
+ * for the remaining powers of two), 1 = G kernels (Stockham / Bluestein in LDS)
+ * for every length, 2 = automatic without the P kernels (A/B measurements, tests).
  * Re-plans if a time axis is already set. */
 int thz_set_kernel_family(thz_ctx *ctx, int family);
 size_t thz_nt(const thz_ctx *ctx);

@@ -7,6 +7,7 @@ from thz_image_explorer_amd import Engine
 import synth
 nx, ny, nt = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (512, 1024, 4096)))
 eng = Engine(0)
+eng.set_kernel_family(int(os.environ.get('THZ_FAMILY', '0')))
 tm = synth.make_time(nt); eng.set_time_axis(tm); nf = eng.nf
 chain = synth.default_chain(tm)
 npix = nx * ny

@@ -8,23 +8,25 @@ using namespace thz;
 
 namespace thz { extern int g_f_bar_override; }
 
-static int g_allow_f = 1;
+static int g_allow_f = 1, g_allow_p = 1;
 static std::vector<float> g_ones;
 static PlanDev make_plan(PlanHost &H)
 {
     g_ones.assign((size_t)H.nf, 1.0f);
     return plan_dev(H, H.tw.data(), H.tw_split.data(), H.chirp_conj.data(), H.bfft.data(),
                     H.f_t1.empty() ? nullptr : H.f_t1.data(), H.f_t2.empty() ? nullptr : H.f_t2.data(),
-                    H.f_w2n.empty() ? nullptr : H.f_w2n.data(), g_ones.data());
+                    H.f_w2n.empty() ? nullptr : H.f_w2n.data(), g_ones.data(), H.p_t1.empty() ? nullptr : H.p_t1.data(),
+                    H.p_t2.empty() ? nullptr : H.p_t2.data());
 }
 
 extern "C" {
 
 void emu_allow_f(int on) { g_allow_f = on; }
+void emu_allow_p(int on) { g_allow_p = on; }
 int emu_family(int nt)
 {
     PlanHost H;
-    if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
     return H.family;
 }
 
@@ -32,7 +34,7 @@ int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const flo
                 float *data_out, float *fft, float *amp, float *ph, const float *mask)
 {
     PlanHost H;
-    if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
     PlanDev D = make_plan(H);
     launch_fft_fwd(nullptr, D, npix, in, wa, wb, data_out, (c32 *)fft, amp, ph, mask);
     return 0;
@@ -41,7 +43,7 @@ int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const flo
 int emu_fft_inv(int nt, size_t npix, const float *fft, const float *win, float *out, float *img)
 {
     PlanHost H;
-    if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
     PlanDev D = make_plan(H);
     launch_fft_inv(nullptr, D, npix, (const c32 *)fft, win, out, img);
     return 0;
@@ -51,7 +53,7 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
                  const float *post, float *fft, float *amp, float *ph, float *out, float *img)
 {
     PlanHost H;
-    if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
     if (H.mode != kModePow2 && H.family < kFamilyFB) return -2;
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img);
@@ -65,7 +67,7 @@ int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, con
                     const float *post, float *fft, float *amp, float *ph, float *out, float *img)
 {
     PlanHost H;
-    if (!build_plan((size_t)nt, H, g_allow_f != 0)) return -2;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
     if (H.family != kFamilyF) return -2;
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask);

@@ -45,17 +45,22 @@ def _fwd(emu, x, wa, mask, nt):
     return dout, fft, amp, ph
 
 
-@pytest.mark.parametrize("family", ["auto", "g"])
-@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 30, 1500, 3000])
+@pytest.mark.parametrize("family", ["auto", "g", "nop"])
+@pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 1000, 30, 1500, 3000])
 def test_forward_inverse_vs_oracle(emu, nt, family):
-    emu.emu_allow_f(1 if family == "auto" else 0)
+    emu.emu_allow_f(0 if family == "g" else 1)
+    emu.emu_allow_p(1 if family == "auto" else 0)
     if family == "g" and nt not in (1024, 2048, 4096):
         pytest.skip("only one family exists for this length")
-    # auto: F for 1024/2048/4096, FB / FB2 / FB4 (chirp-z over the F core) for the other lengths
-    # below 4096 that are not a power of two
+    if family == "nop" and nt not in (1001, 1000):
+        pytest.skip("no P kernel for this length anyway")
+    # auto: F for 1024/2048/4096, P (mixed radix) for 1001 / 1000, FB / FB2 / FB4 (chirp-z over the F core) for
+    # the other lengths below 4096 that are not a power of two; nop: the same without the P kernels
     want = 0
-    if family == "auto":
+    if family != "g":
         want = 1 if nt in (1024, 2048, 4096) else ((2 if nt < 1024 else 3 if nt < 2048 else 4) if nt & (nt - 1) else 0)
+        if family == "auto" and nt in (1001, 1000):
+            want = 6
     assert emu.emu_family(nt) == want
     npix = 11  # > waves per block: exercises the grid-stride loop and a ragged last block
     rng = np.random.default_rng(nt)
@@ -82,6 +87,7 @@ def test_forward_inverse_vs_oracle(emu, nt, family):
     ref_t = back[0] * win
     assert np.abs(out - ref_t).max() / np.abs(ref_t).max() < 1e-5
     assert np.abs(img - (ref_t.astype(np.float64) ** 2).sum(1)).max() / img.max() < 1e-5
+    emu.emu_allow_p(1)
 
 
 @pytest.mark.parametrize("nt", [256, 1024, 2048, 4096])
@@ -110,6 +116,7 @@ def test_chirpz_pipeline_vs_oracle(emu, nt):
     """FB / FB2 kernels (fft_fb.hpp): non-power-of-two trace lengths, chirp-z over the F core
     (one core run per transform up to nt = 1023, two up to 2047, four up to 4095, eight up to 8191)"""
     emu.emu_allow_f(1)
+    emu.emu_allow_p(0)   # 1001 / 1000 have a mixed-radix kernel of their own (test_mixed_radix_pipeline_vs_oracle)
     assert emu.emu_family(nt) == (2 if nt < 1024 else 3 if nt < 2048 else 4 if nt < 4096 else 5)
     nx, ny = (5, 1) if nt % 2 else (2, 3)   # odd trace count: the last pair has one member
     time = synth.make_time(nt)
@@ -132,6 +139,39 @@ def test_chirpz_pipeline_vs_oracle(emu, nt):
     strong = st["amplitudes"] > 0.05 * st["amplitudes"].max(axis=-1, keepdims=True)
     d = ph.reshape(ref["phases"].shape).astype(np.float64) - ref["phases"]
     assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))[strong].max() < 3e-3
+
+
+@pytest.mark.parametrize("nt,npix_shape", [(1001, (5, 1)), (1001, (2, 3)), (1000, (5, 1)), (1000, (3, 6))])
+def test_mixed_radix_pipeline_vs_oracle(emu, nt, npix_shape):
+    """P kernels (fft_p.hpp): nt = 1001 = 7 x 11 x 13 (the length of real scans) and 1000 = 10 x 10 x 10 as one
+    direct three-pass mixed-radix transform per pair of traces; odd and even trace counts, more pairs than one
+    block has waves"""
+    emu.emu_allow_f(1)
+    emu.emu_allow_p(1)
+    assert emu.emu_family(nt) == 6
+    nx, ny = npix_shape
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) + 11, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()
+    chain = synth.default_chain(time)
+    npix, nf = nx * ny, nt // 2 + 1
+    fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+    ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+    rc = emu.emu_pipeline(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]),
+                          _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img))
+    assert rc == 0
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+    assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+    assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / max(np.abs(ref["data"]).max(), 1e-30) < 1e-5
+    assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / max(ref["img"].max(), 1e-30) < 1e-5
+    # unwrapped phases on the strong bins of the unmasked spectrum
+    st = ob.fft_stage((cube * chain["w_pre"]).astype(np.float32), time, 0, 0.0, 0.0)
+    strong = st["amplitudes"] > 0.05 * st["amplitudes"].max(axis=-1, keepdims=True)
+    d = ph.reshape(ref["phases"].shape).astype(np.float64) - ref["phases"]
+    assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))[strong].max() < 3e-3
+
+
 
 
 @pytest.mark.parametrize("nt", [1024, 4096])

@@ -593,10 +593,14 @@ def test_chirpz_fused_pipeline_lengths(engine, shape):
     nx, ny, nt = shape
     time = synth.make_time(nt)
     cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 320))[:, :nt].reshape(nx, ny, nt).copy()
-    engine.set_time_axis(time)
-    assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else ("fb2-" if nt < 2048 else "fb4-" if nt < 4096 else "fb8-"))
-    chain = synth.default_chain(time)
-    got = synth.run_gpu_pipeline(engine, cube, chain)
+    engine.set_kernel_family(2)   # without the mixed-radix kernels: 1000 has one (test_mixed_radix_fused_pipeline)
+    try:
+        engine.set_time_axis(time)
+        assert engine.kernel_variant().startswith("fb-bluestein" if nt < 1024 else ("fb2-" if nt < 2048 else "fb4-" if nt < 4096 else "fb8-"))
+        got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+    finally:
+        engine.set_kernel_family(0)
+    chain = synth.oracle_chain(time)
     ref = ob.run_pipeline(cube, time, chain)
     scale = np.abs(ref["fft"]).max()
     assert rel(got["fft"], ref["fft"], scale) < TOL
@@ -605,6 +609,45 @@ def test_chirpz_fused_pipeline_lengths(engine, shape):
     assert rel(got["img"], ref["img"]) < TOL
     st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
     assert phase_ok(got["phases"], ref["phases"], st["amplitudes"])
+
+
+@pytest.mark.parametrize("family", [0, 2])
+@pytest.mark.parametrize("shape", [(4, 4, 1001), (5, 1, 1001), (37, 19, 1001), (3, 3, 1000), (64, 33, 1000)])
+def test_mixed_radix_fused_pipeline(engine, shape, family):
+    """nt = 1001 = 7 x 11 x 13 and 1000 = 10 x 10 x 10: the P kernels (one direct mixed-radix transform per pair
+    of traces) and, with family 2, the chirp-z kernels they replace — same oracle, same tolerances; trace counts
+    odd and even, fewer and more pairs than a block has waves"""
+    nx, ny, nt = shape
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 1024))[:, :nt].reshape(nx, ny, nt).copy()
+    engine.set_kernel_family(family)
+    try:
+        engine.set_time_axis(time)
+        assert engine.kernel_variant().startswith("p-mixed-radix" if family == 0 else "fb-bluestein")
+        got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+        # the stage entry points use the same kernels in forward-only / inverse-only form
+        st_g = gpu_fft_stage(engine, cube, pkg.host_fft_window(time, 0, 1.0, 7.0))
+        d_f = engine.to_device(st_g["fft"]); d_o = engine.empty((nx * ny, nt)); d_i = engine.empty((nx * ny,))
+        engine.ifft(nx * ny, d_f, None, d_o, d_i)
+        back = d_o.download((nx, ny, nt), np.float32)
+        for b in (d_f, d_o, d_i):
+            b.free()
+    finally:
+        engine.set_kernel_family(0)
+    chain = synth.oracle_chain(time)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"], ref["amplitudes"], scale) < TOL
+    assert rel(got["data"], ref["data"]) < TOL
+    assert rel(got["img"], ref["img"]) < TOL
+    st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(got["phases"], ref["phases"], st["amplitudes"])
+    st_o = ob.fft_stage(cube, time, 0, 1.0, 7.0)
+    assert np.array_equal(st_g["data"], st_o["data"])
+    assert rel(st_g["fft"], st_o["fft"], np.abs(st_o["fft"]).max()) < TOL
+    assert phase_ok(st_g["phases"], st_o["phases"], st_o["amplitudes"])
+    assert rel(back, st_o["data"]) < TOL   # C2R(R2C(w x)) / nt = w x
 
 
 @pytest.mark.parametrize("nt", [3, 6, 7, 1001, 2000, 4000])

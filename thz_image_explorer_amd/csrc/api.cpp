@@ -127,7 +127,7 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     if (!ctx || !time || nt < 2) return fail(ctx, THZ_ERR_INVALID, "time axis needs >= 2 samples");
     if (int rc = use_device(ctx)) return rc;
     PlanHost H;
-    if (!build_plan(nt, H, ctx->allow_f))
+    if (!build_plan(nt, H, ctx->allow_f, ctx->allow_p))
         return fail(ctx, THZ_ERR_UNSUPPORTED,
                     "unsupported trace length " + std::to_string(nt) +
                         " (powers of two 4..16384, or any length 2..8191)");
@@ -135,7 +135,8 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
                  n_bf = H.bfft.size();
     const size_t n_f1 = H.f_t1.size(), n_f2 = H.f_t2.size(), n_fw = H.f_w2n.size();
     const size_t n_ones = (size_t)(H.nf + 1) / 2;  // nf floats of 1.0, counted in c32 units
-    const size_t total = n_tw + n_sp + n_ch + n_bf + n_f1 + n_f2 + n_fw + n_ones;
+    const size_t n_p1 = H.p_t1.size(), n_p2 = H.p_t2.size();
+    const size_t total = n_tw + n_sp + n_ch + n_bf + n_f1 + n_f2 + n_fw + n_ones + n_p1 + n_p2;
     c32 *d = nullptr;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMalloc((void **)&d, total * sizeof(c32)));
@@ -149,6 +150,8 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     pack.insert(pack.end(), H.f_t2.begin(), H.f_t2.end());
     pack.insert(pack.end(), H.f_w2n.begin(), H.f_w2n.end());
     pack.insert(pack.end(), n_ones, c32{1.0f, 1.0f});
+    pack.insert(pack.end(), H.p_t1.begin(), H.p_t1.end());
+    pack.insert(pack.end(), H.p_t2.begin(), H.p_t2.end());
     hipError_t e = hipMemcpy(d, pack.data(), total * sizeof(c32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(d);
@@ -161,7 +164,9 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     ctx->plan_d = plan_dev(H, d, n_sp ? d + n_tw : nullptr, n_ch ? d + n_tw + n_sp : nullptr,
                            n_bf ? d + n_tw + n_sp + n_ch : nullptr, n_f1 ? d + o_f : nullptr,
                            n_f2 ? d + o_f + n_f1 : nullptr, n_fw ? d + o_f + n_f1 + n_f2 : nullptr,
-                           reinterpret_cast<const float *>(d + o_f + n_f1 + n_f2 + n_fw));
+                           reinterpret_cast<const float *>(d + o_f + n_f1 + n_f2 + n_fw),
+                           n_p1 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones : nullptr,
+                           n_p2 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones + n_p1 : nullptr);
     ctx->time.assign(time, time + nt);
     ctx->freq.resize(nt / 2 + 1);
     (void)thz_host_frequency_axis(time, nt, ctx->freq.data());
@@ -171,8 +176,9 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
 
 int thz_set_kernel_family(thz_ctx *ctx, int family)
 {
-    if (!ctx || family < 0 || family > 1) return THZ_ERR_INVALID;
-    ctx->allow_f = family == 0;
+    if (!ctx || family < 0 || family > 2) return THZ_ERR_INVALID;
+    ctx->allow_f = family != 1;
+    ctx->allow_p = family == 0;
     if (ctx->have_plan) {
         std::vector<float> t = ctx->time;
         return thz_set_time_axis(ctx, t.data(), t.size());

@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "fft_f.hpp"
 #include "fft_fb.hpp"
+#include "fft_p.hpp"
 
 #include <cstdlib>
 
@@ -1613,6 +1614,33 @@ static void dispatch_fb(hipStream_t st, const PlanDev &P, FBArgs &A)
     }
 }
 
+// P family (fft_p.hpp): one wave per pair of traces, up to 16 waves per block share the tables
+template <class PL, int MODE>
+static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
+{
+    unsigned waves = 16;
+    while (waves > 1 && PL::lds_bytes((int)waves) > kLdsBytesPerCU) --waves;
+    const size_t lds = PL::lds_bytes((int)waves);
+    const size_t n_pairs = (A.npix + 1) / 2;
+    size_t g = (n_pairs + waves - 1) / waves;
+    if (g > (size_t)kNumCU) g = kNumCU;
+    if (g < 1) g = 1;
+    PTables T{reinterpret_cast<const cx *>(P.p_t1), reinterpret_cast<const cx *>(P.p_t2)};
+    allow_dynamic_lds(k_p<PL, MODE>, lds);
+    THZ_LAUNCH((k_p<PL, MODE>), (unsigned)g, waves * kWave, lds, st, A, T);
+}
+
+template <int MODE>
+static void dispatch_p(hipStream_t st, const PlanDev &P, FBArgs &A)
+{
+    A.nt = P.nt;
+    A.nf = P.nf;
+    switch (P.nt) {
+    case 1001: launch_p<PPlan1001, MODE>(st, P, A); break;
+    default: launch_p<PPlan1000, MODE>(st, P, A); break;
+    }
+}
+
 // FBC: S waves per pair (fft_fb.hpp), forward and inverse as separate kernels, for the lengths
 // 1024 < nt < 8192 that are not a power of two
 
@@ -1684,7 +1712,14 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
             return;
         }
     }
-    if (P.family == kFamilyFB && data_out && wa) {
+    if (P.family == kFamilyP && !wb && !data_out) {
+        FBArgs A{};
+        A.npix = npix; A.in = in; A.pre_win = wa; A.mask = mask ? mask : P.ones;
+        A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        dispatch_p<kFwd>(st, P, A);
+        return;
+    }
+    if ((P.family == kFamilyFB || P.family == kFamilyP) && data_out && wa) {
         launch_td_window(st, npix, P.nt, in, wa, data_out);
         if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
         launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
@@ -1719,6 +1754,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         FArgs A{};
         A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.post_win = win; A.data_out = out; A.img = img;
         dispatch_f<kInv>(st, P, A, false);
+        return;
+    }
+    if (P.family == kFamilyP) {
+        FBArgs A{};
+        A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.mask = P.ones; A.post_win = win;
+        A.data_out = out; A.img = img;
+        dispatch_p<kInv>(st, P, A);
         return;
     }
     if (P.family == kFamilyFB) {
@@ -1767,6 +1809,14 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         // round trip through HBM is noise next to 4 S core runs per pair)
         launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
         launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
+        return;
+    }
+    if (P.family == kFamilyP && fft_out && amp_out && ph_out && data_out) {
+        FBArgs A{};
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
+        A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        A.data_out = data_out; A.img = img;
+        dispatch_p<kPipe>(st, P, A);
         return;
     }
     if (P.family == kFamilyFB && fft_out && amp_out && ph_out && data_out) {

@@ -34,9 +34,12 @@ struct PlanDev {
     const c32 *f_t2;   // [k2][j3]   W_(8 R2)^(j3 k2)
     const c32 *f_w2n;  // [k]        exp(-i*pi*k/N), k in [0, N)
     const float *ones; // nf floats of 1.0 (stand-in mask)
+    // "P" family (mixed-radix three-pass transform of length nt = R1 R2 R3, fft_p.hpp); family == kFamilyP
+    const c32 *p_t1;   // [k1][m]    W_nt^(m k1), nt entries
+    const c32 *p_t2;   // [k2][j3]   W_(R2 R3)^(j3 k2)
 };
 
-enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4, kFamilyFB8 = 5 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)
+enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4, kFamilyFB8 = 5, kFamilyP = 6 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)
 
 // one band of the batched Richardson–Lucy solve (offsets in floats into one workspace)
 struct RlBand {

@@ -19,8 +19,19 @@ struct PlanHost {
     std::vector<c32> tw, tw_split, chirp_conj, bfft;
     int family = kFamilyG;
     std::vector<c32> f_t1, f_t2, f_w2n;
+    std::vector<c32> p_t1, p_t2;  // P family
     const char *variant = "";
 };
+
+// P-family factorisation nt = r1 r2 r3 (fft_p.hpp): the lengths a kernel is instantiated for
+inline bool p_factors(size_t nt, int &r1, int &r2, int &r3)
+{
+    switch (nt) {
+    case 1001: r1 = 7; r2 = 11; r3 = 13; return true;   // every real scan of the reference's sample data
+    case 1000: r1 = 10; r2 = 10; r3 = 10; return true;
+    default: return false;
+    }
+}
 
 // F-family factorisation of the half-length complex transform (fft_f.hpp)
 inline bool f_factors(size_t nt, int &r1, int &r2, int &r3)
@@ -59,7 +70,7 @@ inline void host_fft_pow2(std::vector<std::complex<double>> &a)
 }
 
 // Returns false when nt is outside the supported range.
-inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
+inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p = true)
 {
     const double pi = 3.14159265358979323846;
     if (nt < 2) return false;
@@ -162,13 +173,33 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true)
             P.f_w2n[k] = c32{(float)std::cos(a), (float)std::sin(a)};
         }
     }
+    P.p_t1.clear(); P.p_t2.clear();
+    int q1, q2, q3;
+    if (allow_f && allow_p && p_factors(nt, q1, q2, q3)) {
+        // the chirp-z tables above stay (stage entry points without a P kernel fall back to them)
+        P.family = kFamilyP;
+        P.variant = nt == 1001 ? "p-mixed-radix-7x11x13-regs-lds" : "p-mixed-radix-10x10x10-regs-lds";
+        const size_t m1 = (size_t)q2 * q3;
+        P.p_t1.resize(nt);
+        for (int k1 = 0; k1 < q1; ++k1)
+            for (size_t m = 0; m < m1; ++m) {
+                const double a = -2.0 * pi * (double)((m * (size_t)k1) % nt) / (double)nt;
+                P.p_t1[(size_t)k1 * m1 + m] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+        P.p_t2.resize(m1);
+        for (int k2 = 0; k2 < q2; ++k2)
+            for (int j3 = 0; j3 < q3; ++j3) {
+                const double a = -2.0 * pi * (double)((j3 * k2) % (int)m1) / (double)m1;
+                P.p_t2[(size_t)k2 * q3 + j3] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+    }
     return true;
 }
 
 inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
                         const c32 *chirp_conj, const c32 *bfft, const c32 *f_t1 = nullptr,
                         const c32 *f_t2 = nullptr, const c32 *f_w2n = nullptr,
-                        const float *ones = nullptr)
+                        const float *ones = nullptr, const c32 *p_t1 = nullptr, const c32 *p_t2 = nullptr)
 {
     PlanDev D;
     D.nt = H.nt;
@@ -187,6 +218,9 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     if ((H.family == kFamilyFB || H.family == kFamilyFB2 || H.family == kFamilyFB4 || H.family == kFamilyFB8) && f_t1 && f_t2 && ones
         && chirp_conj && bfft)
         D.family = H.family;
+    if (H.family == kFamilyP && p_t1 && p_t2 && ones) D.family = kFamilyP;
+    D.p_t1 = p_t1;
+    D.p_t2 = p_t2;
     D.ones = ones;
     D.f_t1 = f_t1;
     D.f_t2 = f_t2;

@@ -200,7 +200,7 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
         steps = tilt_plan(time.data(), nt_cur, nx_c, ny_c, cfg->tilt_x_deg, cfg->tilt_y_deg, dx_c, dy_c, nullptr, nullptr);
     if (steps) {
         PlanHost probe;
-        if (!build_plan(nt_cur + 2 * steps, probe, ctx->allow_f))
+        if (!build_plan(nt_cur + 2 * steps, probe, ctx->allow_f, ctx->allow_p))
             return fail(ctx, THZ_ERR_UNSUPPORTED,
                         "tilt compensation extends the traces to " + std::to_string(nt_cur + 2 * steps)
                             + " samples: no transform of that length (powers of two up to 16384, other lengths up to 8191)");
