@@ -352,9 +352,15 @@ void thz_oracle_filter_scan(const float *data, size_t npix, int nt, const float 
 }
 
 /* deconvolution.rs:432-458 verbatim (correlation-indexed, zero outside) */
+/* Rows of the output are independent and every pixel keeps the reference's own summation order (m outer,
+ * n inner, one f32 chain), so the OpenMP split over rows changes no bit of the result — it only lets the
+ * reference's defaults (500 iterations, 47 x 57 taps) finish in seconds on the test box. */
 static void direct_convolve2d(const float *a, int ar, int ac, const float *b, int br, int bc, float *res)
 {
     int hr = br / 2, hc = bc / 2;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int i = 0; i < ar; ++i)
         for (int j = 0; j < ac; ++j) {
             float sum = 0.0f;
@@ -372,6 +378,9 @@ static void direct_convolve2d(const float *a, int ar, int ac, const float *b, in
 static void same_convolve2d(const float *a, int ar, int ac, const float *b, int br, int bc, float *res)
 {
     int sr = (br - 1) / 2, sc = (bc - 1) / 2;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int i = 0; i < ar; ++i)
         for (int j = 0; j < ac; ++j) {
             float sum = 0.0f;

@@ -174,7 +174,7 @@ def test_knife_edge_real_traces(engine):
     time = k["time"]
     cube = ob.subtract_bias(k["traces"].reshape(4, 4, 1001))
     engine.set_time_axis(time)
-    assert "bluestein" in engine.kernel_variant()
+    assert engine.kernel_variant().startswith("p-mixed-radix-7x11x13")   # the length of real scans has its own kernel
     got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
     chain = synth.oracle_chain(time)
     ref = ob.run_pipeline(cube, time, chain)

@@ -393,8 +393,8 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
     StageTimer t(ctx, THZ_STAGE_PIPELINE);
     if (ctx->plan_d.mode == kModePow2
         || ((ctx->plan_d.family == kFamilyFB || ctx->plan_d.family == kFamilyFB2 || ctx->plan_d.family == kFamilyFB4
-             || ctx->plan_d.family == kFamilyFB8)
-            && d_fft && d_amp && d_phase)) {  // chirp-z over the F core: one launch
+             || ctx->plan_d.family == kFamilyFB8 || ctx->plan_d.family == kFamilyP)
+            && d_fft && d_amp && d_phase)) {  // mixed radix / chirp-z over the F core: one launch
         launch_pipeline(ctx->stream, ctx->plan_d, npix, d_raw, d_pre_win, d_fd_mask, d_post_win,
                         reinterpret_cast<c32 *>(d_fft), d_amp, d_phase, d_data_out, d_img);
         return check_launch(ctx);

@@ -91,9 +91,11 @@ __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
     float a[4], ph[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
-        ph[c] = fast_atan2f(X[c].y, X[c].x);
+    for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+    {
+        // four angles as two packed Horner chains (same values as four fast_atan2f calls, half the issue slots)
+        const float yy[4] = {X[0].y, X[1].y, X[2].y, X[3].y}, xx[4] = {X[0].x, X[1].x, X[2].x, X[3].x};
+        fast_atan2f_x4(yy, xx, ph);
     }
     if (g == 0) u.first = wave_bcast<0>(ph[0]);
     float prev = wave_shr1(ph[3]);

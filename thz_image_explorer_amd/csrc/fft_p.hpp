@@ -259,6 +259,13 @@ __device__ __forceinline__ void p_pass23(cx *buf, const cx *t2, const PAddr<P> &
     wave_sync();
 }
 
+// v, or +0.0 when `zero` — on the bits, so that no floating-point identity can bring a sign back
+__device__ __forceinline__ float p_zero_if(float v, bool zero)
+{
+    const uint32_t bits = __builtin_bit_cast(uint32_t, v) & (zero ? 0u : 0xffffffffu);
+    return __builtin_bit_cast(float, bits);
+}
+
 // Same argument block as the chirp-z kernels (w / bf unused)
 template <class P, int MODE>
 __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
@@ -306,21 +313,25 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
             // are issued together (clamped indices, predicated stores)
             const float *x1 = A.in + p * (size_t)N;
             const float *x2 = has2 ? x1 + N : x1;
+            // every round's loads are issued before the first butterfly: one trip to HBM per pair, not one per round
+            float xa[P::RD1][R1], xb[P::RD1][R1];
+#pragma unroll
+            for (int i = 0; i < P::RD1; ++i) {
+#pragma unroll
+                for (int j1 = 0; j1 < R1; ++j1) {
+                    xa[i][j1] = ld_off(x1, (unsigned)(M1 * j1 + ad.b1[i]));
+                    xb[i][j1] = ld_off(x2, (unsigned)(M1 * j1 + ad.b1[i]));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < P::RD1; ++i) {
                 const bool on = lane + kWave * i < P::B1;
                 const int m = ad.b1[i];
-                float xa[R1], xb[R1];
-#pragma unroll
-                for (int j1 = 0; j1 < R1; ++j1) {
-                    xa[j1] = ld_off(x1, (unsigned)(M1 * j1 + m));
-                    xb[j1] = ld_off(x2, (unsigned)(M1 * j1 + m));
-                }
                 cx v[R1];
 #pragma unroll
                 for (int j1 = 0; j1 < R1; ++j1) {
                     const float pw = pre_l[M1 * j1 + m];
-                    v[j1] = cx{xa[j1] * pw, has2 ? xb[j1] * pw : 0.0f};
+                    v[j1] = cx{xa[i][j1] * pw, has2 ? xb[i][j1] * pw : 0.0f};
                 }
                 p_pass1_round<P>(v, buf, t1l, m, on);
                 THZ_SCHED_FENCE();
@@ -348,9 +359,13 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
                         X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
                         X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
                         m[c] = mask_l[kc];
-                        if (kc == 0 || ((N & 1) == 0 && kc == NF - 1)) {  // real input: DC / Nyquist bins are real
-                            X1[c].y = 0.0f;
-                            X2[c].y = 0.0f;
+                        // real input: DC / Nyquist bins are real, with a POSITIVE zero as imaginary part (realfft writes
+                        // +0.0 there; arg() of a negative real bin is then +pi, not -pi).  Forced on the bit pattern: a
+                        // float select left -0.0 = -0.5 (x - x) standing in the 10 x 10 x 10 instantiation
+                        {
+                            const bool real_bin = kc == 0 || ((N & 1) == 0 && kc == NF - 1);
+                            X1[c].y = p_zero_if(X1[c].y, real_bin);
+                            X2[c].y = p_zero_if(X2[c].y, real_bin);
                         }
                     }
                     const size_t o1 = p * (size_t)NF + k0;
@@ -410,19 +425,38 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
         {
             float *o1 = A.data_out + p * (size_t)N;
             float acc1 = 0.0f, acc2 = 0.0f;
-#pragma unroll 4
-            for (int n = lb1; n < N; n += kWave) {
-                const cx U = buf[n];
-                const float pw = post_l[n];
-                const float v1 = (U.x / fnt) * pw;
-                o1[n] = v1;
-                acc1 += v1 * v1;
-                if (has2) {
-                    const float v2 = (-U.y / fnt) * pw;
-                    o1[N + n] = v2;
-                    acc2 += v2 * v2;
+            // four consecutive samples per lane: 16-byte stores (rows are only 4-byte aligned: store_f4)
+            constexpr int QUADS = (N + 3) / 4, QR = (QUADS + kWave - 1) / kWave;
+#pragma unroll
+            for (int i = 0; i < QR; ++i) {
+                const int n0 = lb4 + 4 * kWave * i;
+                if (n0 + 3 < N) {
+                    float v1[4], v2[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const cx U = buf[n0 + c];
+                        const float pw = post_l[n0 + c];
+                        v1[c] = (U.x / fnt) * pw;
+                        v2[c] = (-U.y / fnt) * pw;
+                        acc1 += v1[c] * v1[c];
+                        acc2 += v2[c] * v2[c];
+                    }
+                    store_f4(o1 + n0, v1[0], v1[1], v1[2], v1[3]);
+                    if (has2) store_f4(o1 + N + n0, v2[0], v2[1], v2[2], v2[3]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (n0 + c < N) {
+                            const cx U = buf[n0 + c];
+                            const float pw = post_l[n0 + c];
+                            const float a = (U.x / fnt) * pw, b = (-U.y / fnt) * pw;
+                            o1[n0 + c] = a;
+                            acc1 += a * a;
+                            if (has2) { o1[N + n0 + c] = b; acc2 += b * b; }
+                        }
                 }
             }
+            if (!has2) acc2 = 0.0f;
             if (A.img) {
                 acc1 = wave_reduce_add(acc1);
                 acc2 = wave_reduce_add(acc2);
