@@ -39,6 +39,40 @@ def phase_ok(ph, ref, amp_ref):
     return True
 
 
+def phase_parity(ph, ref_ph, ref_fft, spectrum_tol=TOL):
+    """Unwrapped phases against the oracle's, derived from what numpy_unwrap (math_tools.rs:211-240) can and cannot
+    pin.  (1) Modulo 2 pi every bin agrees to 3e-3 rad: the running sum adds up to nf (~2 049) adjusted
+    differences of magnitude <= pi, each rounded to the sum's ulp (<= 6e-5 at |phi| ~ 600 rad) — observed <= 5e-4
+    — plus the arctangent's own 3e-7.  (2) The multiple of 2 pi may only change at a bin where the reference's own
+    wrap decision |arg X[k] - arg X[k-1]| <> pi is closer to its threshold than the two arguments are known: a
+    spectrum that is right to spectrum_tol * max|X| (the parity bar) has arg X[k] to within that over |X[k]|.
+    Returns (ok, message)."""
+    d = np.asarray(ph, np.float64) - np.asarray(ref_ph, np.float64)
+    j = np.round(d / (2 * np.pi))
+    res = np.abs(d - 2 * np.pi * j)
+    if res.max() > 3e-3:
+        return False, f"residual {res.max():.2e} rad modulo 2 pi"
+    X = ref_fft[..., 0].astype(np.float64) + 1j * ref_fft[..., 1].astype(np.float64)
+    mag = np.abs(X)
+    raw = np.angle(X)
+    dd = np.diff(raw, axis=-1)
+    dd = np.abs(np.abs(dd) - np.pi)                               # distance of the decision from its threshold
+    err = spectrum_tol * mag.max(axis=-1, keepdims=True) / np.maximum(mag, 1e-300) + 1e-6
+    slack = err[..., 1:] + err[..., :-1]
+    changed = np.diff(j, axis=-1) != 0
+    bad = changed & (dd > slack)
+    if j[..., 0].any():
+        # bin 0 is real: arg is 0 or +-pi; a 2 pi offset there is the sign of a zero imaginary part
+        bad0 = (j[..., 0] != 0) & (np.abs(np.abs(raw[..., 0]) - np.pi) > 1e-6)
+        if bad0.any():
+            return False, f"{int(bad0.sum())} traces offset by 2 pi from bin 0 on"
+    if bad.any():
+        idx = np.argwhere(bad)[0]
+        return False, (f"{int(bad.sum())} wrap decisions differ where the reference's is not borderline, first at {idx.tolist()}: "
+                       f"| |dphi| - pi | = {dd[tuple(idx)]:.2e}, slack {slack[tuple(idx)]:.2e}")
+    return True, ""
+
+
 def gpu_fft_stage(eng, cube, w, mask=None, want_data=True):
     nx, ny, nt = cube.shape
     npix, nf = nx * ny, nt // 2 + 1

@@ -331,3 +331,44 @@ def test_session_outputs_absent_until_recomputed(engine):
             assert e.value.code == -4
     finally:
         sess.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 1024), (4, 5, 1001)])
+def test_session_recompute_from_each_chain_position(engine, shape):
+    """UpdateType::Filter(start_idx) (data_thread.rs:1090-1105): one slider changed per chain position, the walk
+    started at that position (what UpdateFilter(uuid) / the fft-window commands send, :813-836, 907-921), every
+    time against the oracle's stage-by-stage chain with the new settings.  Positions 1-5 run the whole chain, 6
+    and 7 only the tail on the resident spectrum — with identical results to a recompute from the front."""
+    nx, ny, nt = shape
+    time, cube = synth.make_cube(nx, ny, nt)
+    sess = pkg.Session(engine, nx, ny, time)
+    try:
+        sess.upload(cube, subtract_bias=False)
+        cfg = pkg.chain_cfg_default(time)
+        sess.recompute(cfg)
+        t0, t1 = float(time[0]), float(time[-1])
+        edits = [(3, lambda c: setattr(c, "td_before_low", t0 + 4.0)),       # Time Band Pass
+                 (3, lambda c: setattr(c.fft_window, "upper", 5.0)),          # fft window commands send fft_index = 3
+                 (5, lambda c: setattr(c, "fd_high", 3.5)),                   # Frequency Band Pass
+                 (7, lambda c: setattr(c, "td_after_high", t1 - 6.0)),        # Time Band Pass (after)
+                 (6, lambda c: None),                                         # ifft re-run, nothing changed
+                 (7, lambda c: setattr(c, "td_after_width", 1.5)),
+                 (2, lambda c: setattr(c, "tilt_active", 0)),                 # Tilt Compensation switched off
+                 (7, lambda c: setattr(c, "td_after_low", t0 + 2.0))]
+        for pos, edit in edits:
+            edit(cfg)
+            sess.recompute(cfg, pos)
+            check(sess, oracle_chain(cube, time, cfg), nx, ny)
+            tail = sess.download(pkg.BUF_DATA).copy()
+            img = sess.download(pkg.BUF_IMG).copy()
+            if pos >= 6:     # the tail-only path writes what the full chain writes (2e-6: fused vs stand-alone inverse)
+                sess.recompute(cfg, 1)
+                full = sess.download(pkg.BUF_DATA)
+                assert np.abs(tail - full).max() <= 2e-6 * np.abs(full).max()
+                assert np.abs(img - sess.download(pkg.BUF_IMG)).max() <= 2e-6 * img.max()
+        # a tail start whose front settings differ from the last full recompute falls back to the full chain
+        cfg.fd_low = 0.5
+        sess.recompute(cfg, 7)
+        check(sess, oracle_chain(cube, time, cfg), nx, ny)
+    finally:
+        sess.close()

@@ -116,13 +116,15 @@ void fd_bandpass(const float *freq, size_t nf, double low, double high, double w
 void water_line_mask(const float *freq, size_t nf, const float *lines, size_t n_lines, float sigma,
                      float *out)
 {
+    // evaluated in double and rounded once: the notch flanks are steep ((f - line) / sigma amplifies the f32
+    // rounding of the axis a hundredfold), and this O(nf x lines) host loop costs nothing
     for (size_t k = 0; k < nf; ++k) {
-        float m = 1.0f;
+        double m = 1.0;
         for (size_t i = 0; i < n_lines; ++i) {
-            const float z = (freq[k] - lines[i]) / sigma;
-            m *= 1.0f - std::exp(-(z * z));
+            const double z = ((double)freq[k] - (double)lines[i]) / (double)sigma;
+            m *= 1.0 - std::exp(-(z * z));
         }
-        out[k] = m;
+        out[k] = (float)m;
     }
 }
 

@@ -600,12 +600,33 @@ ScannedImageFilterData Deconvolution::filter(const ScannedImageFilterData &input
     ScannedImageFilterData output = input;
     const thz_psf psf = gui.psf.view();
     const thz_deconv_cfg cfg{(uint32_t)n_iterations, (uint32_t)n_filters, start_freq, end_freq, win_width, 0u, 0u};
-    // abort: Arc<AtomicBool> -> plain int the engine polls between batches
-    volatile int abort_now = abort_flag.load() ? 1 : 0;
-    float prog = 0.0f;
+    // The engine polls a plain int between iteration batches and writes its progress into a float; the
+    // reference's cancellable loops poll the Arc<AtomicBool> per item (cancellable_loops/src/lib.rs:137-155) and
+    // publish progress through the RwLock<Option<f32>> (deconvolution.rs:896-904).  A watcher thread bridges the
+    // two while the (blocking) call runs: a click on the abort button is seen within one poll interval + one batch.
+    volatile int abort_now = abort_flag.load(std::memory_order_relaxed) ? 1 : 0;
+    volatile float prog = 0.0f;
+    std::atomic<bool> done{false};
+    std::thread watcher([&] {
+        while (!done.load(std::memory_order_acquire)) {
+            if (abort_flag.load(std::memory_order_relaxed)) abort_now = 1;
+            if (progress) {
+                std::lock_guard<std::mutex> g(progress->first);
+                progress->second = prog;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    });
     const int rc = thz_deconvolve(e.ctx(), &psf, &cfg, input.width, input.height, *input.dx, *input.dy,
-                                  input.data.ptr(), output.data.ptr(), output.img.ptr(), nullptr, &abort_now, &prog);
+                                  input.data.ptr(), output.data.ptr(), output.img.ptr(), nullptr, &abort_now,
+                                  const_cast<float *>(&prog));
+    done.store(true, std::memory_order_release);
+    watcher.join();
     clear_progress(progress);
+    if (rc == THZ_ERR_ABORTED) {  // filter.rs:631-637: the stage's output is its input
+        log_warn("deconvolution aborted");
+        return input;
+    }
     if (rc == THZ_SKIPPED) {
         log_warn("deconvolution skipped by a guard (PSF missing / image too small / PSF too large)");
         return input;
