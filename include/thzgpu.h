@@ -333,9 +333,14 @@ typedef struct thz_deconv_cfg {
     uint32_t n_filters;
     float start_freq, end_freq, win_width;
     /* Band-parallel execution across GPUs: this call only sums
-     * bands [band_begin, band_end) of the n_filters-band bank; 0, 0 = all bands.
-     * The per-rank outputs add up to the full result (all-reduce them); the
-     * iteration schedule still uses the beam widths of the whole bank. */
+     * bands [band_begin, band_end) of the n_filters-band bank; 0, 0 = all bands;
+     * band_begin == band_end > 0 = none (more ranks than bands).  The per-rank
+     * d_out add up to the full result (all-reduce them) on every path: when a guard
+     * or an abort makes the stage pass its input through, the rank that owns band 0
+     * writes the input and every other rank zeros, so the all-reduce yields the
+     * input once; every rank returns the same status for a guard.  d_img of a band
+     * subset is the energy of a partial sum: take the image after the all-reduce.
+     * The iteration schedule uses the beam widths of the whole bank. */
     uint32_t band_begin, band_end;
 } thz_deconv_cfg;
 
@@ -562,6 +567,16 @@ thz_session *thz_group_session_member(thz_group_session *gs, int i);
 int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtract_bias);
 /* UpdateType::Filter(start_stage) on every slab + C2 + C1.  Collective; blocking. */
 int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg, int start_stage, int gather);
+/* UpdateType::Filter(<Deconvolution>) over the group — BASELINE config 4's "1 -> 2 GPUs".  Richardson-Lucy is
+ * spatially global per band, so the stage shards by BAND: all-gather of the slabs' "Time Band Pass" output
+ * (every member then holds the whole cube), thz_deconvolve with the rank's bands (thz_host_slab over n_filters),
+ * all-reduce of the band sums, every member keeps its rows; image (and the final cube, if the last recompute
+ * gathered it) re-gathered to rank 0.  Members of one process run on host threads.  An abort or error on any
+ * rank makes every rank pass its input through (agreed by a one-float all-reduce).  Same return codes as
+ * thz_session_deconvolve.  NOTE: the call's critical path is the widest band's 500 dependent
+ * iterations on whichever GPU owns it, so two GPUs shorten the call by little — the split is correct, not fast. */
+int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, const thz_deconv_cfg *cfg,
+                                 volatile const int *abort_flag, float *progress);
 /* gathered results on rank 0's device after a recompute: THZ_BUF_IMG (nx, ny) always; THZ_BUF_DATA with
  * THZ_GATHER_TIME / ALL; THZ_BUF_FFT / AMPLITUDES / PHASES with ALL; THZ_BUF_AVG_* (on every member these
  * are also in its slab session).  NULL when absent or when this process does not drive rank 0. */

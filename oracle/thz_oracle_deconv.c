@@ -327,12 +327,49 @@ static void convolve1d_f64(const float *a, int na, const float *b, int nb, const
     for (int i = 0; i < na; ++i) out[i] = (float)(tmp[i + shift].re / (double)fft_size);
 }
 
+/* DIAGNOSTIC ONLY (scripts/gpu_deconv_error_budget.py): the same convolution through an f32 FFT — NOT the
+ * reference's arithmetic (deconvolution.rs:266-317 is Complex<f64>), used to measure how much of the device's
+ * distance from the oracle is the fp32 FIR and how much the Richardson-Lucy iterations add on top. */
+static int g_fir_f32 = 0;
+void thz_oracle_set_fir_f32(int on) { g_fir_f32 = on; }
+static void convolve1d_f32(const float *a, int na, const float *b, int nb, const plan_f *pl,
+                           int fft_size, cpx_f *wa, cpx_f *wb, cpx_f *tmp, float *out)
+{
+    for (int i = 0; i < fft_size; ++i) { wa[i].re = wa[i].im = 0.0f; wb[i].re = wb[i].im = 0.0f; }
+    for (int i = 0; i < na; ++i) wa[i].re = a[i];
+    for (int i = 0; i < nb; ++i) wb[i].re = b[i];
+    cfft_fwd_f(pl, wa, tmp); memcpy(wa, tmp, sizeof(cpx_f) * (size_t)fft_size);
+    cfft_fwd_f(pl, wb, tmp); memcpy(wb, tmp, sizeof(cpx_f) * (size_t)fft_size);
+    for (int i = 0; i < fft_size; ++i) wa[i] = cmul_f(wa[i], wb[i]);
+    cfft_inv_f(pl, wa, tmp);
+    int shift = (nb - 1) / 2;
+    for (int i = 0; i < na; ++i) out[i] = tmp[i + shift].re / (float)fft_size;
+}
+
 /* filter_scan, deconvolution.rs:574-609 */
 void thz_oracle_filter_scan(const float *data, size_t npix, int nt, const float *filter, int ntaps,
                             float *out)
 {
     int conv = nt + ntaps - 1, fft_size = 1;
     while (fft_size < conv) fft_size <<= 1;
+    if (g_fir_f32) {
+        plan_f *plf = plan_new_f(fft_size);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+        {
+            cpx_f *wa = (cpx_f *)malloc(sizeof(cpx_f) * 3 * (size_t)fft_size);
+            cpx_f *wb = wa + fft_size, *tmp = wb + fft_size;
+#ifdef _OPENMP
+#pragma omp for
+#endif
+            for (long p = 0; p < (long)npix; ++p)
+                convolve1d_f32(data + (size_t)p * nt, nt, filter, ntaps, plf, fft_size, wa, wb, tmp, out + (size_t)p * nt);
+            free(wa);
+        }
+        plan_free_f(plf);
+        return;
+    }
     plan_d *pl = plan_new_d(fft_size);
 #ifdef _OPENMP
 #pragma omp parallel

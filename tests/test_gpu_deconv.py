@@ -132,6 +132,25 @@ def test_band_parallel_partials_add_up(engine):
     assert np.abs(s - outs["all"]).max() / np.abs(outs["all"]).max() < 1e-5
     with pytest.raises(pkg.ThzError):
         engine.deconvolve(psf, pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5, 4, 2), nx, ny, 0.5, 0.5, 0, 0)
+    # the partial outputs add up on the pass-through paths too: a guard (PSF wider than a 20 x 20
+    # image) makes the rank that owns band 0 copy the input through, every other rank contribute zeros; a rank
+    # with no band at all (more ranks than bands) contributes zeros and succeeds
+    big = synth.make_traces(np.arange(20 * 20), nt).reshape(20, 20, nt)
+    d2 = engine.to_device(big)
+    total = np.zeros_like(big)
+    for b0, b1 in ((0, 2), (2, 4), (4, 6)):
+        o2 = engine.empty((400, nt)).zero()
+        assert engine.deconvolve(psf, pkg.DeconvCfg(20, 6, 0.1, 10.0, 0.5, b0, b1), 20, 20, 0.5, 0.5, d2, o2) == 1
+        part = o2.download((20, 20, nt), np.float32)
+        assert np.array_equal(part, big if b0 == 0 else np.zeros_like(big))
+        total += part
+        o2.free()
+    assert np.array_equal(total, big)
+    d3 = engine.to_device(cube); o3 = engine.empty((nx * ny, nt))
+    assert engine.deconvolve(psf, pkg.DeconvCfg(20, 6, 0.4, 3.0, 0.5, 3, 3), nx, ny, 0.5, 0.5, d3, o3) == 0
+    assert not o3.download((nx, ny, nt), np.float32).any()
+    for b in (d2, d3, o3):
+        b.free()
 
 
 def test_deconvolution_abort_and_progress(engine):

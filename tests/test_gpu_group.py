@@ -109,3 +109,54 @@ def test_group_session_refuses_what_does_not_shard():
             gs.close()
     with pytest.raises(pkg.ThzError):
         pkg.Group(devices=[0, 0, 1])   # neither all the same nor all distinct
+
+
+def test_group_session_band_parallel_deconvolution(engine):
+    """BASELINE config 4's "1 -> 2 GPUs": the Deconvolution stage sharded by band over the group (all-gather of the
+    slabs, each rank its bands, all-reduce of the band sums) == the single-session stage; a guard on every rank and
+    an abort both leave the input as the stage's output"""
+    import ctypes
+    import os
+    nx, ny, nt = 36, 32, 256
+    time, cube = synth.make_cube(nx, ny, nt)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    cfg = pkg.chain_cfg_default(time)
+    dcfg = pkg.DeconvCfg(20, 5, 0.4, 3.0, 0.5)
+    single = pkg.Session(engine, nx, ny, time, 0.5, 0.5)
+    try:
+        single.upload(cube, subtract_bias=False)
+        single.recompute(cfg)
+        plain = single.download(pkg.BUF_DATA).copy()
+        assert single.deconvolve(psf, dcfg) == 0
+        want, want_img = single.download(pkg.BUF_DATA), single.download(pkg.BUF_IMG)
+    finally:
+        single.close()
+    for members in (2, 3):
+        with pkg.Group(devices=[0] * members) as g:
+            gs = pkg.GroupSession(g, nx, ny, time, 0.5, 0.5)
+            try:
+                gs.upload(cube, subtract_bias=False)
+                gs.recompute(cfg, 1, pkg.GATHER_TIME)
+                assert np.array_equal(gs.download(pkg.BUF_DATA), plain)
+                img_plain = gs.download(pkg.BUF_IMG).copy()
+                assert gs.deconvolve(psf, dcfg) == 0
+                got, img = gs.download(pkg.BUF_DATA), gs.download(pkg.BUF_IMG)
+                assert rel(got, want) < TOL          # the band sums associate differently
+                assert rel(img, want_img) < TOL
+                # slabs hold their rows of the same result
+                rows = np.concatenate([gs.member(i).download(pkg.BUF_DATA) for i in range(members)])
+                assert np.array_equal(rows, got)
+                # an abort seen by the ranks: every rank passes its input through, the group returns ABORTED
+                abort = ctypes.c_int(1)
+                with pytest.raises(pkg.ThzError) as e:
+                    gs.deconvolve(psf, pkg.DeconvCfg(80, 5, 0.4, 3.0, 0.5), abort=abort)
+                assert e.value.code == -5
+                assert np.array_equal(gs.download(pkg.BUF_IMG), img_plain)
+                assert np.array_equal(gs.download(pkg.BUF_DATA), plain)
+                # a guard (n_filters < 2) on every rank: skipped, input unchanged
+                gs.recompute(cfg, 1, pkg.GATHER_TIME)
+                assert gs.deconvolve(psf, pkg.DeconvCfg(20, 1, 0.4, 3.0, 0.5)) == 1
+                assert np.array_equal(gs.download(pkg.BUF_DATA), plain)
+            finally:
+                gs.close()

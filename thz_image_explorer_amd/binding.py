@@ -198,6 +198,7 @@ SYMBOLS = [
     ("thz_group_session_member", _P, [_P, C.c_int]),
     ("thz_group_session_upload", C.c_int, [_P, _P, C.c_int]),
     ("thz_group_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg), C.c_int, C.c_int]),
+    ("thz_group_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_group_session_result", _P, [_P, C.c_int]),
     ("thz_group_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
@@ -416,8 +417,11 @@ class Session:
             self.h = None
 
     def upload(self, cube, subtract_bias=True):
-        c = np.ascontiguousarray(cube, np.float32)
-        self.eng._check(self.eng.lib.thz_session_upload(self.h, c.ctypes.data, int(subtract_bias)))
+        """cube: host (nx, ny, nt) array, or None when THZ_BUF_RAW was filled on the device"""
+        c = None if cube is None else np.ascontiguousarray(cube, np.float32)
+        if c is not None and c.size != self.nx * self.ny * self.nt:
+            raise ValueError(f"cube has {c.size} samples, the session {self.nx * self.ny * self.nt}")
+        self.eng._check(self.eng.lib.thz_session_upload(self.h, c.ctypes.data if c is not None else None, int(subtract_bias)))
 
     def recompute(self, cfg: ChainCfg, start_stage: int = 1):
         """UpdateType::Filter(start_stage): 1 = everything, 6 / 7 = from the resident spectrum"""
@@ -599,6 +603,15 @@ class GroupSession:
 
     def recompute(self, cfg: ChainCfg, start_stage=1, gather=GATHER_SMALL):
         self.g._check(self.g.lib.thz_group_session_recompute(self.h, C.byref(cfg), int(start_stage), int(gather)))
+
+    def deconvolve(self, psf, cfg, abort=None, progress=None):
+        """band-parallel Deconvolution stage over the group -> status (0 applied, 1 skipped)"""
+        rc = self.g.lib.thz_group_session_deconvolve(self.h, C.byref(psf), C.byref(cfg),
+                                                     C.byref(abort) if abort is not None else None,
+                                                     C.byref(progress) if progress is not None else None)
+        if rc < 0:
+            self.g._check(rc)
+        return rc
 
     def download(self, which, nt_out=None):
         """gathered buffer of rank 0 (whole grid) or a pixel-mean vector"""

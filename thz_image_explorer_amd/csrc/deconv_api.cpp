@@ -123,10 +123,34 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         if (mpy < 3) mpy = 3;
         if (mpx >= (long)ny || mpy >= (long)nx) skip = true;  // img_cols = ny, img_rows = nx
     }
+    // Band-parallel calls (cfg->band_begin / band_end select bands [b0, b1) of the bank; 0, 0 = all): the outputs
+    // of the ranks ADD UP to the full result.  That has to hold on the pass-through paths too — a guard, an
+    // abort — so the input is copied through by the one rank that owns band 0 and every other rank contributes
+    // zeros; a rank whose range is empty (more ranks than bands) contributes zeros as well.
+    int b0 = (int)cfg->band_begin, b1 = (int)cfg->band_end;
+    if (b0 == 0 && b1 == 0) b1 = nb;
+    if (b0 < 0 || b0 > b1 || (!skip && b1 > nb))
+        return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad band range");
+    const bool owns_first = b0 == 0;
+    auto pass_through = [&]() -> int {
+        if (owns_first) return copy_through(ctx, d_in, d_out, d_img, npix, nt);
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, npix * nt * sizeof(float), ctx->stream));
+        if (d_img) HIP_TRY(ctx, hipMemsetAsync(d_img, 0, npix * sizeof(float), ctx->stream));
+        if (d_gains_out && b1 > b0) HIP_TRY(ctx, hipMemsetAsync(d_gains_out, 0, (size_t)(b1 - b0) * npix * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return THZ_OK;
+    };
     if (skip) {
-        if (int rc = copy_through(ctx, d_in, d_out, d_img, npix, nt)) return rc;
+        if (int rc = pass_through()) return rc;
         if (progress) *progress = 1.0f;
         return THZ_SKIPPED;
+    }
+    if (b0 == b1) {  // nothing to add from this rank
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, npix * nt * sizeof(float), ctx->stream));
+        if (d_img) HIP_TRY(ctx, hipMemsetAsync(d_img, 0, npix * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (progress) *progress = 1.0f;
+        return THZ_OK;
     }
 
     tick("filter bank, widths");
@@ -170,10 +194,6 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     tick("plan, twiddles");
     // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double, for the bands of
     // this call (band-parallel multi-GPU: cfg->band_begin/band_end select a subset of the bank)
-    int b0 = (int)cfg->band_begin, b1 = (int)cfg->band_end;
-    if (b0 == 0 && b1 == 0) b1 = nb;
-    if (b0 < 0 || b1 > nb || b0 >= b1)
-        return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad band range");
     const int nbs = b1 - b0;
     {
         std::vector<double> trig(2 * M);  // cos | sin of -2 pi m / M
@@ -314,7 +334,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     for (int base = 0; base < max_iter; base += kRlBatch) {
         if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (int rc = copy_through(ctx, d_in, d_out, d_img, npix, nt)) return rc;
+            if (int rc = pass_through()) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
         }

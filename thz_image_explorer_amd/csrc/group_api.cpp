@@ -12,6 +12,7 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace thz;
@@ -26,6 +27,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -65,6 +67,7 @@ bool rccl_load()
     THZ_SYM(CommDestroy, ncclCommDestroy)
     THZ_SYM(GetErrorString, ncclGetErrorString)
     THZ_SYM(AllReduce, ncclAllReduce)
+    THZ_SYM(Broadcast, ncclBroadcast)
     THZ_SYM(Send, ncclSend)
     THZ_SYM(Recv, ncclRecv)
     THZ_SYM(GroupStart, ncclGroupStart)
@@ -476,6 +479,166 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     }
     gs->gathered = gather;
     return thz_group_sync(g);
+}
+
+// every member ends with all ranks' rows: d_send[i] (counts[rank_i] floats) -> d_recv[i] + offset(rank), in rank order
+static int group_all_gather(thz_group *g, const float *const *d_send, const size_t *counts, float *const *d_recv)
+{
+    std::vector<size_t> off((size_t)g->world + 1, 0);
+    for (int q = 0; q < g->world; ++q) off[(size_t)q + 1] = off[(size_t)q] + counts[q];
+    if (g->same_device || g->world == 1) {
+        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
+        if (g->world > 1)
+            if (int rc = join_on_first(g)) return rc;
+        for (size_t i = 0; i < g->m.size(); ++i)
+            for (size_t k = 0; k < g->m.size(); ++k) {
+                const size_t q = (size_t)g->m[k].rank;
+                if (counts[q])
+                    GHIP_TRY(g, hipMemcpyAsync(d_recv[i] + off[q], d_send[k], counts[q] * sizeof(float), hipMemcpyDeviceToDevice,
+                                               g->m[0].ctx->stream));
+            }
+        return g->world > 1 ? fan_out_from_first(g) : THZ_OK;
+    }
+    Rccl &r = rccl();
+    NCCL_TRY(g, r.GroupStart());
+    ncclResult_t rc = ncclSuccess;
+    for (size_t i = 0; i < g->m.size() && rc == ncclSuccess; ++i)
+        for (int q = 0; q < g->world && rc == ncclSuccess; ++q)
+            if (counts[q])
+                rc = r.Broadcast(g->m[i].rank == q ? d_send[i] : nullptr, d_recv[i] + off[(size_t)q], counts[q], ncclFloat, q,
+                                 g->m[i].comm, g->m[i].ctx->stream);
+    if (rc != ncclSuccess) {
+        (void)r.GroupEnd();
+        return gfail(g, THZ_ERR_HIP, std::string("ncclBroadcast: ") + r.GetErrorString(rc));
+    }
+    NCCL_TRY(g, r.GroupEnd());
+    return THZ_OK;
+}
+
+int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, const thz_deconv_cfg *cfg,
+                                 volatile const int *abort_flag, float *progress)
+{
+    if (!gs || !psf || !cfg) return THZ_ERR_INVALID;
+    thz_group *g = gs->g;
+    const size_t nl = gs->sess.size();
+    for (thz_session *s : gs->sess)
+        if (!s->have_outputs) return gfail(g, THZ_ERR_NOT_READY, "thz_group_session_deconvolve: no recompute has run");
+    const size_t nt = gs->nt_out, cube = gs->nx * gs->ny * nt;
+    // Richardson-Lucy is spatially global per band: every member needs the whole "Time Band Pass" output
+    std::vector<float *> full(nl, nullptr), out(nl, nullptr), flag(nl, nullptr);
+    std::vector<const float *> send(nl);
+    std::vector<size_t> counts((size_t)g->world);
+    for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->rows[(size_t)q] * gs->ny * nt;
+    auto cleanup = [&]() {
+        for (size_t i = 0; i < nl; ++i) {
+            (void)hipSetDevice(g->m[i].ctx->device);
+            (void)hipStreamSynchronize(g->m[i].ctx->stream);
+            if (full[i]) (void)hipFree(full[i]);
+            if (out[i]) (void)hipFree(out[i]);
+            if (flag[i]) (void)hipFree(flag[i]);
+        }
+    };
+    for (size_t i = 0; i < nl; ++i) {
+        GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+        if (hipMalloc((void **)&full[i], cube * sizeof(float)) != hipSuccess || hipMalloc((void **)&out[i], cube * sizeof(float)) != hipSuccess
+            || hipMalloc((void **)&flag[i], sizeof(float)) != hipSuccess) {
+            cleanup();
+            return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: allocation of the whole cube failed");
+        }
+        send[i] = gs->sess[i]->d_data;   // the stage's input is always the Time Band Pass output
+    }
+    if (int rc = group_all_gather(g, send.data(), counts.data(), full.data())) { cleanup(); return rc; }
+    if (int rc = thz_group_sync(g)) { cleanup(); return rc; }
+    // bands [b0, b1) of rank r: the slab rule applied to the bank; the members of this process run side by side
+    std::vector<int> rcs(nl, THZ_OK);
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nl; ++i)
+            th.emplace_back([&, i]() {
+                thz_deconv_cfg c = *cfg;
+                size_t b0 = 0, nb = 0;
+                (void)thz_host_slab(cfg->n_filters, g->world, g->m[i].rank, &b0, &nb);
+                c.band_begin = (uint32_t)b0;
+                c.band_end = (uint32_t)(b0 + nb);
+                if (g->world == 1) c.band_begin = c.band_end = 0;
+                thz_ctx *ctx = g->m[i].ctx;
+                thz_session *s = gs->sess[i];
+                if (ctx->time.size() != nt || std::memcmp(ctx->time.data(), s->time_out.data(), nt * sizeof(float)) != 0)
+                    if (int rc = thz_set_time_axis(ctx, s->time_out.data(), nt)) { rcs[i] = rc; return; }
+                rcs[i] = thz_deconvolve(ctx, psf, &c, gs->nx, gs->ny, s->dx, s->dy, full[i], out[i], nullptr, nullptr, abort_flag,
+                                        i == 0 ? progress : nullptr);
+            });
+        for (auto &t : th) t.join();
+    }
+    // agree on the outcome: an abort or an error seen by any rank makes every rank pass the input through
+    // (thz_deconvolve's own pass-through already adds up when ALL ranks took it: guards are rank-independent)
+    bool all_skipped = true;
+    for (size_t i = 0; i < nl; ++i)
+        if (rcs[i] != THZ_SKIPPED) all_skipped = false;
+    bool any_bad = false;
+    {
+        for (size_t i = 0; i < nl; ++i) {   // one float per member: 1 where the call failed or was aborted; summed over the group
+            GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+            const float v = rcs[i] < 0 ? 1.0f : 0.0f;
+            GHIP_TRY(g, hipMemcpyAsync(flag[i], &v, sizeof v, hipMemcpyHostToDevice, g->m[i].ctx->stream));
+            GHIP_TRY(g, hipStreamSynchronize(g->m[i].ctx->stream));
+        }
+        if (int rc = thz_group_all_reduce_sum(g, flag.data(), 1)) { cleanup(); return rc; }
+        float v = 0.0f;
+        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
+        GHIP_TRY(g, hipMemcpyAsync(&v, flag[0], sizeof v, hipMemcpyDeviceToHost, g->m[0].ctx->stream));
+        GHIP_TRY(g, hipStreamSynchronize(g->m[0].ctx->stream));
+        any_bad = v != 0.0f;
+    }
+    int status = all_skipped ? THZ_SKIPPED : THZ_OK;
+    if (any_bad) {
+        for (size_t i = 0; i < nl; ++i) {
+            GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+            if (g->m[i].rank == 0) GHIP_TRY(g, hipMemcpyAsync(out[i], full[i], cube * sizeof(float), hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
+            else GHIP_TRY(g, hipMemsetAsync(out[i], 0, cube * sizeof(float), g->m[i].ctx->stream));
+        }
+        status = THZ_ERR_ABORTED;
+        for (size_t i = 0; i < nl; ++i)
+            if (rcs[i] < 0 && rcs[i] != THZ_ERR_ABORTED) status = rcs[i];
+    }
+    // C2 of the band sums: every member ends with the whole deconvolved cube, keeps its own rows
+    if (int rc = thz_group_all_reduce_sum(g, out.data(), cube)) { cleanup(); return rc; }
+    for (size_t i = 0; i < nl; ++i) {
+        thz_session *s = gs->sess[i];
+        thz_ctx *ctx = g->m[i].ctx;
+        GHIP_TRY(g, hipSetDevice(ctx->device));
+        const size_t q = (size_t)g->m[i].rank, n = counts[q], npix = gs->rows[q] * gs->ny;
+        if (s->deconv_floats != n) {
+            if (s->d_deconv) { (void)hipFree(s->d_deconv); s->d_deconv = nullptr; }
+            if (s->d_deconv_img) { (void)hipFree(s->d_deconv_img); s->d_deconv_img = nullptr; }
+            s->deconv_floats = 0;
+            if (hipMalloc((void **)&s->d_deconv, n * sizeof(float)) != hipSuccess
+                || hipMalloc((void **)&s->d_deconv_img, npix * sizeof(float)) != hipSuccess) {
+                cleanup();
+                return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: slab allocation failed");
+            }
+            s->deconv_floats = n;
+        }
+        GHIP_TRY(g, hipMemcpyAsync(s->d_deconv, out[i] + gs->x0[q] * gs->ny * nt, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (int rc = thz_intensity(ctx, npix, s->d_deconv, s->d_deconv_img)) { cleanup(); return gfail(g, rc, thz_last_error(ctx)); }
+        s->deconv_current = status >= 0;
+    }
+    // C1: the new image (and, if the last recompute gathered it, the new final cube) to rank 0
+    {
+        std::vector<const float *> im;
+        std::vector<size_t> ic((size_t)g->world);
+        for (int q = 0; q < g->world; ++q) ic[(size_t)q] = gs->rows[(size_t)q] * gs->ny;
+        for (thz_session *s : gs->sess) im.push_back(s->deconv_current ? s->d_deconv_img : s->d_img);
+        if (int rc = thz_group_gather(g, im.data(), ic.data(), gs->d_img)) { cleanup(); return rc; }
+        if (gs->gathered >= THZ_GATHER_TIME && gs->root_local >= 0) {
+            GHIP_TRY(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
+            GHIP_TRY(g, hipMemcpyAsync(gs->d_data, out[(size_t)gs->root_local], cube * sizeof(float), hipMemcpyDeviceToDevice,
+                                       g->m[(size_t)gs->root_local].ctx->stream));
+        }
+    }
+    cleanup();
+    if (status < 0) return gfail(g, status, "thz_group_session_deconvolve: aborted or failed on a rank; the stage passes its input through");
+    return status;
 }
 
 void *thz_group_session_result(thz_group_session *gs, int which)
