@@ -81,10 +81,17 @@ def test_config3_resolution_target_full_chain_with_water_line_filter(engine):
         k_line = int(np.argmin(np.abs(freq - 1.0974)))      # 1.097 THz water line
         assert np.abs(got_fft[:, :, k_line]).max() < 0.05 * np.abs(got_fft).max()
         # pixel means of the ifft stage (fast form: sums + linearity) against the reference's summation order
-        for which, ncomp, key in ((pkg.BUF_AVG_FFT, 2, "fft"), (pkg.BUF_AVG_AMPLITUDES, 1, "amplitudes"),
-                                  (pkg.BUF_AVG_PHASES, 1, "phases")):
+        for which, ncomp, key in ((pkg.BUF_AVG_FFT, 2, "fft"), (pkg.BUF_AVG_AMPLITUDES, 1, "amplitudes")):
             want = ob.pixel_mean(ref[key], ncomp)
             assert rel(sess.download(which), want) < TOL
+        # mean unwrapped phase: a 2 pi decision flip on a noise bin of ONE trace (tolerated above, and unpinned by
+        # the reference itself) moves the mean by 2 pi / 16 384, so the oracle's mean is only good to the flips it
+        # took; the device's mean must be the mean of the device's own phases
+        got_ph = sess.download(pkg.BUF_PHASES).astype(np.float64)
+        assert rel(sess.download(pkg.BUF_AVG_PHASES), got_ph.mean(0)) < 2e-6
+        flips = np.abs(np.round((got_ph.reshape(nx, ny, nf) - ref["phases"]) / (2 * np.pi))).mean(axis=(0, 1))
+        assert np.all(np.abs(sess.download(pkg.BUF_AVG_PHASES) - ob.pixel_mean(ref["phases"], 1))
+                      <= 2 * np.pi * flips + 1e-5 * np.abs(ref["phases"]).max())
     finally:
         sess.close()
 

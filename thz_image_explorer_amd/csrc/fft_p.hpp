@@ -170,24 +170,28 @@ struct PAddr {
     int t2[P::RD2];  // pass 2: j3
     int b3[P::RD3];  // pass 3: k1 M1 + R3 k2 (butterfly b = k1 + R1 k2)
     int o3[P::RD3];  // pass 3: b
+    // A lane without a butterfly in a pass's last round works on the butterfly it already finished in round 0
+    // (its own, so nobody else is writing there) and does not store: no lane ever reads what another lane writes
+    // in the same round — true on the GPU by lock-step anyway, and what keeps the emulation ThreadSanitizer-clean.
     __device__ __forceinline__ void init(int lane)
     {
+        static_assert(P::B1 >= kWave && P::B2 >= kWave && P::B3 >= kWave, "round 0 is full in every pass");
 #pragma unroll
         for (int i = 0; i < P::RD1; ++i) {
             const int b = lane + kWave * i;
-            b1[i] = b < P::B1 ? b : P::B1 - 1;
+            b1[i] = b < P::B1 ? b : lane;
         }
 #pragma unroll
         for (int i = 0; i < P::RD2; ++i) {
             int b = lane + kWave * i;
-            b = b < P::B2 ? b : P::B2 - 1;
+            b = b < P::B2 ? b : lane;
             b2[i] = (b / P::R3) * P::M1 + b % P::R3;
             t2[i] = b % P::R3;
         }
 #pragma unroll
         for (int i = 0; i < P::RD3; ++i) {
             int b = lane + kWave * i;
-            b = b < P::B3 ? b : P::B3 - 1;
+            b = b < P::B3 ? b : lane;
             b3[i] = (b % P::R1) * P::M1 + P::R3 * (b / P::R1);
             o3[i] = b;
         }
