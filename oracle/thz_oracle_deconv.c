@@ -391,12 +391,16 @@ void thz_oracle_filter_scan(const float *data, size_t npix, int nt, const float 
 /* deconvolution.rs:432-458 verbatim (correlation-indexed, zero outside) */
 /* Rows of the output are independent and every pixel keeps the reference's own summation order (m outer,
  * n inner, one f32 chain), so the OpenMP split over rows changes no bit of the result — it only lets the
- * reference's defaults (500 iterations, 47 x 57 taps) finish in seconds on the test box. */
+ * reference's defaults (500 iterations, 47 x 57 taps) finish in seconds on the test box.  The team size is set
+ * by the caller (thz_oracle_set_conv_threads): these loops run a thousand times per call, and a team of every
+ * hardware thread of a 256-thread host inside a 16-CPU container spends its time in barriers. */
+static int g_conv_threads = 8;
+void thz_oracle_set_conv_threads(int n) { g_conv_threads = n > 0 ? n : 1; }
 static void direct_convolve2d(const float *a, int ar, int ac, const float *b, int br, int bc, float *res)
 {
     int hr = br / 2, hc = bc / 2;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_conv_threads)
 #endif
     for (int i = 0; i < ar; ++i)
         for (int j = 0; j < ac; ++j) {
@@ -416,7 +420,7 @@ static void same_convolve2d(const float *a, int ar, int ac, const float *b, int 
 {
     int sr = (br - 1) / 2, sc = (bc - 1) / 2;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_conv_threads)
 #endif
     for (int i = 0; i < ar; ++i)
         for (int j = 0; j < ac; ++j) {

@@ -23,8 +23,22 @@ def lib():
         L.thz_oracle_blackman_window.restype = C.c_float
         L.thz_oracle_blackman_window.argtypes = [C.c_float, C.c_float]
         L.thz_oracle_ifft_stage.restype = C.c_long
+        L.thz_oracle_set_conv_threads(C.c_int(cpu_share()))
         _lib = L
     return _lib
+
+
+def cpu_share(cap=16):
+    """CPUs this process may really use: affinity mask and cgroup quota (a GPU box hands a 16-CPU share of a
+    256-thread host to the job), capped"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
 
 
 def _p(a):
