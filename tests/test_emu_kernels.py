@@ -141,13 +141,15 @@ def test_chirpz_pipeline_vs_oracle(emu, nt):
     assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))[strong].max() < 3e-3
 
 
-@pytest.mark.parametrize("nt,npix_shape", [(1001, (5, 1)), (1001, (2, 3)), (1000, (5, 1)), (1000, (3, 6))])
-def test_mixed_radix_pipeline_vs_oracle(emu, nt, npix_shape):
+@pytest.mark.parametrize("pairs", [1, 2])
+@pytest.mark.parametrize("nt,npix_shape", [(1001, (5, 1)), (1001, (2, 3)), (1001, (1, 1)), (1001, (7, 1)), (1000, (5, 1)), (1000, (3, 6))])
+def test_mixed_radix_pipeline_vs_oracle(emu, nt, npix_shape, pairs):
     """P kernels (fft_p.hpp): nt = 1001 = 7 x 11 x 13 (the length of real scans) and 1000 = 10 x 10 x 10 as one
     direct three-pass mixed-radix transform per pair of traces; odd and even trace counts, more pairs than one
     block has waves"""
     emu.emu_allow_f(1)
     emu.emu_allow_p(1)
+    emu.emu_set_p_pairs(pairs)   # one or two pairs of traces per wave: units of 2 or 4 traces, ragged last unit
     assert emu.emu_family(nt) == 6
     nx, ny = npix_shape
     time = synth.make_time(nt)
@@ -464,3 +466,31 @@ def test_forward_inverse_with_store_barriers(emu, nt):
     for a, b in zip(res[0], res[3]):
         assert np.array_equal(a, b)
     assert np.abs(res[0][3]).max() > 0
+
+
+@pytest.mark.parametrize("nt", [1001, 1000])
+def test_mixed_radix_stage_kernels_two_pairs_per_wave(emu, nt):
+    """k_p<fwd> / k_p<inv> with two pairs of traces per wave == with one (same butterflies, dealt differently),
+    for a trace count that leaves the last unit with 1, 2 or 3 of its 4 traces"""
+    emu.emu_allow_f(1); emu.emu_allow_p(1)
+    time = synth.make_time(nt)
+    wa = ob.apply_window(0, np.ones(nt, np.float32), time, 1.0, 7.0)
+    mask = ob.fd_bandpass_window(ob.frequency_axis(time), 0.2, 5.0, 0.1)[0]
+    win = ob.td_bandpass_window(time, float(time[0]), float(time[-1]), 0.1)[0]
+    try:
+        for npix in (9, 10, 11):
+            x = np.ascontiguousarray(synth.make_traces(np.arange(npix) + 3, max(nt, 1024))[:, :nt], np.float32)
+            res = {}
+            for q in (1, 2):
+                emu.emu_set_p_pairs(q)
+                fft = np.zeros((npix, nt // 2 + 1, 2), np.float32); amp = np.zeros((npix, nt // 2 + 1), np.float32)
+                ph = np.zeros_like(amp)
+                assert emu.emu_fft_fwd(nt, C.c_size_t(npix), _p(x), _p(wa), None, None, _p(fft), _p(amp), _p(ph), _p(mask)) == 0
+                out = np.zeros_like(x); img = np.zeros(npix, np.float32)
+                assert emu.emu_fft_inv(nt, C.c_size_t(npix), _p(fft), _p(win), _p(out), _p(img)) == 0
+                res[q] = (fft, amp, ph, out, img)
+            for a, b in zip(res[1], res[2]):
+                assert np.array_equal(a, b)
+            assert np.abs(res[1][3]).max() > 0
+    finally:
+        emu.emu_set_p_pairs(0)

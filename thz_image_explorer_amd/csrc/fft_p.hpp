@@ -147,13 +147,14 @@ struct PPlan {
     // LDS per block: [T1: N cx, [k1][m]][T2: R2 R3 cx, [k2][j3]][mask nf][pre N][post N] floats, [per wave: N cx (+pad)]
     static constexpr int T1_ENTRIES = N, T2_ENTRIES = M1 + (M1 & 1);
     static constexpr int WAVE_ENTRIES = N + (N & 1);
-    static constexpr size_t lds_bytes(int waves)
+    static constexpr size_t lds_bytes(int waves, int pairs_per_wave = 1)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx)
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + waves * pairs_per_wave * WAVE_ENTRIES) * sizeof(cx)
                + (size_t)(pad4(NF) + 2 * pad4(N)) * sizeof(float);
     }
 };
 
+constexpr int kPPairsDefault = 1;  // pairs of traces per wave unless THZ_P_PAIRS says otherwise
 using PPlan1001 = PPlan<7, 11, 13>;
 using PPlan1000 = PPlan<10, 10, 10>;
 
@@ -162,73 +163,91 @@ struct PTables {
     const cx *t2;  // [k2][j3] W_(R2 R3)^(j3 k2),    R2 R3 entries
 };
 
-// lane -> butterfly maps of the three passes (trace-invariant; kept per round as LDS base indices)
-template <class P>
+// lane -> butterfly maps of the three passes (trace-invariant; kept per round as LDS base indices).
+// Q pairs of traces share a wave (Q = 1 or 2): their Q N / R butterflies of a pass are dealt to the lanes as ONE
+// list — pair q's transform lives in the wave's q-th buffer — so that the last round of a pass is fuller
+// (1001 = 7 x 11 x 13: 143 / 91 / 77 butterflies are 3 / 2 / 2 rounds for one pair, 286 / 182 / 154 are 5 / 3 / 3
+// for two: a quarter fewer radix-R butterflies issued per transform).
+template <class P, int Q>
 struct PAddr {
-    int b1[P::RD1];  // pass 1: m            (butterfly m = lane + 64 round), clamped
-    int b2[P::RD2];  // pass 2: k1 M1 + j3   (butterfly b = k1 R3 + j3)
-    int t2[P::RD2];  // pass 2: j3
-    int b3[P::RD3];  // pass 3: k1 M1 + R3 k2 (butterfly b = k1 + R1 k2)
-    int o3[P::RD3];  // pass 3: b
+    static constexpr int RD1 = P::rounds(Q * P::B1), RD2 = P::rounds(Q * P::B2), RD3 = P::rounds(Q * P::B3);
+    int m1[RD1];   // pass 1: m of the butterfly                         (table / window index)
+    int g1[RD1];   // pass 1: global sample offset (2 q N + m), floats from the unit's first trace
+    int l1[RD1];   // pass 1: LDS base q WE + m
+    int b2[RD2];   // pass 2: q WE + k1 M1 + j3   (butterfly b = k1 R3 + j3)
+    int t2[RD2];   // pass 2: j3
+    int b3[RD3];   // pass 3: q WE + k1 M1 + R3 k2 (butterfly b = k1 + R1 k2)
+    int o3[RD3];   // pass 3: q WE + b
     // A lane without a butterfly in a pass's last round works on the butterfly it already finished in round 0
     // (its own, so nobody else is writing there) and does not store: no lane ever reads what another lane writes
     // in the same round — true on the GPU by lock-step anyway, and what keeps the emulation ThreadSanitizer-clean.
     __device__ __forceinline__ void init(int lane)
     {
         static_assert(P::B1 >= kWave && P::B2 >= kWave && P::B3 >= kWave, "round 0 is full in every pass");
+        constexpr int WE = P::WAVE_ENTRIES;
 #pragma unroll
-        for (int i = 0; i < P::RD1; ++i) {
-            const int b = lane + kWave * i;
-            b1[i] = b < P::B1 ? b : lane;
+        for (int i = 0; i < RD1; ++i) {
+            int b = lane + kWave * i;
+            b = b < Q * P::B1 ? b : lane;
+            const int q = b / P::B1, m = b % P::B1;
+            m1[i] = m;
+            g1[i] = 2 * q * P::N + m;
+            l1[i] = q * WE + m;
         }
 #pragma unroll
-        for (int i = 0; i < P::RD2; ++i) {
+        for (int i = 0; i < RD2; ++i) {
             int b = lane + kWave * i;
-            b = b < P::B2 ? b : lane;
-            b2[i] = (b / P::R3) * P::M1 + b % P::R3;
+            b = b < Q * P::B2 ? b : lane;
+            const int q = b / P::B2;
+            b -= q * P::B2;
+            b2[i] = q * WE + (b / P::R3) * P::M1 + b % P::R3;
             t2[i] = b % P::R3;
         }
 #pragma unroll
-        for (int i = 0; i < P::RD3; ++i) {
+        for (int i = 0; i < RD3; ++i) {
             int b = lane + kWave * i;
-            b = b < P::B3 ? b : lane;
-            b3[i] = (b % P::R1) * P::M1 + P::R3 * (b / P::R1);
-            o3[i] = b;
+            b = b < Q * P::B3 ? b : lane;
+            const int q = b / P::B3;
+            b -= q * P::B3;
+            b3[i] = q * WE + (b % P::R1) * P::M1 + P::R3 * (b / P::R1);
+            o3[i] = q * WE + b;
         }
     }
     __device__ __forceinline__ void refresh()
     {
 #pragma unroll
-        for (int i = 0; i < P::RD1; ++i) b1[i] = launder_v(b1[i]);
+        for (int i = 0; i < RD1; ++i) { m1[i] = launder_v(m1[i]); g1[i] = launder_v(g1[i]); l1[i] = launder_v(l1[i]); }
 #pragma unroll
-        for (int i = 0; i < P::RD2; ++i) { b2[i] = launder_v(b2[i]); t2[i] = launder_v(t2[i]); }
+        for (int i = 0; i < RD2; ++i) { b2[i] = launder_v(b2[i]); t2[i] = launder_v(t2[i]); }
 #pragma unroll
-        for (int i = 0; i < P::RD3; ++i) { b3[i] = launder_v(b3[i]); o3[i] = launder_v(o3[i]); }
+        for (int i = 0; i < RD3; ++i) { b3[i] = launder_v(b3[i]); o3[i] = launder_v(o3[i]); }
     }
 };
 
-// pass 1 of one round: v[j1] holds z[M1 j1 + m]; writes y[k1][m] W_N^(m k1) to buf[k1 M1 + m]
+// pass 1 of one round: v[j1] holds z[M1 j1 + m]; writes y[k1][m] W_N^(m k1) to buf[lb + k1 M1], lb = q WE + m
 template <class P>
-__device__ __forceinline__ void p_pass1_round(cx (&v)[P::R1], cx *buf, const cx *t1, int m, bool on)
+__device__ __forceinline__ void p_pass1_round(cx (&v)[P::R1], cx *buf, const cx *t1, int m, int lb, bool on)
 {
     PDft<P::R1>::run(v);
     if (on) {
-        buf[m] = v[0];
+        buf[lb] = v[0];
 #pragma unroll
-        for (int k1 = 1; k1 < P::R1; ++k1) buf[k1 * P::M1 + m] = cx_mul(v[k1], t1[k1 * P::M1 + m]);
+        for (int k1 = 1; k1 < P::R1; ++k1) buf[lb + k1 * P::M1] = cx_mul(v[k1], t1[k1 * P::M1 + m]);
     }
 }
 
-// passes 2 and 3 on buf; leaves the natural-order transform in buf[0 .. N).  Ends with wave_sync().
-template <class P>
-__device__ __forceinline__ void p_pass23(cx *buf, const cx *t2, const PAddr<P> &ad, int lane)
+// passes 2 and 3 on the wave's Q buffers; leaves the natural-order transforms in buf[q WE + 0 .. N).
+// Ends with wave_sync().
+template <class P, int Q>
+__device__ __forceinline__ void p_pass23(cx *buf, const cx *t2, const PAddr<P, Q> &ad, int lane)
 {
     constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3;
+    constexpr int RD2 = PAddr<P, Q>::RD2, RD3 = PAddr<P, Q>::RD3;
     wave_sync();
     // ---- pass 2: butterfly (k1, j3), elements k1 M1 + R3 j2 + j3, in place
 #pragma unroll
-    for (int i = 0; i < P::RD2; ++i) {
-        const bool on = lane + kWave * i < P::B2;
+    for (int i = 0; i < RD2; ++i) {
+        const bool on = lane + kWave * i < Q * P::B2;
         cx v[R2];
 #pragma unroll
         for (int j2 = 0; j2 < R2; ++j2) v[j2] = buf[ad.b2[i] + R3 * j2];
@@ -243,16 +262,16 @@ __device__ __forceinline__ void p_pass23(cx *buf, const cx *t2, const PAddr<P> &
     wave_sync();
     // ---- pass 3: butterfly (k1, k2), elements k1 M1 + R3 k2 + j3 -> X[k1 + R1 k2 + R1 R2 k3]: every
     // round's inputs are read before any output is written (outputs land in other butterflies' inputs)
-    cx d[P::RD3][R3];
+    cx d[RD3][R3];
 #pragma unroll
-    for (int i = 0; i < P::RD3; ++i) {
+    for (int i = 0; i < RD3; ++i) {
 #pragma unroll
         for (int j3 = 0; j3 < R3; ++j3) d[i][j3] = buf[ad.b3[i] + j3];
     }
     wave_sync();
 #pragma unroll
-    for (int i = 0; i < P::RD3; ++i) {
-        const bool on = lane + kWave * i < P::B3;
+    for (int i = 0; i < RD3; ++i) {
+        const bool on = lane + kWave * i < Q * P::B3;
         PDft<R3>::run(d[i]);
         if (on) {
 #pragma unroll
@@ -270,19 +289,21 @@ __device__ __forceinline__ float p_zero_if(float v, bool zero)
     return __builtin_bit_cast(float, bits);
 }
 
-// Same argument block as the chirp-z kernels (w / bf unused)
-template <class P, int MODE>
-__global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
+// Same argument block as the chirp-z kernels (w / bf unused).  A wave takes Q consecutive pairs (a "unit" of
+// 2 Q traces) per trip.
+template <class P, int MODE, int Q>
+__global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 {
     THZ_DYN_LDS(lds);
-    constexpr int N = P::N, NF = P::NF, R1 = P::R1, M1 = P::M1;
+    constexpr int N = P::N, NF = P::NF, R1 = P::R1, M1 = P::M1, WE = P::WAVE_ENTRIES;
+    constexpr int RD1 = PAddr<P, Q>::RD1;
     const int lane = lane_id();
     const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     cx *t1 = reinterpret_cast<cx *>(lds);
     cx *t2 = t1 + P::T1_ENTRIES;
-    cx *buf = t2 + P::T2_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
-    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES);
+    cx *buf = t2 + P::T2_ENTRIES + (size_t)wib * (Q * WE);
+    float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * (Q * WE));
     float *pre_s = mask_s + P::pad4(NF);
     float *post_s = pre_s + P::pad4(N);
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
@@ -294,16 +315,15 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
     }
     __syncthreads();
 
-    PAddr<P> ad;
+    PAddr<P, Q> ad;
     ad.init(lane);
     const float fnt = (float)N;
     constexpr int n_groups = (NF + 255) / 256;  // epilogue groups of 256 bins: bin = 256 g + 4 lane + c
-    const size_t n_pairs = (A.npix + 1) / 2;
+    const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
     const size_t stride = (size_t)gridDim.x * wpb;
 
-    for (size_t q = (size_t)blockIdx.x * wpb + wib; q < n_pairs; q += stride) {
-        const size_t p = 2 * q;
-        const bool has2 = p + 1 < A.npix;  // wave-uniform
+    for (size_t u = (size_t)blockIdx.x * wpb + wib; u < n_units; u += stride) {
+        const size_t p0 = 2 * Q * u;  // first trace of the unit
         ad.refresh();
         const cx *t1l = launder_uniform((const cx *)t1);
         const cx *t2l = launder_uniform((const cx *)t2);
@@ -311,39 +331,50 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
         const float *post_l = launder_uniform((const float *)post_s);
         const float *mask_l = launder_uniform((const float *)mask_s);
         const int lb4 = launder_v(4 * lane), lb1 = launder_v(lane);
+        // traces of the unit that exist (wave-uniform): n_tr in 1 .. 2 Q
+        const int n_tr = (int)((A.npix - p0) < (size_t)(2 * Q) ? (A.npix - p0) : (size_t)(2 * Q));
 
         if constexpr (MODE != kInv) {
-            // ---- pass 1 from memory: z[n] = (x1[n] + i x2[n]) pre[n], n = M1 j1 + m; a round's loads
-            // are issued together (clamped indices, predicated stores)
-            const float *x1 = A.in + p * (size_t)N;
-            const float *x2 = has2 ? x1 + N : x1;
-            // every round's loads are issued before the first butterfly: one trip to HBM per pair, not one per round
-            float xa[P::RD1][R1], xb[P::RD1][R1];
+            // ---- pass 1 from memory: z[n] = (x1[n] + i x2[n]) pre[n], n = M1 j1 + m.  Every round's loads are
+            // issued before the first butterfly (one trip to HBM per unit); a trace that does not exist is read
+            // from the unit's first trace instead (in bounds) and enters as zero
+            const float *x0 = A.in + p0 * (size_t)N;
+            float xa[RD1][R1], xb[RD1][R1];
 #pragma unroll
-            for (int i = 0; i < P::RD1; ++i) {
+            for (int i = 0; i < RD1; ++i) {
+                const int q2 = 2 * (ad.g1[i] / (2 * N));  // first trace of this butterfly's pair within the unit
+                const unsigned ga = (unsigned)(q2 < n_tr ? ad.g1[i] : ad.m1[i]);
+                const unsigned gb = (unsigned)(q2 + 1 < n_tr ? ad.g1[i] + N : ad.m1[i]);
 #pragma unroll
                 for (int j1 = 0; j1 < R1; ++j1) {
-                    xa[i][j1] = ld_off(x1, (unsigned)(M1 * j1 + ad.b1[i]));
-                    xb[i][j1] = ld_off(x2, (unsigned)(M1 * j1 + ad.b1[i]));
+                    xa[i][j1] = ld_off(x0, ga + (unsigned)(M1 * j1));
+                    xb[i][j1] = ld_off(x0, gb + (unsigned)(M1 * j1));
                 }
             }
 #pragma unroll
-            for (int i = 0; i < P::RD1; ++i) {
-                const bool on = lane + kWave * i < P::B1;
-                const int m = ad.b1[i];
+            for (int i = 0; i < RD1; ++i) {
+                const bool on = lane + kWave * i < Q * P::B1;
+                const int m = ad.m1[i];
+                const int q2 = 2 * (ad.g1[i] / (2 * N));
+                const float sa = q2 < n_tr ? 1.0f : 0.0f, sb = q2 + 1 < n_tr ? 1.0f : 0.0f;
                 cx v[R1];
 #pragma unroll
                 for (int j1 = 0; j1 < R1; ++j1) {
                     const float pw = pre_l[M1 * j1 + m];
-                    v[j1] = cx{xa[i][j1] * pw, has2 ? xb[i][j1] * pw : 0.0f};
+                    v[j1] = cx{xa[i][j1] * (pw * sa), xb[i][j1] * (pw * sb)};
                 }
-                p_pass1_round<P>(v, buf, t1l, m, on);
+                p_pass1_round<P>(v, buf, t1l, m, ad.l1[i], on);
                 THZ_SCHED_FENCE();
             }
-            p_pass23<P>(buf, t2l, ad, lane);  // buf[k] = Z[k] = X1[k] + i X2[k]
+            p_pass23<P, Q>(buf, t2l, ad, lane);  // buf[q WE + k] = Z_q[k] = X1[k] + i X2[k] of pair q
 
-            // ---- spectrum epilogue: X1 = (Z[k] + conj Z[N-k]) / 2, X2 = (Z[k] - conj Z[N-k]) / 2i
-            {
+            // ---- spectrum epilogue, pair by pair: X1 = (Z[k] + conj Z[N-k]) / 2, X2 = (Z[k] - conj Z[N-k]) / 2i
+#pragma unroll 1
+            for (int q = 0; q < Q; ++q) {
+                if (2 * q >= n_tr) break;  // wave-uniform
+                const size_t p = p0 + 2 * (size_t)q;
+                const bool has2 = 2 * q + 1 < n_tr;
+                cx *bq = buf + q * WE;
                 FBUnwrap u1, u2;
 #pragma unroll 1
                 for (int g = 0; g < n_groups; ++g) {
@@ -359,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
                         const int kc = ok[c] ? k : NF - 1;
                         const int km = kc == 0 ? 0 : N - kc;  // Z[N] = Z[0]
                         kcs[c] = kc;
-                        const cx Fk = buf[kc], Fm = buf[km];
+                        const cx Fk = bq[kc], Fm = bq[km];
                         X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
                         X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
                         m[c] = mask_l[kc];
@@ -387,8 +418,8 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
                             if (ok[c]) {
                                 const cx y1 = cx{X1[c].x * m[c], X1[c].y * m[c]}, y2 = cx{X2[c].x * m[c], X2[c].y * m[c]};
                                 const int kc = kcs[c];
-                                buf[kc] = cx{y1.x - y2.y, -y1.y - y2.x};
-                                if (kc != 0 && 2 * kc != N) buf[N - kc] = cx{y1.x + y2.y, y1.y - y2.x};
+                                bq[kc] = cx{y1.x - y2.y, -y1.y - y2.x};
+                                if (kc != 0 && 2 * kc != N) bq[N - kc] = cx{y1.x + y2.y, y1.y - y2.x};
                             }
                     }
                 }
@@ -397,16 +428,21 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
         } else {
             // inverse only: conj(G) from the two spectra in memory; DC (and Nyquist for even N) imaginary
             // parts are ignored like realfft's C2R does
-            const cx *f1 = A.fft_in + p * (size_t)NF;
-            for (int k = lb1; k < NF; k += kWave) {
-                cx y1 = ld_off(f1, (unsigned)k);
-                cx y2 = has2 ? ld_off(f1, (unsigned)(NF + k)) : cx{0.0f, 0.0f};
-                if (k == 0 || ((N & 1) == 0 && k == NF - 1)) {
-                    y1.y = 0.0f;
-                    y2.y = 0.0f;
+#pragma unroll 1
+            for (int q = 0; q < Q; ++q) {
+                const bool live = 2 * q < n_tr, has2 = 2 * q + 1 < n_tr;
+                const cx *f1 = A.fft_in + (p0 + (live ? 2 * (size_t)q : 0)) * (size_t)NF;
+                cx *bq = buf + q * WE;
+                for (int k = lb1; k < NF; k += kWave) {
+                    cx y1 = ld_off(f1, (unsigned)k);
+                    cx y2 = has2 ? ld_off(f1, (unsigned)(NF + k)) : cx{0.0f, 0.0f};
+                    if (k == 0 || ((N & 1) == 0 && k == NF - 1)) {
+                        y1.y = 0.0f;
+                        y2.y = 0.0f;
+                    }
+                    bq[k] = cx{y1.x - y2.y, -y1.y - y2.x};
+                    if (k != 0 && 2 * k != N) bq[N - k] = cx{y1.x + y2.y, y1.y - y2.x};
                 }
-                buf[k] = cx{y1.x - y2.y, -y1.y - y2.x};
-                if (k != 0 && 2 * k != N) buf[N - k] = cx{y1.x + y2.y, y1.y - y2.x};
             }
             wave_sync();
         }
@@ -414,19 +450,23 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
 
         // ---- U = DFT(conj G): pass 1 in place from LDS, then passes 2 and 3
 #pragma unroll
-        for (int i = 0; i < P::RD1; ++i) {
-            const bool on = lane + kWave * i < P::B1;
-            const int m = ad.b1[i];
+        for (int i = 0; i < RD1; ++i) {
+            const bool on = lane + kWave * i < Q * P::B1;
             cx v[R1];
 #pragma unroll
-            for (int j1 = 0; j1 < R1; ++j1) v[j1] = buf[M1 * j1 + m];
-            p_pass1_round<P>(v, buf, t1l, m, on);
+            for (int j1 = 0; j1 < R1; ++j1) v[j1] = buf[ad.l1[i] + M1 * j1];
+            p_pass1_round<P>(v, buf, t1l, ad.m1[i], ad.l1[i], on);
             THZ_SCHED_FENCE();
         }
-        p_pass23<P>(buf, t2l, ad, lane);
+        p_pass23<P, Q>(buf, t2l, ad, lane);
 
         // ---- y1 = Re U / nt, y2 = -Im U / nt, each times post[n]; images = sum y^2
-        {
+#pragma unroll 1
+        for (int q = 0; q < Q; ++q) {
+            if (2 * q >= n_tr) break;  // wave-uniform
+            const size_t p = p0 + 2 * (size_t)q;
+            const bool has2 = 2 * q + 1 < n_tr;
+            const cx *bq = buf + q * WE;
             float *o1 = A.data_out + p * (size_t)N;
             float acc1 = 0.0f, acc2 = 0.0f;
             // four consecutive samples per lane: 16-byte stores (rows are only 4-byte aligned: store_f4)
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
                     float v1[4], v2[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const cx U = buf[n0 + c];
+                        const cx U = bq[n0 + c];
                         const float pw = post_l[n0 + c];
                         v1[c] = (U.x / fnt) * pw;
                         v2[c] = (-U.y / fnt) * pw;
@@ -451,7 +491,7 @@ __global__ __launch_bounds__(1024) void k_p(FBArgs A, PTables T)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
                         if (n0 + c < N) {
-                            const cx U = buf[n0 + c];
+                            const cx U = bq[n0 + c];
                             const float pw = post_l[n0 + c];
                             const float a = (U.x / fnt) * pw, b = (-U.y / fnt) * pw;
                             o1[n0 + c] = a;

@@ -162,6 +162,7 @@ int all_reduce(thz_group *g, T *const *d_bufs, size_t count, ncclDataType_t type
     Rccl &r = rccl();
     NCCL_TRY(g, r.GroupStart());
     for (size_t i = 0; i < g->m.size(); ++i) {
+        (void)hipSetDevice(g->m[i].ctx->device);  // the communicator's device is current while its call is enqueued
         ncclResult_t rc = r.AllReduce(d_bufs[i], d_bufs[i], count, type, ncclSum, g->m[i].comm, g->m[i].ctx->stream);
         if (rc != ncclSuccess) {
             (void)r.GroupEnd();
@@ -327,8 +328,10 @@ int thz_group_gather(thz_group *g, const float *const *d_send, const size_t *cou
     ncclResult_t rc = ncclSuccess;
     for (size_t i = 0; i < g->m.size() && rc == ncclSuccess; ++i) {
         const size_t q = (size_t)g->m[i].rank;
+        (void)hipSetDevice(g->m[i].ctx->device);
         if (q != 0 && counts[q]) rc = r.Send(d_send[i], counts[q], ncclFloat, 0, g->m[i].comm, g->m[i].ctx->stream);
     }
+    if (root >= 0) (void)hipSetDevice(g->m[(size_t)root].ctx->device);
     if (root >= 0)
         for (int q = 1; q < g->world && rc == ncclSuccess; ++q)
             if (counts[q])
@@ -504,7 +507,7 @@ static int group_all_gather(thz_group *g, const float *const *d_send, const size
     ncclResult_t rc = ncclSuccess;
     for (size_t i = 0; i < g->m.size() && rc == ncclSuccess; ++i)
         for (int q = 0; q < g->world && rc == ncclSuccess; ++q)
-            if (counts[q])
+            if (counts[q] && hipSetDevice(g->m[i].ctx->device) == hipSuccess)
                 rc = r.Broadcast(g->m[i].rank == q ? d_send[i] : nullptr, d_recv[i] + off[(size_t)q], counts[q], ncclFloat, q,
                                  g->m[i].comm, g->m[i].ctx->stream);
     if (rc != ncclSuccess) {

@@ -1614,20 +1614,34 @@ static void dispatch_fb(hipStream_t st, const PlanDev &P, FBArgs &A)
     }
 }
 
-// P family (fft_p.hpp): one wave per pair of traces, up to 16 waves per block share the tables
-template <class PL, int MODE>
+// P family (fft_p.hpp): Q pairs of traces per wave (kPPairs; THZ_P_PAIRS overrides for A/B measurements), up to
+// 16 / Q waves per block share the tables
+int g_p_pairs_override = 0;  // tests (the emulation harness) select Q here
+static int p_pairs()
+{
+    if (g_p_pairs_override == 1 || g_p_pairs_override == 2) return g_p_pairs_override;
+#ifndef THZ_EMU
+    if (const char *e = getenv("THZ_P_PAIRS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2) return v;
+    }
+#endif
+    return kPPairsDefault;
+}
+
+template <class PL, int MODE, int Q>
 static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
 {
-    unsigned waves = 16;
-    while (waves > 1 && PL::lds_bytes((int)waves) > kLdsBytesPerCU) --waves;
-    const size_t lds = PL::lds_bytes((int)waves);
-    const size_t n_pairs = (A.npix + 1) / 2;
-    size_t g = (n_pairs + waves - 1) / waves;
+    unsigned waves = 16 / Q;
+    while (waves > 1 && PL::lds_bytes((int)waves, Q) > kLdsBytesPerCU) --waves;
+    const size_t lds = PL::lds_bytes((int)waves, Q);
+    const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
+    size_t g = (n_units + waves - 1) / waves;
     if (g > (size_t)kNumCU) g = kNumCU;
     if (g < 1) g = 1;
     PTables T{reinterpret_cast<const cx *>(P.p_t1), reinterpret_cast<const cx *>(P.p_t2)};
-    allow_dynamic_lds(k_p<PL, MODE>, lds);
-    THZ_LAUNCH((k_p<PL, MODE>), (unsigned)g, waves * kWave, lds, st, A, T);
+    allow_dynamic_lds(k_p<PL, MODE, Q>, lds);
+    THZ_LAUNCH((k_p<PL, MODE, Q>), (unsigned)g, waves * kWave, lds, st, A, T);
 }
 
 template <int MODE>
@@ -1635,9 +1649,16 @@ static void dispatch_p(hipStream_t st, const PlanDev &P, FBArgs &A)
 {
     A.nt = P.nt;
     A.nf = P.nf;
+    const bool two = p_pairs() == 2;
     switch (P.nt) {
-    case 1001: launch_p<PPlan1001, MODE>(st, P, A); break;
-    default: launch_p<PPlan1000, MODE>(st, P, A); break;
+    case 1001:
+        if (two) launch_p<PPlan1001, MODE, 2>(st, P, A);
+        else launch_p<PPlan1001, MODE, 1>(st, P, A);
+        break;
+    default:
+        if (two) launch_p<PPlan1000, MODE, 2>(st, P, A);
+        else launch_p<PPlan1000, MODE, 1>(st, P, A);
+        break;
     }
 }
 
