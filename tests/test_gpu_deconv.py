@@ -33,6 +33,8 @@ def _bar_target_cube(nx, ny, nt):
     dict(nx=20, ny=18, nt=1001, dx=0.5, dy=0.5, n_iter=6, n_filters=5, f0=0.4, f1=3.0, mode=0),
     dict(nx=18, ny=20, nt=2000, dx=0.5, dy=0.5, n_iter=6, n_filters=4, f0=0.4, f1=3.0, mode=0),
     dict(nx=16, ny=17, nt=4000, dx=0.5, dy=0.5, n_iter=4, n_filters=3, f0=0.4, f1=3.0, mode=0),
+    # many iterations on wide kernels (the reference's FFT-convolution branch; split, fused sums on the device)
+    dict(nx=48, ny=40, nt=128, dx=1.0, dy=1.0, n_iter=200, n_filters=4, f0=0.25, f1=2.0, mode=1, loose=True),
 ])
 def test_deconvolution_vs_oracle(engine, case):
     z = np.load(os.path.join(GOLD, "psf_sample.npz"))
@@ -57,9 +59,14 @@ def test_deconvolution_vs_oracle(engine, case):
     img = d_img.download((nx, ny), np.float32)
     gains = d_g.download((case["n_filters"], nx, ny), np.float32)
     assert np.isfinite(out).all()
-    assert np.abs(gains - ogains).max() / np.abs(ogains).max() < 2e-4
-    assert np.abs(out - oref).max() / np.abs(oref).max() < 2e-4
-    assert np.abs(img - oimg).max() / oimg.max() < 5e-4
+    # Error budget (scripts/gpu_deconv_error_budget.py, profiles/r02_deconv_error_budget.txt): the
+    # device's fp32 FIR against the reference's Complex<f64> one costs 3e-7 on the cube and a few 1e-6 on the gains,
+    # and Richardson-Lucy does not amplify it (measured 2.5e-7 ... 8e-7 / 3e-7 ... 2.3e-6 / 5e-7 ... 2.2e-6 for
+    # cube / gains / image on these cases; 5.6e-6 / 8.7e-6 / 7.1e-6 after 200 iterations on wide kernels)
+    bar = 3.0 if case.get("loose") else 1.0
+    assert np.abs(out - oref).max() / np.abs(oref).max() < 1e-5 * bar
+    assert np.abs(gains - ogains).max() / np.abs(ogains).max() < 1e-5 * bar
+    assert np.abs(img - oimg).max() / oimg.max() < 1e-5 * bar
     # the filter does something: it is not the identity
     assert np.abs(out - cube).max() / np.abs(cube).max() > 1e-2
     for b in (d_in, d_out, d_img, d_g):
