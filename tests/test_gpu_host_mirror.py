@@ -30,6 +30,16 @@ def test_host_mirror_selftest_and_default_chain():
             np.array([0.5, 0.5], np.float32).tofile(f)
             time.tofile(f)
             raw.tofile(f)
+        # the PSF splines of psf.npz for the live-abort test (keys of io.rs:146-166), in the order PsfArrays holds them
+        z = np.load(os.path.join(ROOT, "tests", "golden", "psf_sample.npz"))
+        with open(os.path.join(d, "psf.bin"), "wb") as f:
+            np.array([z["wx_base_a"], z["wx_base_b"], z["wy_base_a"], z["wy_base_b"]], np.float32).ravel().tofile(f)
+            for prefix, kk, vk in (("wx_corr_", "wx_corr_knots_thz", "wx_corr_values_mm"), ("wy_corr_", "wy_corr_knots_thz", "wy_corr_values_mm"),
+                                   ("x0_", "x0_knots_thz", "x0_values_mm"), ("y0_", "y0_knots_thz", "y0_values_mm")):
+                for key in (kk, vk, prefix + "coeff_a", prefix + "coeff_b", prefix + "coeff_c", prefix + "coeff_d"):
+                    a = np.asarray(z[key], np.float64).astype(np.float32).ravel()
+                    np.array([a.size], np.int32).tofile(f)
+                    a.tofile(f)
         if tio.available():
             tio.save_scan(os.path.join(d, "scan.thzimg"), time, raw,
                           {"width": nx, "height": ny, "dx [mm]": "0.5", "dy [mm]": "0.25", "user": "test"})

@@ -239,16 +239,34 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         if (B.n_iter > max_iter) max_iter = B.n_iter;
         B.blk0 = blk;
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
-        B.tblk0 = tblk;
         B.tiles_w = (B.W + 15) / 16;
         B.n_tiles = B.tiles_w * ((B.H + 15) / 16);
-        tblk += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
         tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;
         B.off_u = (unsigned)ws_floats; ws_floats += img;
         B.off_t = (unsigned)ws_floats; ws_floats += img;
     }
+    // The tiled grid lists the bands by falling iteration count: at iteration `it` the tiles that still
+    // iterate are a PREFIX of the grid (live_blocks(it)), so a launch need not carry the blocks of finished bands —
+    // late in the call that is the difference between ~100 blocks and ~1 500 that each cost a dispatch only to
+    // find out they have nothing to do.
+    std::vector<int> order((size_t)nbs);
+    for (int b = 0; b < nbs; ++b) order[(size_t)b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return bands[(size_t)a].n_iter > bands[(size_t)c].n_iter; });
+    std::vector<std::pair<int, unsigned>> live_steps;  // (n_iter of a band, blocks up to and including it), by falling n_iter
+    for (int o = 0; o < nbs; ++o) {
+        RlBand &B = bands[(size_t)order[(size_t)o]];
+        B.tblk0 = tblk;
+        tblk += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
+        live_steps.emplace_back(B.n_iter, tblk);
+    }
+    auto live_blocks = [&](int it) {  // blocks of the bands with n_iter > it
+        unsigned n = 0;
+        for (const auto &st : live_steps)
+            if (st.first > it) n = st.second;
+        return n;
+    };
     for (int b = 0; b < nbs; ++b) {
         const BandPsf &bp = psfs[(size_t)b];
         RlBand &B = bands[(size_t)b];
@@ -261,15 +279,17 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         for (int b = 0; b < nbs; ++b)
             fprintf(stderr, "band %2d  f=%.3f THz  psf %3d x %3d  n_iter %4d  tiles %u\n", b, centers[(size_t)b],
                     bands[(size_t)b].pr, bands[(size_t)b].pc, bands[(size_t)b].n_iter,
-                    (b + 1 < nbs ? bands[(size_t)b + 1].tblk0 : tblk) - bands[(size_t)b].tblk0);
+                    rl_tile_block_count(bands[(size_t)b].pr, bands[(size_t)b].pc, (unsigned)bands[(size_t)b].n_tiles));
     psf_pack.insert(psf_pack.end(), 32, 0.0f);  // the tiled step reads taps a whole chunk at a time
     HIP_TRY(ctx, mem.alloc(&d_ws, (ws_floats + psf_pack.size()) * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
                                 hipMemcpyHostToDevice, ctx->stream));
     std::vector<RlTileRef> tiles(tblk);
-    for (int b = 0; b < nbs; ++b)
-        for (unsigned t = bands[(size_t)b].tblk0; t < (b + 1 < nbs ? bands[(size_t)b + 1].tblk0 : tblk); ++t)
-            tiles[t] = RlTileRef{bands[(size_t)b]};
+    for (int o = 0; o < nbs; ++o) {
+        const RlBand &B = bands[(size_t)order[(size_t)o]];
+        const unsigned end = o + 1 < nbs ? bands[(size_t)order[(size_t)o + 1]].tblk0 : tblk;
+        for (unsigned t = B.tblk0; t < end; ++t) tiles[t] = RlTileRef{B};
+    }
     RlTileRef *d_tiles = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_tiles, tiles.size() * sizeof(RlTileRef)));
     HIP_TRY(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RlTileRef), hipMemcpyHostToDevice, ctx->stream));
@@ -296,10 +316,11 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // image tile + halo + taps fit in LDS (THZ_NO_TILE: developer knob, forces the fallback for tests)
     const bool tiled = tile_lds <= (size_t)150 * 1024 && !getenv("THZ_NO_TILE");
     if (tiled) prepare_rl_step_tiled(tile_lds);
-    auto enqueue = [&](const int *it_base, int it) {
+    auto enqueue = [&](const int *it_base, int it, unsigned grid_blocks) {
         if (tiled) {
-            launch_rl_step_tiled(ctx->stream, d_tiles, tblk, tile_lds, it_base, it, 0, d_ws);
-            launch_rl_step_tiled(ctx->stream, d_tiles, tblk, tile_lds, it_base, it, 1, d_ws);
+            if (grid_blocks == 0) return;
+            launch_rl_step_tiled(ctx->stream, d_tiles, grid_blocks, tile_lds, it_base, it, 0, d_ws);
+            launch_rl_step_tiled(ctx->stream, d_tiles, grid_blocks, tile_lds, it_base, it, 1, d_ws);
         } else {
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 0, d_ws);
             launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 1, d_ws);
@@ -307,30 +328,46 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     };
     int *d_it = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_it, sizeof(int)));
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    const bool use_graph = !getenv("THZ_NO_GRAPH");  // developer knob: plain launches for A/B timing
-    if (use_graph && max_iter > kRlBatch
-        && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (int o = 0; o < kRlBatch; ++o) enqueue(d_it, o);
-        if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph
-            || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            if (graph) (void)hipGraphDestroy(graph);
-            graph = nullptr;
-            exec = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    struct GraphGuard {
-        hipGraph_t g;
-        hipGraphExec_t e;
-        ~GraphGuard()
+    const bool use_graph = !getenv("THZ_NO_GRAPH");      // developer knobs: plain launches / the whole grid
+    const bool compact = !getenv("THZ_RL_FULL_GRID");    // every time, for A/B timing
+    // One captured batch per grid size: a batch that starts at iteration `base` launches the live prefix of the
+    // tile grid, rounded up to a power of two so that a call needs a handful of graphs, not one per band.
+    struct GraphCache {
+        std::vector<std::pair<unsigned, std::pair<hipGraph_t, hipGraphExec_t>>> g;
+        ~GraphCache()
         {
-            if (e) (void)hipGraphExecDestroy(e);
-            if (g) (void)hipGraphDestroy(g);
+            for (auto &e : g) {
+                if (e.second.second) (void)hipGraphExecDestroy(e.second.second);
+                if (e.second.first) (void)hipGraphDestroy(e.second.first);
+            }
         }
-    } graph_guard{graph, exec};
-    tick("graph capture");
+    } cache;
+    auto grid_for = [&](int base) -> unsigned {
+        if (!tiled) return blk;
+        if (!compact) return tblk;
+        const unsigned live = live_blocks(base);
+        unsigned g2 = 1;
+        while (g2 < live) g2 <<= 1;
+        return g2 < tblk ? g2 : tblk;
+    };
+    auto graph_for = [&](unsigned grid) -> hipGraphExec_t {
+        for (auto &e : cache.g)
+            if (e.first == grid) return e.second.second;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int o = 0; o < kRlBatch; ++o) enqueue(d_it, o, grid);
+            if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph
+                || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph = nullptr;
+                exec = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        cache.g.push_back({grid, {graph, exec}});
+        return exec;
+    };
     for (int base = 0; base < max_iter; base += kRlBatch) {
         if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -338,11 +375,13 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
         }
+        const unsigned grid = grid_for(base);
+        hipGraphExec_t exec = (use_graph && max_iter > kRlBatch) ? graph_for(grid) : nullptr;
         if (exec) {
             HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_it), base, 1, ctx->stream));
             HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
         } else {
-            for (int it = base; it < base + kRlBatch && it < max_iter; ++it) enqueue(nullptr, it);
+            for (int it = base; it < base + kRlBatch && it < max_iter; ++it) enqueue(nullptr, it, compact && tiled ? live_blocks(it) : grid);
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
         if (progress) *progress = (float)std::min(base + kRlBatch, max_iter) / (float)max_iter;

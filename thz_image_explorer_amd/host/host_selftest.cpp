@@ -7,7 +7,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <optional>
 #include <string>
+#include <thread>
 
 using namespace thzhost;
 
@@ -282,9 +287,115 @@ static void run_file_chain(const std::string &dir)
     CHECK(threw, "missing file throws");
 }
 
+// Two "devices" on one GPU: a thz_group whose two members are two contexts on device 0 —
+// the same-device form of the group, collectives as device-local copies — against one session over the whole
+// cube: the image must be the same bit for bit, the pixel means to rounding.
+static void test_group_two_members()
+{
+    const size_t nx = 10, ny = 6, nt = 1024;
+    std::vector<float> time = linspace(1000.0f, 1000.0f + 0.05f * (float)(nt - 1), nt), cube(nx * ny * nt);
+    for (size_t p = 0; p < nx * ny; ++p)
+        for (size_t t = 0; t < nt; ++t) {
+            const float z = ((float)t * 0.05f - 10.0f - 0.01f * (float)p) / 0.35f;
+            cube[p * nt + t] = (1.0f + 0.01f * (float)(p % 7)) * (-z * std::exp(-z * z));
+        }
+    thz_chain_cfg cfg;
+    CHECK(thz_chain_cfg_default(time.data(), nt, &cfg) == THZ_OK, "chain defaults");
+    // one session over everything
+    thz_ctx *ctx = nullptr;
+    thz_session *one = nullptr;
+    CHECK(thz_create(0, &ctx) == THZ_OK, "thz_create");
+    CHECK(thz_session_create(ctx, nx, ny, nt, time.data(), 0.5f, 0.5f, &one) == THZ_OK, "session");
+    CHECK(thz_session_upload(one, cube.data(), 0) == THZ_OK, "upload");
+    CHECK(thz_session_recompute(one, &cfg) == THZ_OK, "recompute");
+    std::vector<float> img1(nx * ny), avg1(nt / 2 + 1), img2(nx * ny), avg2(nt / 2 + 1);
+    CHECK(thz_session_download(one, THZ_BUF_IMG, 0, nx * ny, img1.data()) == THZ_OK, "image");
+    CHECK(thz_session_download(one, THZ_BUF_AVG_AMPLITUDES, 0, 1, avg1.data()) == THZ_OK, "means");
+    thz_session_destroy(one);
+    thz_destroy(ctx);
+    // two members on device 0
+    const int devs[2] = {0, 0};
+    thz_group *g = nullptr;
+    thz_group_session *gs = nullptr;
+    CHECK(thz_group_create(devs, 2, &g) == THZ_OK, "thz_group_create");
+    CHECK(thz_group_world(g) == 2 && thz_group_local_count(g) == 2, "two members");
+    size_t x0 = 0, n = 0;
+    CHECK(thz_host_slab(nx, 2, 1, &x0, &n) == THZ_OK && x0 == 5 && n == 5, "slab rule");
+    CHECK(thz_group_session_create(g, nx, ny, nt, time.data(), 0.5f, 0.5f, &gs) == THZ_OK, "group session");
+    CHECK(thz_group_session_upload(gs, cube.data(), 0) == THZ_OK, "group upload");
+    CHECK(thz_group_session_recompute(gs, &cfg, 1, THZ_GATHER_SMALL) == THZ_OK, "group recompute");
+    CHECK(thz_group_session_download(gs, THZ_BUF_IMG, 0, nx * ny, img2.data()) == THZ_OK, "gathered image");
+    CHECK(thz_group_session_download(gs, THZ_BUF_AVG_AMPLITUDES, 0, 1, avg2.data()) == THZ_OK, "group means");
+    CHECK(img1 == img2, "slabs reproduce the whole-cube image bit for bit");
+    float worst = 0.0f, scale = 0.0f;
+    for (size_t k = 0; k < avg1.size(); ++k) {
+        worst = std::fmax(worst, std::fabs(avg1[k] - avg2[k]));
+        scale = std::fmax(scale, std::fabs(avg1[k]));
+    }
+    CHECK(worst <= 2e-6f * scale, "all-reduced means");
+    float dummy = 0.0f;
+    CHECK(thz_group_session_download(gs, THZ_BUF_DATA, 0, 1, &dummy) == THZ_ERR_NOT_READY, "ungathered buffer is absent");
+    thz_group_session_destroy(gs);
+    thz_group_destroy(g);
+}
+
+// filter.rs:631-637 / cancellable_loops: a click on the abort button DURING the call ends it
+static void test_deconvolution_live_abort(const std::string &dir)
+{
+    // psf.npz is not readable from C++ without an npz reader: the Python side hands the splines over as psf.bin
+    std::FILE *f = std::fopen((dir + "/psf.bin").c_str(), "rb");
+    if (!f) { std::printf("SKIP test_deconvolution_live_abort (no psf.bin)\n"); return; }
+    auto rd = [&](std::vector<float> &v) {
+        int32_t n = 0;
+        if (std::fread(&n, 4, 1, f) != 1) n = 0;
+        v.resize((size_t)n);
+        if (n && std::fread(v.data(), 4, (size_t)n, f) != (size_t)n) v.clear();
+    };
+    GuiSettingsContainer gui;
+    float base[4] = {0, 0, 0, 0};
+    if (std::fread(base, 4, 4, f) != 4) { std::fclose(f); return; }
+    gui.psf.wx_a = base[0]; gui.psf.wx_b = base[1]; gui.psf.wy_a = base[2]; gui.psf.wy_b = base[3];
+    for (int i = 0; i < 4; ++i) { rd(gui.psf.k[i]); rd(gui.psf.v[i]); rd(gui.psf.a[i]); rd(gui.psf.b[i]); rd(gui.psf.c[i]); rd(gui.psf.d[i]); }
+    std::fclose(f);
+    const size_t w = 64, h = 64, nt = 256;
+    std::vector<float> time = linspace(1000.0f, 1000.0f + 0.05f * (float)(nt - 1), nt), data(w * h * nt);
+    for (size_t p = 0; p < w * h; ++p)
+        for (size_t t = 0; t < nt; ++t) {
+            const float z = ((float)t * 0.05f - 5.0f) / 0.35f;
+            data[p * nt + t] = (0.4f + 0.6f * (float)((p / 3) % 2)) * (-z * std::exp(-z * z));
+        }
+    ScannedImageFilterData input = make_input(data, w, h, time);
+    input.dx = 0.5f; input.dy = 0.5f;
+    Deconvolution flt;
+    flt.n_iterations = 500; flt.n_filters = 25; flt.start_freq = 0.1f; flt.end_freq = 10.0f; flt.win_width = 0.5f;
+    ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
+    std::atomic<bool> abort{false};
+    float seen = -1.0f;
+    std::thread clicker([&] {   // the GUI thread: watches the progress bar, clicks the abort button once it moves
+        for (int i = 0; i < 4000 && !abort.load(); ++i) {
+            {
+                std::lock_guard<std::mutex> g(pl->first);
+                if (pl->second && *pl->second > 0.0f) { seen = *pl->second; abort.store(true); }
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        abort.store(true);
+    });
+    const ScannedImageFilterData out = flt.filter(input, gui, pl, abort);
+    clicker.join();
+    CHECK(seen > 0.0f && seen < 1.0f, "progress was published while the call ran");
+    CHECK(out.data.download() == data, "an abort during the call returns the input");
+    {
+        std::lock_guard<std::mutex> g(pl->first);
+        CHECK(!pl->second.has_value(), "progress cleared after the call");
+    }
+}
+
 int main(int argc, char **argv)
 {
     try {
+        test_group_two_members();
+        if (argc > 1) test_deconvolution_live_abort(argv[1]);
         test_fft_roundtrip();
         test_fd_bandpass();
         test_td_bandpass();
