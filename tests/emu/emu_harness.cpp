@@ -151,7 +151,7 @@ extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const fl
     const unsigned tiles_n = rl_tile_block_count(pr, pc, (unsigned)B.n_tiles);  // blocks of the tiled grid
     std::vector<RlTileRef> tiles(tiles_n, RlTileRef{B});
     for (int step = 0; step < 2; ++step) {
-        if (tiled) launch_rl_step_tiled(nullptr, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());
+        if (tiled) launch_rl_step_tiled(nullptr, mode != 0, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());
         else launch_rl_step(nullptr, &B, 1, blocks, nullptr, 0, step, ws.data());
     }
     std::memcpy(t_out, ws.data() + B.off_t, img * sizeof(float));

@@ -53,6 +53,8 @@ void thz_destroy(thz_ctx *ctx)
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipStream_t st : ctx->aux_streams)
+        if (st) (void)hipStreamDestroy(st);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

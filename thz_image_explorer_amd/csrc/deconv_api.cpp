@@ -247,26 +247,67 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.off_u = (unsigned)ws_floats; ws_floats += img;
         B.off_t = (unsigned)ws_floats; ws_floats += img;
     }
-    // The tiled grid lists the bands by falling iteration count: at iteration `it` the tiles that still
-    // iterate are a PREFIX of the grid (live_blocks(it)), so a launch need not carry the blocks of finished bands —
-    // late in the call that is the difference between ~100 blocks and ~1 500 that each cost a dispatch only to
-    // find out they have nothing to do.
-    std::vector<int> order((size_t)nbs);
-    for (int b = 0; b < nbs; ++b) order[(size_t)b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return bands[(size_t)a].n_iter > bands[(size_t)c].n_iter; });
-    std::vector<std::pair<int, unsigned>> live_steps;  // (n_iter of a band, blocks up to and including it), by falling n_iter
-    for (int o = 0; o < nbs; ++o) {
-        RlBand &B = bands[(size_t)order[(size_t)o]];
-        B.tblk0 = tblk;
-        tblk += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
-        live_steps.emplace_back(B.n_iter, tblk);
-    }
-    auto live_blocks = [&](int it) {  // blocks of the bands with n_iter > it
-        unsigned n = 0;
-        for (const auto &st : live_steps)
-            if (st.first > it) n = st.second;
-        return n;
+    // The bands never exchange anything, so the tiled iteration runs as up to kRlChains independent CHAINS of
+    // launches (parallel branches of the captured graph, one stream each): the narrow-kernel bands (<= 256 taps, one
+    // dependent sum per pixel: long launches whatever their number of tiles), and the wide-kernel bands by falling
+    // iteration count in three groups — the longest-lived band alone (the call's critical path: nothing else
+    // makes its launches wait), the next two, the rest.  A launch of a chain lasts as long as its slowest tile, so
+    // bands of similar kernel size share a chain; chains overlap on the chip, which one chain's ~100-700 blocks of
+    // 10-20 us never fill.  Inside a chain the bands are listed by falling iteration count, so the tiles that still
+    // iterate at iteration `it` are a PREFIX of the list (live_blocks) and a launch carries no block of a finished
+    // band.  tblk0 counts from the start of the band's own list.
+    constexpr int kRlChains = 4;
+    struct TileList {
+        bool wide = false;
+        std::vector<int> order;                           // bands of this chain, by falling n_iter
+        std::vector<std::pair<int, unsigned>> live_steps;  // (n_iter of a band, blocks up to and including it)
+        unsigned blocks = 0, first = 0;                   // blocks of the list / where it starts in d_tiles
+        size_t lds = 0;
+        unsigned live_blocks(int it) const
+        {
+            unsigned n = 0;
+            for (const auto &st : live_steps)
+                if (st.first > it) n = st.second;
+            return n;
+        }
     };
+    std::vector<TileList> lists;
+    {
+        std::vector<int> wide_bands, narrow_bands;
+        for (int b = 0; b < nbs; ++b) (bands[(size_t)b].mode != 0 ? wide_bands : narrow_bands).push_back(b);
+        auto by_iter = [&](int a, int c) { return bands[(size_t)a].n_iter > bands[(size_t)c].n_iter; };
+        std::stable_sort(wide_bands.begin(), wide_bands.end(), by_iter);
+        std::stable_sort(narrow_bands.begin(), narrow_bands.end(), by_iter);
+        const bool one_chain = getenv("THZ_RL_ONE_CHAIN") != nullptr;  // developer knob, for A/B timing
+        const size_t cut[3] = {one_chain ? wide_bands.size() : 1, 3, wide_bands.size()};
+        size_t at = 0;
+        for (size_t end : cut) {
+            end = std::min(end, wide_bands.size());
+            if (end <= at) continue;
+            TileList L;
+            L.wide = true;
+            L.order.assign(wide_bands.begin() + (long)at, wide_bands.begin() + (long)end);
+            lists.push_back(L);
+            at = end;
+        }
+        if (!narrow_bands.empty()) {
+            TileList L;
+            L.order = narrow_bands;
+            lists.push_back(L);
+        }
+    }
+    static_assert(kRlChains >= 4, "three wide chains and the narrow one");
+    for (TileList &L : lists) {
+        L.first = tblk;
+        for (int b : L.order) {
+            RlBand &B = bands[(size_t)b];
+            B.tblk0 = L.blocks;
+            L.blocks += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
+            L.live_steps.emplace_back(B.n_iter, L.blocks);
+            L.lds = std::max(L.lds, rl_tile_lds_bytes(B.pr, B.pc));
+        }
+        tblk += L.blocks;
+    }
     for (int b = 0; b < nbs; ++b) {
         const BandPsf &bp = psfs[(size_t)b];
         RlBand &B = bands[(size_t)b];
@@ -285,11 +326,12 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
                                 hipMemcpyHostToDevice, ctx->stream));
     std::vector<RlTileRef> tiles(tblk);
-    for (int o = 0; o < nbs; ++o) {
-        const RlBand &B = bands[(size_t)order[(size_t)o]];
-        const unsigned end = o + 1 < nbs ? bands[(size_t)order[(size_t)o + 1]].tblk0 : tblk;
-        for (unsigned t = B.tblk0; t < end; ++t) tiles[t] = RlTileRef{B};
-    }
+    for (const TileList &L : lists)
+        for (int b : L.order) {
+            const RlBand &B = bands[(size_t)b];
+            const unsigned n = rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
+            for (unsigned t = 0; t < n; ++t) tiles[L.first + B.tblk0 + t] = RlTileRef{B};
+        }
     RlTileRef *d_tiles = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_tiles, tiles.size() * sizeof(RlTileRef)));
     HIP_TRY(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RlTileRef), hipMemcpyHostToDevice, ctx->stream));
@@ -315,76 +357,172 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     constexpr int kRlBatch = 32;
     // image tile + halo + taps fit in LDS (THZ_NO_TILE: developer knob, forces the fallback for tests)
     const bool tiled = tile_lds <= (size_t)150 * 1024 && !getenv("THZ_NO_TILE");
-    if (tiled) prepare_rl_step_tiled(tile_lds);
-    auto enqueue = [&](const int *it_base, int it, unsigned grid_blocks) {
-        if (tiled) {
-            if (grid_blocks == 0) return;
-            launch_rl_step_tiled(ctx->stream, d_tiles, grid_blocks, tile_lds, it_base, it, 0, d_ws);
-            launch_rl_step_tiled(ctx->stream, d_tiles, grid_blocks, tile_lds, it_base, it, 1, d_ws);
-        } else {
-            launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 0, d_ws);
-            launch_rl_step(ctx->stream, d_bands, nbs, blk, it_base, it, 1, d_ws);
+    if (tiled) {
+        size_t lds_kind[2] = {0, 0};
+        for (const TileList &L : lists) lds_kind[L.wide ? 1 : 0] = std::max(lds_kind[L.wide ? 1 : 0], L.lds);
+        for (int k = 0; k < 2; ++k)
+            if (lds_kind[k]) prepare_rl_step_tiled(k == 1, lds_kind[k]);
+    }
+    const bool use_graph = !getenv("THZ_NO_GRAPH");      // developer knobs: plain launches / the whole grid
+    const bool compact = !getenv("THZ_RL_FULL_GRID");    // every time (serial path), for A/B timing
+    // Iterations are launch-sized work (10-20 us a launch), so a batch of kRlBatch iterations of a chain is
+    // captured once into a hipGraph — a plain sequence of 2 kRlBatch launches over the chain's whole tile list (a
+    // finished band's block leaves after one scalar load; cutting the grid to the live prefix measured no gain,
+    // profiles/r02_deconv_timing_compact_vs_full_grid.txt) — and replayed on the chain's own stream; the batch's
+    // first iteration number lives in device memory (d_it[chain]) so that one graph serves all of a chain's batches.
+    // One multi-branch graph for all chains was tried first: its instantiation cost 9 ms per distinct set of grids.
+    // The chains meet at the end of every batch, where the abort flag is polled.
+    const bool parallel = tiled && use_graph && max_iter > kRlBatch;
+    hipStream_t chain_stream[kRlChains] = {ctx->stream, ctx->stream, ctx->stream, ctx->stream};
+    if (parallel)
+        for (size_t c = 1; c < lists.size(); ++c) {
+            if (!ctx->aux_streams[c - 1]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_streams[c - 1], hipStreamNonBlocking));
+            chain_stream[c] = ctx->aux_streams[c - 1];
         }
+    auto sync_chains = [&]() -> hipError_t {
+        hipError_t first = hipSuccess;
+        for (size_t c = 0; c < (parallel ? lists.size() : (size_t)1); ++c) {
+            const hipError_t e = hipStreamSynchronize(chain_stream[c]);
+            if (first == hipSuccess) first = e;
+        }
+        return first;
     };
     int *d_it = nullptr;
-    HIP_TRY(ctx, mem.alloc(&d_it, sizeof(int)));
-    const bool use_graph = !getenv("THZ_NO_GRAPH");      // developer knobs: plain launches / the whole grid
-    const bool compact = !getenv("THZ_RL_FULL_GRID");    // every time, for A/B timing
-    // One captured batch per grid size: a batch that starts at iteration `base` launches the live prefix of the
-    // tile grid, rounded up to a power of two so that a call needs a handful of graphs, not one per band.
-    struct GraphCache {
-        std::vector<std::pair<unsigned, std::pair<hipGraph_t, hipGraphExec_t>>> g;
-        ~GraphCache()
+    HIP_TRY(ctx, mem.alloc(&d_it, kRlChains * sizeof(int)));
+    struct ChainGraphs {
+        hipGraph_t graph[kRlChains] = {nullptr, nullptr, nullptr, nullptr};
+        hipGraphExec_t exec[kRlChains] = {nullptr, nullptr, nullptr, nullptr};
+        bool tried[kRlChains] = {false, false, false, false};
+        hipEvent_t start = nullptr;
+        ~ChainGraphs()
         {
-            for (auto &e : g) {
-                if (e.second.second) (void)hipGraphExecDestroy(e.second.second);
-                if (e.second.first) (void)hipGraphDestroy(e.second.first);
+            for (int c = 0; c < kRlChains; ++c) {
+                if (exec[c]) (void)hipGraphExecDestroy(exec[c]);
+                if (graph[c]) (void)hipGraphDestroy(graph[c]);
             }
+            if (start) (void)hipEventDestroy(start);
         }
-    } cache;
-    auto grid_for = [&](int base) -> unsigned {
-        if (!tiled) return blk;
-        if (!compact) return tblk;
-        const unsigned live = live_blocks(base);
-        unsigned g2 = 1;
-        while (g2 < live) g2 <<= 1;
-        return g2 < tblk ? g2 : tblk;
+    } cg;
+    auto chain_launches = [&](size_t c, hipStream_t st, const int *it_base, int o0, int o1, unsigned grid) {
+        const TileList &L = lists[c];
+        for (int o = o0; o < o1; ++o)
+            for (int step = 0; step < 2; ++step)
+                launch_rl_step_tiled(st, L.wide, d_tiles + L.first, grid, L.lds, it_base, o, step, d_ws);
     };
-    auto graph_for = [&](unsigned grid) -> hipGraphExec_t {
-        for (auto &e : cache.g)
-            if (e.first == grid) return e.second.second;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int o = 0; o < kRlBatch; ++o) enqueue(d_it, o, grid);
-            if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph
-                || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                graph = nullptr;
-                exec = nullptr;
+    auto graph_of = [&](size_t c) -> hipGraphExec_t {
+        if (cg.tried[c]) return cg.exec[c];
+        cg.tried[c] = true;
+        if (hipStreamBeginCapture(chain_stream[c], hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            chain_launches(c, chain_stream[c], d_it + c, 0, kRlBatch, lists[c].blocks);
+            if (hipStreamEndCapture(chain_stream[c], &cg.graph[c]) != hipSuccess || !cg.graph[c]
+                || hipGraphInstantiate(&cg.exec[c], cg.graph[c], nullptr, nullptr, 0) != hipSuccess) {
+                cg.exec[c] = nullptr;
                 (void)hipGetLastError();
             }
         }
-        cache.g.push_back({grid, {graph, exec}});
-        return exec;
+        return cg.exec[c];
     };
-    for (int base = 0; base < max_iter; base += kRlBatch) {
-        if (abort_flag && *abort_flag) {  // cancellable_loops semantics: polled between batches
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (int rc = pass_through()) return rc;
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
+    if (parallel) {  // the chains start behind the padded images
+        HIP_TRY(ctx, hipEventCreateWithFlags(&cg.start, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(cg.start, ctx->stream));
+        for (size_t c = 1; c < lists.size(); ++c) HIP_TRY(ctx, hipStreamWaitEvent(chain_stream[c], cg.start, 0));
+    }
+    auto aborted = [&]() -> int {
+        HIP_TRY(ctx, sync_chains());
+        if (int rc = pass_through()) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
+    };
+    if (parallel) {
+        // batch k + 1 is enqueued before the host waits for batch k: the chains never run dry while the host
+        // walks a graph's nodes.  The abort flag is polled once per batch (cancellable_loops semantics; a click
+        // takes effect within two batches, ~1.5 ms).
+        struct DoneEvents {
+            hipEvent_t ev[kRlChains][2] = {};
+            bool pending[kRlChains][2] = {};
+            ~DoneEvents()
+            {
+                for (auto &row : ev)
+                    for (hipEvent_t e : row)
+                        if (e) (void)hipEventDestroy(e);
+            }
+        } done;
+        for (size_t c = 0; c < lists.size(); ++c)
+            for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&done.ev[c][k], hipEventDisableTiming));
+        std::vector<hipEvent_t> marks[kRlChains];
+        hipEvent_t t_start = nullptr;
+        auto submit = [&](int batch) -> int {
+            const int base = batch * kRlBatch, end = std::min(base + kRlBatch, max_iter);
+            for (size_t c = 0; c < lists.size(); ++c) {
+                if (lists[c].live_blocks(base) == 0) continue;
+                if (hipGraphExec_t exec = graph_of(c)) {
+                    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_it + c), base, 1, chain_stream[c]));
+                    HIP_TRY(ctx, hipGraphLaunch(exec, chain_stream[c]));
+                } else {
+                    chain_launches(c, chain_stream[c], nullptr, base, end, lists[c].blocks);
+                }
+                HIP_TRY(ctx, hipEventRecord(done.ev[c][batch & 1], chain_stream[c]));
+                done.pending[c][batch & 1] = true;
+                if (timing) {  // developer knob: when every chain's batches ended, relative to the first submit
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(ctx, hipEventCreate(&e));
+                    HIP_TRY(ctx, hipEventRecord(e, chain_stream[c]));
+                    marks[c].push_back(e);
+                }
+            }
+            return THZ_OK;
+        };
+        if (timing) {
+            HIP_TRY(ctx, hipEventCreate(&t_start));
+            HIP_TRY(ctx, hipEventRecord(t_start, ctx->stream));
         }
-        const unsigned grid = grid_for(base);
-        hipGraphExec_t exec = (use_graph && max_iter > kRlBatch) ? graph_for(grid) : nullptr;
-        if (exec) {
-            HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_it), base, 1, ctx->stream));
-            HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
-        } else {
-            for (int it = base; it < base + kRlBatch && it < max_iter; ++it) enqueue(nullptr, it, compact && tiled ? live_blocks(it) : grid);
+        const int n_batches = (max_iter + kRlBatch - 1) / kRlBatch;
+        if (abort_flag && *abort_flag) return aborted();
+        if (int rc = submit(0)) return rc;
+        for (int k = 0; k < n_batches; ++k) {
+            if (k + 1 < n_batches)
+                if (int rc = submit(k + 1)) return rc;
+            for (size_t c = 0; c < lists.size(); ++c)
+                if (done.pending[c][k & 1]) {
+                    HIP_TRY(ctx, hipEventSynchronize(done.ev[c][k & 1]));
+                    done.pending[c][k & 1] = false;
+                }
+            if (progress) *progress = (float)std::min((k + 1) * kRlBatch, max_iter) / (float)max_iter;
+            if (abort_flag && *abort_flag && k + 1 < n_batches) return aborted();
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
-        if (progress) *progress = (float)std::min(base + kRlBatch, max_iter) / (float)max_iter;
+        HIP_TRY(ctx, sync_chains());
+        if (int rc = check_launch(ctx)) return rc;
+        if (timing) {
+            for (size_t c = 0; c < lists.size(); ++c) {
+                fprintf(stderr, "thz_deconvolve: chain %zu (%s, %u blocks, %zu bands) batches end at [ms]:", c,
+                        lists[c].wide ? "wide" : "narrow", lists[c].blocks, lists[c].order.size());
+                for (hipEvent_t e : marks[c]) {
+                    float ms = 0.0f;
+                    (void)hipEventElapsedTime(&ms, t_start, e);
+                    fprintf(stderr, " %.2f", ms);
+                    (void)hipEventDestroy(e);
+                }
+                fprintf(stderr, "\n");
+            }
+            (void)hipEventDestroy(t_start);
+        }
+    } else {
+        for (int base = 0; base < max_iter; base += kRlBatch) {
+            if (abort_flag && *abort_flag) return aborted();  // polled between batches
+            const int end = std::min(base + kRlBatch, max_iter);
+            for (int it = base; it < end; ++it) {
+                if (!tiled) {
+                    launch_rl_step(ctx->stream, d_bands, nbs, blk, nullptr, it, 0, d_ws);
+                    launch_rl_step(ctx->stream, d_bands, nbs, blk, nullptr, it, 1, d_ws);
+                } else {
+                    for (size_t c = 0; c < lists.size(); ++c)
+                        chain_launches(c, ctx->stream, nullptr, it, it + 1, compact ? lists[c].live_blocks(it) : lists[c].blocks);
+                }
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // keeps the abort poll honest
+            if (int rc = check_launch(ctx)) return rc;
+            if (progress) *progress = (float)end / (float)max_iter;
+        }
     }
     tick("iterations");
     launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);

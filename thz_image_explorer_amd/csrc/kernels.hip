@@ -1220,23 +1220,28 @@ __host__ __device__ inline unsigned rl_tile_blocks(bool turned, unsigned n_tiles
     return turned ? n_tiles : (n_tiles + kRlTilesPerBlock - 1) / kRlTilesPerBlock;
 }
 
-__global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
-                                                              const int *__restrict__ it_base, int iteration,
-                                                              int step, float *__restrict__ ws)
+// The grid of a launch is a list of tiles of ONE kind (WIDE: kernels of more than 256 taps), the bands in it by
+// falling iteration count, so that the tiles still iterating are a prefix of the list.  Two kernels rather than
+// one with a branch: the wide path fits 64 VGPRs, which lets two 1024-thread blocks share a CU — one block's
+// staging and partial-sum reduction then run under the other's tap loop — while the narrow path's double-buffered
+// chunks need more registers and less LDS.
+template <bool WIDE>
+__global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
+                                                                            const int *__restrict__ it_base, int iteration,
+                                                                            int step, float *__restrict__ ws)
 {
     THZ_DYN_LDS(smem);
     if (it_base) iteration += *it_base;
-    // the tile's band record, by value in the per-tile table: the tiles of finished bands (most of the
-    // grid, most of the time) leave after a single memory latency
+    // the tile's band record, by value in the per-tile table: the tiles of finished bands leave after a single
+    // memory latency
     const RlBand B = tiles[blockIdx.x].band;
     if (iteration >= B.n_iter) return;  // block-uniform
     const int pr = B.pr, pc = B.pc;
-    const bool turned = B.mode != 0;
     const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;  // halo tile
     const int nch = rl_chunks(pc);
     const float *a = ws + (step == 0 ? B.off_u : B.off_t);
     const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
-    if (!turned) {
+    if constexpr (!WIDE) {
         // ---- narrow kernel: four tiles, one per 256-thread group; the taps are staged once for all four
         const int grp = (int)(threadIdx.x >> 8), px = (int)(threadIdx.x & 255);
         const unsigned lt = (blockIdx.x - B.tblk0) * kRlTilesPerBlock + (unsigned)grp;
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *_
         if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
         else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
         return;
-    }
+    } else {
     // ---- wide kernel: one tile, stored turned by 180 degrees, the kernel's rows dealt to the 16 waves
     const unsigned lt = blockIdx.x - B.tblk0;
     const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
@@ -1329,6 +1334,7 @@ __global__ __launch_bounds__(kRlThreads) void k_rl_step_tiled(const RlTileRef *_
     for (int g = 0; g < kRlSplit; ++g) sum += part_s[g * 256 + px];
     if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
     else ws[B.off_u + idx] = other * sum;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restrict__ filters, int n_bands,
@@ -2187,12 +2193,18 @@ size_t rl_tile_lds_bytes(int pr, int pc)
 
 unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles) { return rl_tile_blocks(rl_turned(pr, pc), n_tiles); }
 
-void prepare_rl_step_tiled(size_t lds_bytes) { allow_dynamic_lds(k_rl_step_tiled, lds_bytes); }
+void prepare_rl_step_tiled(bool wide, size_t lds_bytes)
+{
+    if (wide) allow_dynamic_lds(k_rl_step_tiled<true>, lds_bytes);
+    else allow_dynamic_lds(k_rl_step_tiled<false>, lds_bytes);
+}
 
-void launch_rl_step_tiled(hipStream_t st, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
+void launch_rl_step_tiled(hipStream_t st, bool wide, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
                           const int *it_base, int iteration, int step, float *ws)
 {
-    THZ_LAUNCH(k_rl_step_tiled, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    if (total_tiles == 0) return;
+    if (wide) THZ_LAUNCH(k_rl_step_tiled<true>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    else THZ_LAUNCH(k_rl_step_tiled<false>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,

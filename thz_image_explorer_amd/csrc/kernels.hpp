@@ -71,13 +71,13 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 // LDS-tiled form of the same step: total_tiles blocks, lds_bytes = rl_tile_lds_bytes of the largest band
 size_t rl_tile_lds_bytes(int pr, int pc);
 unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles);  // blocks of the tiled grid a band's tiles take
-void prepare_rl_step_tiled(size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
+void prepare_rl_step_tiled(bool wide, size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
 // per tile of the tiled grid: its band's record by value — a block needs one (scalar) load to know
 // whether its band still iterates and everything else about it, not a chain of two
 struct RlTileRef {
     RlBand band;
 };
-void launch_rl_step_tiled(hipStream_t st, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
+void launch_rl_step_tiled(hipStream_t st, bool wide, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
                           const int *it_base, int iteration, int step, float *ws);
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
                     const float *energy, const float *ws, float *gain);

@@ -367,7 +367,8 @@ static void test_deconvolution_live_abort(const std::string &dir)
     ScannedImageFilterData input = make_input(data, w, h, time);
     input.dx = 0.5f; input.dy = 0.5f;
     Deconvolution flt;
-    flt.n_iterations = 500; flt.n_filters = 25; flt.start_freq = 0.1f; flt.end_freq = 10.0f; flt.win_width = 0.5f;
+    flt.n_iterations = 5000; flt.n_filters = 25; flt.start_freq = 0.1f;  // long enough (>= 100 ms) for a click to land inside the call
+    flt.end_freq = 10.0f; flt.win_width = 0.5f;
     ProgressLock pl = std::make_shared<std::pair<std::mutex, std::optional<float>>>();
     std::atomic<bool> abort{false};
     float seen = -1.0f;

@@ -614,7 +614,7 @@ ScannedImageFilterData Deconvolution::filter(const ScannedImageFilterData &input
                 std::lock_guard<std::mutex> g(progress->first);
                 progress->second = prog;
             }
-            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
     });
     const int rc = thz_deconvolve(e.ctx(), &psf, &cfg, input.width, input.height, *input.dx, *input.dy,
