@@ -247,15 +247,15 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.off_u = (unsigned)ws_floats; ws_floats += img;
         B.off_t = (unsigned)ws_floats; ws_floats += img;
     }
-    // The bands never exchange anything, so the tiled iteration runs as up to kRlChains independent CHAINS of
-    // launches (parallel branches of the captured graph, one stream each): the narrow-kernel bands (<= 256 taps, one
-    // dependent sum per pixel: long launches whatever their number of tiles), and the wide-kernel bands by falling
-    // iteration count in three groups — the longest-lived band alone (the call's critical path: nothing else
-    // makes its launches wait), the next two, the rest.  A launch of a chain lasts as long as its slowest tile, so
-    // bands of similar kernel size share a chain; chains overlap on the chip, which one chain's ~100-700 blocks of
-    // 10-20 us never fill.  Inside a chain the bands are listed by falling iteration count, so the tiles that still
-    // iterate at iteration `it` are a PREFIX of the list (live_blocks) and a launch carries no block of a finished
-    // band.  tblk0 counts from the start of the band's own list.
+    // The bands never exchange anything, so the tiled iteration runs as independent CHAINS of launches, one stream
+    // each: the wide-kernel bands (more than 256 taps) and the narrow-kernel ones (one dependent sum per pixel: a
+    // launch of 17 us whatever its number of tiles, which under one common launch made every wide tile wait).
+    // Inside a chain the bands are listed by falling iteration count, so the tiles that still iterate at iteration
+    // `it` are a PREFIX of the list (live_blocks).  tblk0 counts from the start of the band's own list.
+    // Measured on 128 x 128 x 1001, 500 iterations (profiles/r02_rl_chains.txt): one chain for everything 22.6 ms
+    // per call, wide | narrow 16.6 ms, and the wide bands further split into three chains by iteration count
+    // (THZ_RL_SPLIT_WIDE, kept as a developer knob) 19.3 ms — while every band is alive the chip is full (1 100
+    // blocks for 512 places), the chains' launches take turns, and more chains only add launches.
     constexpr int kRlChains = 4;
     struct TileList {
         bool wide = false;
@@ -278,8 +278,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         auto by_iter = [&](int a, int c) { return bands[(size_t)a].n_iter > bands[(size_t)c].n_iter; };
         std::stable_sort(wide_bands.begin(), wide_bands.end(), by_iter);
         std::stable_sort(narrow_bands.begin(), narrow_bands.end(), by_iter);
-        const bool one_chain = getenv("THZ_RL_ONE_CHAIN") != nullptr;  // developer knob, for A/B timing
-        const size_t cut[3] = {one_chain ? wide_bands.size() : 1, 3, wide_bands.size()};
+        const bool split_wide = getenv("THZ_RL_SPLIT_WIDE") != nullptr;  // developer knob, for A/B timing
+        const size_t cut[3] = {split_wide ? 1 : wide_bands.size(), 3, wide_bands.size()};
         size_t at = 0;
         for (size_t end : cut) {
             end = std::min(end, wide_bands.size());
