@@ -63,13 +63,13 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 void emu_set_f_bar(int mode) { thz::g_f_bar_override = mode; }
 void emu_set_p_pairs(int q) { thz::g_p_pairs_override = q; }
 
-// fused chain with a complex multiplier (F family only); FArgs::bar via emu_set_f_bar
+// fused chain with a complex multiplier (F and P families); FArgs::bar via emu_set_f_bar
 int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
                     const float *post, float *fft, float *amp, float *ph, float *out, float *img)
 {
     PlanHost H;
     if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
-    if (H.family != kFamilyF) return -2;
+    if (H.family != kFamilyF && H.family != kFamilyP) return -2;
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask);
     return 0;

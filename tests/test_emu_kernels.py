@@ -468,6 +468,49 @@ def test_forward_inverse_with_store_barriers(emu, nt):
     assert np.abs(res[0][3]).max() > 0
 
 
+@pytest.mark.parametrize("pairs", [1, 2])
+@pytest.mark.parametrize("nt", [1001, 1000])
+def test_mixed_radix_pipeline_complex_multiplier(emu, nt, pairs):
+    """k_p<pipe, CM> — the complex per-bin multiplier (K13, reference deconvolution) inside the mixed-radix chain at
+    the length of real scans: against a numpy fp64 model (Y = X mask H with a real DC / Nyquist bin, amplitudes
+    |X mask H|, phases of X), odd trace count (the last pair has one trace)"""
+    emu.emu_allow_f(1); emu.emu_allow_p(1)
+    emu.emu_set_p_pairs(pairs)
+    try:
+        assert emu.emu_family(nt) == 6
+        nx, ny = 3, 7
+        time = synth.make_time(nt)
+        cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 1024))[:, :nt].reshape(nx, ny, nt).copy()
+        chain = synth.default_chain(time)
+        npix, nf = nx * ny, nt // 2 + 1
+        H = _wiener_cmask(time, nf)
+        fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+        ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+        rc = emu.emu_pipeline_ex(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                 _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img))
+        assert rc == 0
+        X = np.fft.rfft(cube.reshape(npix, nt).astype(np.float64) * chain["w_pre"].astype(np.float64), axis=1)
+        Y = X * ((H[:, 0].astype(np.float64) + 1j * H[:, 1]) * chain["fd_mask"])
+        a_ref = np.abs(Y)
+        Y[:, 0] = Y[:, 0].real
+        if nt % 2 == 0:
+            Y[:, -1] = Y[:, -1].real
+        t_ref = np.fft.irfft(Y, n=nt, axis=1) * chain["w_post"]
+        got = fft[..., 0] + 1j * fft[..., 1]
+        assert np.abs(got - Y).max() / np.abs(Y).max() < 1e-5
+        assert np.all(fft[:, 0, 1] == 0) and (nt % 2 or np.all(fft[:, -1, 1] == 0))
+        assert np.abs(amp - a_ref).max() / a_ref.max() < 1e-5
+        assert np.abs(out - t_ref).max() / np.abs(t_ref).max() < 1e-5
+        assert np.abs(img - (t_ref ** 2).sum(1)).max() / (t_ref ** 2).sum(1).max() < 1e-5
+        ref = ob.run_pipeline(cube, time, chain)   # phases are those of X
+        d = ph.reshape(ref["phases"].shape) - ref["phases"]
+        strong = ref["amplitudes"] > 0.05 * ref["amplitudes"].max(axis=-1, keepdims=True)
+        d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+        assert np.abs(d[strong]).max() < 3e-3
+    finally:
+        emu.emu_set_p_pairs(0)
+
+
 @pytest.mark.parametrize("nt", [1001, 1000])
 def test_mixed_radix_stage_kernels_two_pairs_per_wave(emu, nt):
     """k_p<fwd> / k_p<inv> with two pairs of traces per wave == with one (same butterflies, dealt differently),

@@ -532,7 +532,7 @@ def _wiener_from_template(time, eps=1e-2):
 
 @pytest.mark.parametrize("bar", [0, 3])
 @pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums"])
-@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (5, 5, 256)])
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (3, 5, 1001), (3, 5, 1000), (5, 5, 256)])
 def test_fused_pipeline_ex(engine, shape, mode, bar, monkeypatch):
     """thz_pipeline_ex: complex per-bin multiplier (K13) inside the fused launch, in-launch pixel sums, store-phase
     barriers — vs the oracle (plain chain) / a numpy fp64 model of the definition in DESIGN.md §7 (K13 is
@@ -726,3 +726,30 @@ def test_polar_ifft_of_averaged_spectra(engine, nt):
         ref = ob.polar_irfft(amp, ph, nt, zero_dc)
         assert rel(got, ref) < TOL
     assert np.abs(ref).max() > 0
+
+
+@pytest.mark.parametrize("cmask", [False, True])
+@pytest.mark.parametrize("nt", [1001, 1000, 1024, 2048, 4096, 1500, 640])
+def test_fused_chain_inverts_exactly_the_stored_spectrum(engine, nt, cmask):
+    """The reference's ifft stage reads the fft stage's stored output (data_thread.rs:1090-1105); a Filter(6 / 7)
+    update re-runs the stand-alone inverse on the resident spectrum.  So the fused launch's time-domain output must
+    be BIT-identical to thz_ifft of the spectrum it stored — no fused multiply-add may swallow the rounding of
+    X * mask on the way from the epilogue to the inverse (it did once, in k_p<pipe>: 9e-8 of the maximum)."""
+    nx, ny = 5, 7
+    time, cube = synth.make_cube(nx, ny, nt)
+    e = engine
+    e.set_time_axis(time)
+    chain = synth.default_chain(time)
+    npix, nf = nx * ny, nt // 2 + 1
+    H = _wiener_from_template(time) if cmask else None
+    d_raw = e.to_device(cube); d_pre = e.to_device(chain["w_pre"]); d_fd = e.to_device(chain["fd_mask"])
+    d_post = e.to_device(chain["w_post"]); d_H = e.to_device(H) if cmask else None
+    d_fft = e.empty((npix, nf, 2)); d_amp = e.empty((npix, nf)); d_ph = e.empty((npix, nf))
+    d_out = e.empty((npix, nt)); d_out2 = e.empty((npix, nt)); d_img = e.empty((npix,)); d_img2 = e.empty((npix,))
+    e.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, None)
+    e.ifft(npix, d_fft, d_post, d_out2, d_img2)
+    e.sync()
+    a, b = d_out.download((npix, nt), np.float32), d_out2.download((npix, nt), np.float32)
+    assert np.abs(a).max() > 0
+    assert np.array_equal(a, b)
+    assert np.array_equal(d_img.download((npix,), np.float32), d_img2.download((npix,), np.float32))

@@ -32,6 +32,7 @@ struct FBArgs {
     float *img;             // npix or nullptr
     const cx *w;            // nt: exp(-i pi n^2 / nt)
     const cx *bf;           // M : FFT_M(b) / M
+    const cx *cmask;        // nf complex multipliers on top of `mask`, or nullptr (P kernels)
 };
 
 // LDS per block, in floats behind the core tables: [mask nf][pre nt][post nt], each padded to 4
@@ -85,13 +86,12 @@ struct FBUnwrap {
 };
 
 // f / ao / po may each be null (stage entry points that do not want that output)
-__device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m)[4], const bool (&ok)[4], int g,
-                                               int lane, FBUnwrap &u, cx *f, float *ao, float *po)
+// unwrapped phases of four consecutive bins per lane (bin 256 g + 4 lane + c), running over the groups of a trace
+__device__ __forceinline__ void fb_phase_bins(const cx (&X)[4], const bool (&ok)[4], int g, int lane, FBUnwrap &u,
+                                              float *po)
 {
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
-    float a[4], ph[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+    float ph[4];
     {
         // four angles as two packed Horner chains (same values as four fast_atan2f calls, half the issue slots)
         const float yy[4] = {X[0].y, X[1].y, X[2].y, X[3].y}, xx[4] = {X[0].x, X[1].x, X[2].x, X[3].x};
@@ -114,24 +114,67 @@ __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m
     const float base = u.carry + excl;
     u.carry += wave_bcast<kWave - 1>(incl);
     u.prev_tail = wave_bcast<kWave - 1>(ph[3]);
+    if (!po) return;
+    if (ok[3]) {
+        store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
+                 u.first + (base + s_[3]));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ok[c]) po[c] = u.first + (base + s_[c]);
+    }
+}
+
+// stores of a group of bins: spectrum Y (f), amplitudes a (ao)
+__device__ __forceinline__ void fb_store_bins(const cx (&Y)[4], const float (&a)[4], const bool (&ok)[4], cx *f, float *ao)
+{
     if (ok[3]) {
         if (f) {
-            store_f4(reinterpret_cast<float *>(f), X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
-            store_f4(reinterpret_cast<float *>(f) + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+            store_f4(reinterpret_cast<float *>(f), Y[0].x, Y[0].y, Y[1].x, Y[1].y);
+            store_f4(reinterpret_cast<float *>(f) + 4, Y[2].x, Y[2].y, Y[3].x, Y[3].y);
         }
         if (ao) store_f4(ao, a[0], a[1], a[2], a[3]);
-        if (po)
-            store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
-                     u.first + (base + s_[3]));
     } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (ok[c]) {
-                if (f) f[c] = cx{X[c].x * m[c], X[c].y * m[c]};
+                if (f) f[c] = Y[c];
                 if (ao) ao[c] = a[c];
-                if (po) po[c] = u.first + (base + s_[c]);
             }
     }
+}
+
+// real multiplier m (the band pass): spectrum X m, amplitude |X| m, phase of X
+__device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m)[4], const bool (&ok)[4], int g,
+                                               int lane, FBUnwrap &u, cx *f, float *ao, float *po)
+{
+    float a[4];
+    cx Y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
+        Y[c] = cx{X[c].x * m[c], X[c].y * m[c]};
+    }
+    fb_store_bins(Y, a, ok, f, ao);
+    fb_phase_bins(X, ok, g, lane, u, po);
+}
+
+// complex multiplier h (K13: band pass x reference deconvolution): spectrum Y = X h with the imaginary part
+// dropped where `real_bin` (DC / Nyquist: the C2R precondition, math_tools.rs:510-512), amplitude |X h| (taken
+// before the dropping), phase of X — as the F kernels' CMASK epilogue.  Y is handed back for the inverse.
+__device__ __forceinline__ void fb_finish_bins_c(const cx (&X)[4], const cx (&h)[4], const bool (&real_bin)[4],
+                                                 const bool (&ok)[4], int g, int lane, FBUnwrap &u, cx *f, float *ao,
+                                                 float *po, cx (&Y)[4])
+{
+    float a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        Y[c] = cx_mul(X[c], h[c]);
+        a[c] = fast_sqrt(fmaf(Y[c].x, Y[c].x, Y[c].y * Y[c].y));
+        if (real_bin[c]) Y[c].y = 0.0f;
+    }
+    fb_store_bins(Y, a, ok, f, ao);
+    fb_phase_bins(X, ok, g, lane, u, po);
 }
 
 // Two real traces per convolution: z = (x1 + i x2) w goes through the chirp-z machinery once,
@@ -164,7 +207,7 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
 
     FAddr<P> ad;
     ad.init(lane);
-    const float fnt = (float)L;
+    const DivConst by_nt((float)L);
     const int n_groups = (nf + 255) / 256;  // epilogue groups of 256 bins: bin = 256 g + 4 lane + c
     const int half = L / 2;
     const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
@@ -272,7 +315,8 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                     for (int c = 0; c < 4; ++c)
                         if (ok[c]) {
                             buf[nat(k0 + c)] = cx{X1[c].x * m[c], X1[c].y * m[c]};
-                            buf[nat(y2_base + k0 + c)] = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                            // a missing second trace is exactly zero, as in the stand-alone inverse
+                            buf[nat(y2_base + k0 + c)] = has2 ? cx{X2[c].x * m[c], X2[c].y * m[c]} : cx{0.0f, 0.0f};
                         }
                 }
             }
@@ -347,11 +391,11 @@ __global__ __launch_bounds__(512) void k_fb(FBArgs A, FTables T)
                 const cx wv = ld_off(wl, (unsigned)n);
                 const cx U = cx_mul(cx{s.y, s.x}, wv);
                 const float pw = post_l[n];
-                const float v1 = (U.x / fnt) * pw;
+                const float v1 = by_nt(U.x) * pw;
                 o1[n] = v1;
                 acc1 += v1 * v1;
                 if (has2) {
-                    const float v2 = (-U.y / fnt) * pw;
+                    const float v2 = by_nt(-U.y) * pw;
                     o1[L + n] = v2;
                     acc2 += v2 * v2;
                 }
@@ -476,7 +520,7 @@ __global__ __launch_bounds__(512) void k_fbc(FB2Args B, FTables T)
 
     FAddr<P> ad;
     ad.init(lane);
-    const float fnt = (float)L;
+    const DivConst by_nt((float)L);
     const int half = L / 2;
     const float sgn = (L & 1) ? -1.0f : 1.0f;  // w[nt-k] = sgn * w[k]
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
@@ -689,11 +733,11 @@ __global__ __launch_bounds__(512) void k_fbc(FB2Args B, FTables T)
                 for (int n = s * chunk + lb1; n < n_end; n += kWave) {
                     const cx U = cx_mul(fbs_c<P, S>(reg0, tw, n), ld_off(wl, (unsigned)n));
                     const float pw = post_g ? ld_off(post_g, (unsigned)n) : 1.0f;
-                    const float v1 = (U.x / fnt) * pw;
+                    const float v1 = by_nt(U.x) * pw;
                     o1[n] = v1;
                     acc1 += v1 * v1;
                     if (has2) {
-                        const float v2 = (-U.y / fnt) * pw;
+                        const float v2 = by_nt(-U.y) * pw;
                         o1[L + n] = v2;
                         acc2 += v2 * v2;
                     }

@@ -144,13 +144,13 @@ struct PPlan {
     static constexpr int rounds(int b) { return (b + kWave - 1) / kWave; }
     static constexpr int RD1 = rounds(B1), RD2 = rounds(B2), RD3 = rounds(B3);
     static constexpr int pad4(int v) { return (v + 3) & ~3; }
-    // LDS per block: [T1: N cx, [k1][m]][T2: R2 R3 cx, [k2][j3]][mask nf][pre N][post N] floats, [per wave: N cx (+pad)]
+    // LDS per block: [T1: N cx, [k1][m]][T2: R2 R3 cx, [k2][j3]][per wave: N cx (+pad)][mask nf floats, or nf cx][pre N][post N]
     static constexpr int T1_ENTRIES = N, T2_ENTRIES = M1 + (M1 & 1);
     static constexpr int WAVE_ENTRIES = N + (N & 1);
-    static constexpr size_t lds_bytes(int waves, int pairs_per_wave = 1)
+    static constexpr size_t lds_bytes(int waves, int pairs_per_wave = 1, bool cmask = false)
     {
         return (size_t)(T1_ENTRIES + T2_ENTRIES + waves * pairs_per_wave * WAVE_ENTRIES) * sizeof(cx)
-               + (size_t)(pad4(NF) + 2 * pad4(N)) * sizeof(float);
+               + (size_t)((cmask ? 2 : 1) * pad4(NF) + 2 * pad4(N)) * sizeof(float);
     }
 };
 
@@ -291,7 +291,9 @@ __device__ __forceinline__ float p_zero_if(float v, bool zero)
 
 // Same argument block as the chirp-z kernels (w / bf unused).  A wave takes Q consecutive pairs (a "unit" of
 // 2 Q traces) per trip.
-template <class P, int MODE, int Q>
+// CM: A.cmask holds nf complex multipliers H[k] applied on top of the real mask (stored spectrum X m H, amplitude
+// |X m H|, phase of X; see fb_finish_bins_c) — the reference-pulse deconvolution of a real scan in the same launch.
+template <class P, int MODE, int Q, bool CM = false>
 __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 {
     THZ_DYN_LDS(lds);
@@ -304,11 +306,20 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
     cx *t2 = t1 + P::T1_ENTRIES;
     cx *buf = t2 + P::T2_ENTRIES + (size_t)wib * (Q * WE);
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * (Q * WE));
-    float *pre_s = mask_s + P::pad4(NF);
+    float *pre_s = mask_s + (CM ? 2 : 1) * P::pad4(NF);
     float *post_s = pre_s + P::pad4(N);
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < M1; i += (int)blockDim.x) t2[i] = T.t2[i];
-    for (int i = (int)threadIdx.x; i < NF; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    if constexpr (CM) {
+        cx *cm = reinterpret_cast<cx *>(mask_s);
+        for (int i = (int)threadIdx.x; i < NF; i += (int)blockDim.x) {
+            const float m = A.mask[i];
+            const cx h = A.cmask[i];
+            cm[i] = cx{h.x * m, h.y * m};
+        }
+    } else {
+        for (int i = (int)threadIdx.x; i < NF; i += (int)blockDim.x) mask_s[i] = A.mask[i];
+    }
     for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
         pre_s[i] = A.pre_win ? A.pre_win[i] : 1.0f;
         post_s[i] = A.post_win ? A.post_win[i] : 1.0f;
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 
     PAddr<P, Q> ad;
     ad.init(lane);
-    const float fnt = (float)N;
+    const DivConst by_nt((float)N);
     constexpr int n_groups = (NF + 255) / 256;  // epilogue groups of 256 bins: bin = 256 g + 4 lane + c
     const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
     const size_t stride = (size_t)gridDim.x * wpb;
@@ -379,9 +390,9 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 #pragma unroll 1
                 for (int g = 0; g < n_groups; ++g) {
                     const int k0 = 256 * g + lb4;
-                    cx X1[4], X2[4];
+                    cx X1[4], X2[4], h[4];
                     float m[4];
-                    bool ok[4];
+                    bool ok[4], rb[4];
                     int kcs[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -393,7 +404,8 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                         const cx Fk = bq[kc], Fm = bq[km];
                         X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
                         X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
-                        m[c] = mask_l[kc];
+                        if constexpr (CM) h[c] = reinterpret_cast<const cx *>(mask_l)[kc];
+                        else m[c] = mask_l[kc];
                         // real input: DC / Nyquist bins are real, with a POSITIVE zero as imaginary part (realfft writes
                         // +0.0 there; arg() of a negative real bin is then +pi, not -pi).  Forced on the bit pattern: a
                         // float select left -0.0 = -0.5 (x - x) standing in the 10 x 10 x 10 instantiation
@@ -401,22 +413,41 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                             const bool real_bin = kc == 0 || ((N & 1) == 0 && kc == NF - 1);
                             X1[c].y = p_zero_if(X1[c].y, real_bin);
                             X2[c].y = p_zero_if(X2[c].y, real_bin);
+                            rb[c] = real_bin;
                         }
                     }
                     const size_t o1 = p * (size_t)NF + k0;
-                    fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
-                                   A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
-                    if (has2)
-                        fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
-                                       A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr);
+                    cx Y1[4], Y2[4];  // the multiplied spectra (CM)
+                    if constexpr (CM) {
+                        fb_finish_bins_c(X1, h, rb, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                                         A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr, Y1);
+                        if (has2)
+                            fb_finish_bins_c(X2, h, rb, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
+                                             A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr, Y2);
+                        else
+                            for (int c = 0; c < 4; ++c) Y2[c] = cx{0.0f, 0.0f};
+                    } else {
+                        fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
+                                       A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
+                        if (has2)
+                            fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
+                                           A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr);
+                    }
                     // input of the inverse, in place: conj(G[k]) and conj(G[N-k]) of G = Y1full + i Y2full
                     // (Yfull[n] = Y[n] up to N/2, conj(Y[N-n]) above) — bin k's owner is the only reader of
                     // slots k and N-k
                     if constexpr (MODE == kPipe) {
+                        // no contraction here: y = X m must round before the sums below, so that the inverse
+                        // transforms exactly the spectrum that was stored (a later Filter(6 / 7) update re-runs k_p<inv>
+                        // on the stored one and has to land on the same samples)
+#pragma clang fp contract(off)
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
                             if (ok[c]) {
-                                const cx y1 = cx{X1[c].x * m[c], X1[c].y * m[c]}, y2 = cx{X2[c].x * m[c], X2[c].y * m[c]};
+                                // a missing second trace is exactly zero, as in k_p<inv> (its "spectrum" here is
+                                // the rounding noise of the split, which would leak into the first trace's samples)
+                                const cx y1 = CM ? Y1[c] : cx{X1[c].x * m[c], X1[c].y * m[c]};
+                                const cx y2 = !has2 ? cx{0.0f, 0.0f} : CM ? Y2[c] : cx{X2[c].x * m[c], X2[c].y * m[c]};
                                 const int kc = kcs[c];
                                 bq[kc] = cx{y1.x - y2.y, -y1.y - y2.x};
                                 if (kc != 0 && 2 * kc != N) bq[N - kc] = cx{y1.x + y2.y, y1.y - y2.x};
@@ -480,8 +511,8 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                     for (int c = 0; c < 4; ++c) {
                         const cx U = bq[n0 + c];
                         const float pw = post_l[n0 + c];
-                        v1[c] = (U.x / fnt) * pw;
-                        v2[c] = (-U.y / fnt) * pw;
+                        v1[c] = by_nt(U.x) * pw;
+                        v2[c] = by_nt(-U.y) * pw;
                         acc1 += v1[c] * v1[c];
                         acc2 += v2[c] * v2[c];
                     }
@@ -493,7 +524,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                         if (n0 + c < N) {
                             const cx U = bq[n0 + c];
                             const float pw = post_l[n0 + c];
-                            const float a = (U.x / fnt) * pw, b = (-U.y / fnt) * pw;
+                            const float a = by_nt(U.x) * pw, b = by_nt(-U.y) * pw;
                             o1[n0 + c] = a;
                             acc1 += a * a;
                             if (has2) { o1[N + n0 + c] = b; acc2 += b * b; }

@@ -222,11 +222,11 @@ __device__ __forceinline__ void c2r_store(const c32 *R, int N, int nt, size_t p,
                                           const float *__restrict__ win, float *__restrict__ out,
                                           float *__restrict__ img, int lane)
 {
-    const float fnt = (float)nt;
+    const DivConst by_nt((float)nt);
     float acc = 0.0f;
     for (int n = lane; n < N; n += kWave) {
         const c32 r = R[n];
-        float v0 = r.im / fnt, v1 = r.re / fnt;
+        float v0 = by_nt(r.im), v1 = by_nt(r.re);
         if (win) { v0 *= win[2 * n]; v1 *= win[2 * n + 1]; }
         *reinterpret_cast<float2 *>(out + p * nt + 2 * n) = make_float2(v0, v1);
         acc += v0 * v0;
@@ -360,13 +360,13 @@ __global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
             }
             wave_sync();
             c32 *R = wave_bluestein_core(A, B, P, lane);
-            const float fnt = (float)nt;
+            const DivConst by_nt((float)nt);
             float acc = 0.0f;
             for (int t = lane; t < nt; t += kWave) {
                 const c32 r = R[t];
                 const c32 c = P.chirp_conj[t];
                 // Re( swap(r) * c ) = r.im*c.re - r.re*c.im
-                float v = (r.im * c.re - r.re * c.im) / fnt;
+                float v = by_nt(r.im * c.re - r.re * c.im);
                 if (win) v *= win[t];
                 out[p * nt + t] = v;
                 acc += v * v;
@@ -1635,19 +1635,34 @@ static int p_pairs()
     return kPPairsDefault;
 }
 
-template <class PL, int MODE, int Q>
+template <class PL, int MODE, int Q, bool CM>
 static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
 {
     unsigned waves = 16 / Q;
-    while (waves > 1 && PL::lds_bytes((int)waves, Q) > kLdsBytesPerCU) --waves;
-    const size_t lds = PL::lds_bytes((int)waves, Q);
+    while (waves > 1 && PL::lds_bytes((int)waves, Q, CM) > kLdsBytesPerCU) --waves;
+    const size_t lds = PL::lds_bytes((int)waves, Q, CM);
     const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
     size_t g = (n_units + waves - 1) / waves;
     if (g > (size_t)kNumCU) g = kNumCU;
     if (g < 1) g = 1;
     PTables T{reinterpret_cast<const cx *>(P.p_t1), reinterpret_cast<const cx *>(P.p_t2)};
-    allow_dynamic_lds(k_p<PL, MODE, Q>, lds);
-    THZ_LAUNCH((k_p<PL, MODE, Q>), (unsigned)g, waves * kWave, lds, st, A, T);
+    allow_dynamic_lds(k_p<PL, MODE, Q, CM>, lds);
+    THZ_LAUNCH((k_p<PL, MODE, Q, CM>), (unsigned)g, waves * kWave, lds, st, A, T);
+}
+
+template <class PL, int MODE>
+static void launch_p_variant(hipStream_t st, const PlanDev &P, const FBArgs &A)
+{
+    const bool two = p_pairs() == 2;
+    if constexpr (MODE != kInv) {
+        if (A.cmask) {  // complex multiplier on top of the band pass
+            if (two) launch_p<PL, MODE, 2, true>(st, P, A);
+            else launch_p<PL, MODE, 1, true>(st, P, A);
+            return;
+        }
+    }
+    if (two) launch_p<PL, MODE, 2, false>(st, P, A);
+    else launch_p<PL, MODE, 1, false>(st, P, A);
 }
 
 template <int MODE>
@@ -1655,16 +1670,9 @@ static void dispatch_p(hipStream_t st, const PlanDev &P, FBArgs &A)
 {
     A.nt = P.nt;
     A.nf = P.nf;
-    const bool two = p_pairs() == 2;
     switch (P.nt) {
-    case 1001:
-        if (two) launch_p<PPlan1001, MODE, 2>(st, P, A);
-        else launch_p<PPlan1001, MODE, 1>(st, P, A);
-        break;
-    default:
-        if (two) launch_p<PPlan1000, MODE, 2>(st, P, A);
-        else launch_p<PPlan1000, MODE, 1>(st, P, A);
-        break;
+    case 1001: launch_p_variant<PPlan1001, MODE>(st, P, A); break;
+    default: launch_p_variant<PPlan1000, MODE>(st, P, A); break;
     }
 }
 
@@ -1706,9 +1714,10 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
                     const float *wa, const float *wb, float *data_out, c32 *fft_out,
                     float *amp_out, float *ph_out, const float *mask, const c32 *cmask)
 {
-    // A complex multiplier is fused only by the F kernels; every other family multiplies in a second
+    // A complex multiplier is fused by the F and P kernels; every other family multiplies in a second
     // (elementwise) launch over the stored spectrum and amplitudes.
-    if (cmask && !(P.family == kFamilyF && fft_out && ((amp_out != nullptr) == (ph_out != nullptr)))) {
+    const bool p_direct = P.family == kFamilyP && !wb && !data_out;
+    if (cmask && !p_direct && !(P.family == kFamilyF && fft_out && ((amp_out != nullptr) == (ph_out != nullptr)))) {
         launch_fft_fwd(st, P, npix, in, wa, wb, data_out, fft_out, amp_out, ph_out, mask, nullptr);
         launch_fd_cmask(st, npix, P.nf, P.nt, fft_out, amp_out, cmask);
         return;
@@ -1743,13 +1752,14 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
         FBArgs A{};
         A.npix = npix; A.in = in; A.pre_win = wa; A.mask = mask ? mask : P.ones;
         A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        A.cmask = reinterpret_cast<const cx *>(cmask);
         dispatch_p<kFwd>(st, P, A);
         return;
     }
     if ((P.family == kFamilyFB || P.family == kFamilyP) && data_out && wa) {
         launch_td_window(st, npix, P.nt, in, wa, data_out);
         if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
-        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask, cmask);
         return;
     }
     if (P.family == kFamilyFB && !wb && !data_out) {
@@ -1824,7 +1834,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         dispatch_f<kPipe>(st, P, A, true);
         return;
     }
-    if (cmask) {
+    if (cmask && !(P.family == kFamilyP && fft_out && amp_out && ph_out && data_out)) {
         // every other family: the complex multiply is its own pass over the stored spectrum
         launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask, cmask);
         launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
@@ -1843,6 +1853,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.npix = npix; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
         A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
         A.data_out = data_out; A.img = img;
+        A.cmask = reinterpret_cast<const cx *>(cmask);
         dispatch_p<kPipe>(st, P, A);
         return;
     }
