@@ -93,6 +93,75 @@ def test_group_session_matches_single_session(engine, shape, members):
             gs.close()
 
 
+def test_rank_api_through_real_rccl_single_rank(engine, monkeypatch):
+    """The process-per-GPU entry points (thz_group_unique_id + thz_group_create_rank — what bench.py --gpus N and the
+    Rust data threads call) with THZ_GROUP_FORCE_RCCL: librccl is dlopen'ed, the communicator is built with
+    ncclCommInitRank and the collectives of upload / recompute / deconvolve go through ncclAllReduce, grouped
+    ncclSend / ncclRecv and ncclBroadcast ON REAL RCCL — with the one rank a one-GPU box can hold.  What stays
+    untested here is only the fabric."""
+    monkeypatch.setenv("THZ_GROUP_FORCE_RCCL", "1")
+    nx, ny, nt = 6, 5, 1024
+    time, cube = synth.make_cube(nx, ny, nt)
+    cfg = pkg.chain_cfg_default(time)
+    single = pkg.Session(engine, nx, ny, time)
+    try:
+        single.upload(cube, subtract_bias=False)
+        single.recompute(cfg)
+        bufs = (pkg.BUF_IMG, pkg.BUF_DATA, pkg.BUF_FFT, pkg.BUF_AMPLITUDES, pkg.BUF_PHASES)
+        means = (pkg.BUF_AVG_FFT, pkg.BUF_AVG_AMPLITUDES, pkg.BUF_AVG_PHASES)
+        want = {w: single.download(w) for w in bufs + means}
+    finally:
+        single.close()
+    uid = pkg.group_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pkg.Group(device=0, rank=0, world=1, uid=uid) as g:
+        assert g.world == 1 and g.ranks == [0]
+        e = g.engine(0)
+        v = np.arange(1000, dtype=np.float32)
+        b = e.to_device(v)
+        g.all_reduce_sum([b], 1000)          # ncclAllReduce over one rank: the values come back unchanged
+        g.sync()
+        assert np.array_equal(b.download((1000,), np.float32), v)
+        h = e.to_device(np.arange(16, dtype=np.uint64) + (1 << 40))
+        g.all_reduce_u64([h], 16)
+        g.sync()
+        assert np.array_equal(h.download((16,), np.uint64), np.arange(16, dtype=np.uint64) + (1 << 40))
+        gs = pkg.GroupSession(g, nx, ny, time)
+        try:
+            gs.upload(cube, subtract_bias=False)
+            gs.recompute(cfg, 1, pkg.GATHER_ALL)
+            for w in bufs:
+                assert np.array_equal(gs.download(w), want[w])
+            for w in means:
+                assert rel(gs.download(w), want[w]) < 2e-6
+        finally:
+            gs.close()
+        b.free(); h.free()
+        # the band-parallel Deconvolution stage: all-gather of the slabs by ncclBroadcast, all-reduce of the band sums
+        import os
+        nx2, ny2, nt2 = 36, 32, 256
+        time2, cube2 = synth.make_cube(nx2, ny2, nt2)
+        psf = pkg.psf_from_npz(np.load(os.path.join(os.path.dirname(__file__), "golden", "psf_sample.npz")))
+        cfg2, dcfg = pkg.chain_cfg_default(time2), pkg.DeconvCfg(20, 5, 0.4, 3.0, 0.5)
+        single = pkg.Session(engine, nx2, ny2, time2, 0.5, 0.5)
+        try:
+            single.upload(cube2, subtract_bias=False)
+            single.recompute(cfg2)
+            assert single.deconvolve(psf, dcfg) == 0
+            want_d, want_i = single.download(pkg.BUF_DATA), single.download(pkg.BUF_IMG)
+        finally:
+            single.close()
+        gs = pkg.GroupSession(g, nx2, ny2, time2, 0.5, 0.5)
+        try:
+            gs.upload(cube2, subtract_bias=False)
+            gs.recompute(cfg2, 1, pkg.GATHER_TIME)
+            assert gs.deconvolve(psf, dcfg) == 0
+            assert rel(gs.download(pkg.BUF_DATA), want_d) < TOL
+            assert rel(gs.download(pkg.BUF_IMG), want_i) < TOL
+        finally:
+            gs.close()
+
+
 def test_group_session_refuses_what_does_not_shard():
     time, cube = synth.make_cube(4, 4, 256)
     with pkg.Group(devices=[0, 0]) as g:

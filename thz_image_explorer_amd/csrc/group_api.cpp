@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -143,7 +144,7 @@ template <class T>
 int all_reduce(thz_group *g, T *const *d_bufs, size_t count, ncclDataType_t type)
 {
     if (!g || !d_bufs) return THZ_ERR_INVALID;
-    if (count == 0 || g->world == 1) return THZ_OK;
+    if (count == 0 || (g->world == 1 && !g->m[0].comm)) return THZ_OK;
     for (size_t i = 0; i < g->m.size(); ++i)
         if (!d_bufs[i]) return gfail(g, THZ_ERR_INVALID, "all-reduce: null buffer");
     if (g->same_device) {
@@ -277,7 +278,9 @@ int thz_group_create_rank(int device, int rank, int world, const void *id, thz_g
         thz_group_destroy(g);
         return rc;
     }
-    if (world > 1) {
+    // THZ_GROUP_FORCE_RCCL: a single-rank group still opens librccl, builds its communicator and sends its
+    // collectives through it — how the RCCL entry points are exercised on a one-GPU box (tests/test_gpu_group.py)
+    if (world > 1 || (id && getenv("THZ_GROUP_FORCE_RCCL"))) {
         if (!rccl_load()) {
             thz_group_destroy(g);
             return THZ_ERR_HIP;
@@ -322,7 +325,7 @@ int thz_group_gather(thz_group *g, const float *const *d_send, const size_t *cou
         GHIP_TRY(g, hipMemcpyAsync(d_recv_root, d_send[root], counts[0] * sizeof(float), hipMemcpyDeviceToDevice,
                                    g->m[(size_t)root].ctx->stream));
     }
-    if (g->world == 1) return THZ_OK;
+    if (g->world == 1 && !g->m[0].comm) return THZ_OK;
     Rccl &r = rccl();
     NCCL_TRY(g, r.GroupStart());
     ncclResult_t rc = ncclSuccess;
@@ -489,7 +492,7 @@ static int group_all_gather(thz_group *g, const float *const *d_send, const size
 {
     std::vector<size_t> off((size_t)g->world + 1, 0);
     for (int q = 0; q < g->world; ++q) off[(size_t)q + 1] = off[(size_t)q] + counts[q];
-    if (g->same_device || g->world == 1) {
+    if (g->same_device || (g->world == 1 && !g->m[0].comm)) {
         GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
         if (g->world > 1)
             if (int rc = join_on_first(g)) return rc;
@@ -508,7 +511,7 @@ static int group_all_gather(thz_group *g, const float *const *d_send, const size
     for (size_t i = 0; i < g->m.size() && rc == ncclSuccess; ++i)
         for (int q = 0; q < g->world && rc == ncclSuccess; ++q)
             if (counts[q] && hipSetDevice(g->m[i].ctx->device) == hipSuccess)
-                rc = r.Broadcast(g->m[i].rank == q ? d_send[i] : nullptr, d_recv[i] + off[(size_t)q], counts[q], ncclFloat, q,
+                rc = r.Broadcast(g->m[i].rank == q ? d_send[i] : d_recv[i] + off[(size_t)q], d_recv[i] + off[(size_t)q], counts[q], ncclFloat, q,
                                  g->m[i].comm, g->m[i].ctx->stream);
     if (rc != ncclSuccess) {
         (void)r.GroupEnd();
