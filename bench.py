@@ -296,6 +296,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nt, ny, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()   # rank 0 ran its extra kernel legs meanwhile: the communicators go down together
     gs.close()
     group.close()
     if dist is not None:
