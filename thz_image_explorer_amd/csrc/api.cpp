@@ -128,6 +128,12 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
 {
     if (!ctx || !time || nt < 2) return fail(ctx, THZ_ERR_INVALID, "time axis needs >= 2 samples");
     if (int rc = use_device(ctx)) return rc;
+    // the same axis under the same kernel-family switches: the plan and its device tables stand (a session
+    // re-plans at every recompute, data_thread.rs:1194-1227 — tables for nt = 4096 are thousands of double-precision
+    // sines, an allocation and a blocking upload: 0.1 ms that a 2 ms slab recompute would feel)
+    if (ctx->have_plan && ctx->time.size() == nt && ctx->plan_allow_f == ctx->allow_f && ctx->plan_allow_p == ctx->allow_p
+        && std::memcmp(ctx->time.data(), time, nt * sizeof(float)) == 0)
+        return THZ_OK;
     PlanHost H;
     if (!build_plan(nt, H, ctx->allow_f, ctx->allow_p))
         return fail(ctx, THZ_ERR_UNSUPPORTED,
@@ -169,6 +175,8 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
                            reinterpret_cast<const float *>(d + o_f + n_f1 + n_f2 + n_fw),
                            n_p1 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones : nullptr,
                            n_p2 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones + n_p1 : nullptr);
+    ctx->plan_allow_f = ctx->allow_f;
+    ctx->plan_allow_p = ctx->allow_p;
     ctx->time.assign(time, time + nt);
     ctx->freq.resize(nt / 2 + 1);
     (void)thz_host_frequency_axis(time, nt, ctx->freq.data());

@@ -23,6 +23,7 @@ struct thz_ctx {
     c32 *d_tables = nullptr;  // one allocation: tw | tw_split | chirp_conj | bfft
     bool have_plan = false;
     bool allow_f = true, allow_p = true;  // thz_set_kernel_family
+    bool plan_allow_f = true, plan_allow_p = true;  // the switches the current plan was built under
     hipStream_t aux_streams[3] = {nullptr, nullptr, nullptr};  // the deconvolution's extra chains (created on first use)
     void *ws = nullptr;  // scratch workspace (pixel means, ROI lists)
     size_t ws_bytes = 0;

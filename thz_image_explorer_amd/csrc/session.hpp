@@ -19,6 +19,8 @@ struct thz_session {
     float *d_raw = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr, *d_data = nullptr,
           *d_img = nullptr, *d_avg = nullptr;  // d_avg: [2 nf | nf | nf]
     float *d_vec = nullptr;                    // pre | mask | post multipliers (+ tilt scratch)
+    float *h_vec = nullptr;                    // pinned host image of d_vec: the multipliers go up in one asynchronous copy
+    size_t vec_floats = 0;
     float *d_tilt = nullptr;                   // extended cube when tilt != 0 (kept while its size stays the same)
     size_t tilt_floats = 0, ins_count = 0;
     std::vector<float> fd_real, fd_cmask;      // further Frequency-domain plugins: K14 real (nf), K13 complex (2 nf)

@@ -32,7 +32,13 @@ int alloc_outputs(thz_session *s, size_t nt_out)
     if (int rc = dev_alloc(ctx, &s->d_ph, npix * nf)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_data, npix * nt_out)) return rc;
     if (int rc = dev_alloc(ctx, &s->d_avg, 4 * nf)) return rc;
-    if (int rc = dev_alloc(ctx, &s->d_vec, 3 * nt_out + 3 * nf + 16)) return rc;  // pre | post | mask | cmask (+ tilt scratch)
+    s->vec_floats = 3 * nt_out + 3 * nf + 16;  // pre | post | mask | cmask (+ tilt scratch)
+    if (int rc = dev_alloc(ctx, &s->d_vec, s->vec_floats)) return rc;
+    if (s->h_vec) {
+        (void)hipHostFree(s->h_vec);
+        s->h_vec = nullptr;
+    }
+    HIP_TRY(ctx, hipHostMalloc((void **)&s->h_vec, s->vec_floats * sizeof(float), hipHostMallocDefault));
     s->nt_out = nt_out;
     s->nf_out = nf;
     s->out_pix = npix;
@@ -94,6 +100,7 @@ void thz_session_destroy(thz_session *s)
                     (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img, (void *)s->d_scaled,
                     (void *)s->d_rawsum, (void *)s->d_msum})
         if (p) (void)hipFree(p);
+    if (s->h_vec) (void)hipHostFree(s->h_vec);
     delete s;
 }
 
@@ -164,8 +171,10 @@ static int session_tail(thz_session *s, const thz_chain_cfg *cfg)
     std::vector<float> post;
     post_multiplier(cfg, s->time_out, post);
     float *d_post = s->d_vec + nt;
-    HIP_TRY(ctx, hipMemcpyAsync(d_post, post.data(), nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `post` dies at return
+    // through the session's pinned image of d_vec: asynchronous, and nobody writes h_vec again before this
+    // recompute's closing synchronisation
+    std::memcpy(s->h_vec + nt, post.data(), nt * sizeof(float));
+    HIP_TRY(ctx, hipMemcpyAsync(d_post, s->h_vec + nt, nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     s->deconv_current = false;
     return thz_ifft(ctx, npix, s->d_fft, d_post, s->d_data, s->d_img);
 }
@@ -286,12 +295,21 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
     // keep the masks 16-byte aligned for the kernels' vector reads
     float *d_mask = s->d_vec + ((2 * nt_cur + 3) & ~(size_t)3);
     float *d_cmask = d_mask + ((nf + 3) & ~(size_t)3);
-    HIP_TRY(ctx, hipMemcpyAsync(d_pre, pre.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_post, post.data(), nt_cur * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_mask, mask.data(), nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (!s->fd_cmask.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(d_cmask, s->fd_cmask.data(), 2 * nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die at return
+    {
+        // one asynchronous copy out of the session's pinned image of d_vec (four pageable copies and a stream
+        // synchronisation cost 0.1 ms per recompute, 5 % of a 128-row slab's); h_vec is not written again before
+        // this recompute's closing synchronisation
+        float *h = s->h_vec;
+        std::memcpy(h + (d_pre - s->d_vec), pre.data(), nt_cur * sizeof(float));
+        std::memcpy(h + (d_post - s->d_vec), post.data(), nt_cur * sizeof(float));
+        std::memcpy(h + (d_mask - s->d_vec), mask.data(), nf * sizeof(float));
+        size_t used = (size_t)(d_mask - s->d_vec) + nf;
+        if (!s->fd_cmask.empty()) {
+            std::memcpy(h + (d_cmask - s->d_vec), s->fd_cmask.data(), 2 * nf * sizeof(float));
+            used = (size_t)(d_cmask - s->d_vec) + 2 * nf;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(s->d_vec, h, used * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
 
     // ---- pixel means.  want_means == 1: amplitude / phase sums accumulated inside the fused launch, and
     // avg_fft by linearity — every multiplier in front of the transform is the same for all pixels unless
