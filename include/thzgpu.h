@@ -231,7 +231,8 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
  *               reference-pulse (Wiener) filter K13 (thz_host_wiener_filter) inside the
  *               ONE pass over HBM: spectrum = X * (cmask * mask), imaginary parts of bin 0 and (even
  *               nt) of the last bin forced to 0 (math_tools.rs:510-512), amplitudes = |X cmask mask|,
- *               phases those of X (band_pass_fd.rs:184-212 does not touch them either).  Trace lengths
+ *               phases those of X (band_pass_fd.rs:184-212 does not touch them either).  Fused for nt = 1024 / 2048 /
+ *               4096 and 1001 / 1000 (the F and P kernel families); trace lengths
  *               without a fused kernel for it run fft -> thz_apply_fd_cmask -> ifft internally.
  *   d_sums      (2 nf) or NULL: sum over the npix traces of the stored amplitudes [0, nf) and of the
  *               unwrapped phases [nf, 2 nf) — the numerators of the pixel means of the ifft stage

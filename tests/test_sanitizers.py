@@ -38,7 +38,7 @@ def test_kernels_are_race_free():
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang with the sanitizer runtimes")
 @pytest.mark.skipif(os.environ.get("THZ_SANITIZE_ALL") != "1",
-                    reason="two more minutes of build + run; set THZ_SANITIZE_ALL=1 (last run clean: round 1)")
+                    reason="two more minutes of build + run; set THZ_SANITIZE_ALL=1 (last run clean: round 2, after the P-kernel and RL-kernel changes)")
 def test_kernels_stay_in_bounds():
     """the same driver under AddressSanitizer + UBSan: the emulation's LDS is a heap block of exactly the
     launch's dynamic-LDS size, so a lane reading or writing past it (the GPU would hand back zeros or a
