@@ -6,7 +6,7 @@
 
 using namespace thz;
 
-namespace thz { extern int g_f_bar_override; extern int g_p_pairs_override; }
+namespace thz { extern int g_f_bar_override; extern int g_p_pairs_override; extern int g_f_sum_dbuf_override; }
 
 static int g_allow_f = 1, g_allow_p = 1;
 static std::vector<float> g_ones;
@@ -62,6 +62,7 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 
 void emu_set_f_bar(int mode) { thz::g_f_bar_override = mode; }
 void emu_set_p_pairs(int q) { thz::g_p_pairs_override = q; }
+void emu_set_f_sum_dbuf(int m) { thz::g_f_sum_dbuf_override = m; }
 
 // fused chain with a complex multiplier (F and P families); FArgs::bar via emu_set_f_bar
 int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
@@ -73,6 +74,23 @@ int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, con
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask);
     return 0;
+}
+
+// fused chain with the pixel sums taken inside the launch (F family, kCfgSums): sums[0, nf) amplitudes, [nf, 2 nf)
+// unwrapped phases, as thz_pipeline_ex does it (block rows + launch_sum_axis0).  Returns the number of block rows.
+int emu_pipeline_sums(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
+                      const float *post, float *fft, float *amp, float *ph, float *out, float *img, float *sums)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
+    if (H.family != kFamilyF) return -2;
+    PlanDev D = make_plan(H);
+    const size_t rows = pipeline_sum_rows(D, npix, cmask != nullptr);
+    if (rows == 0) return -3;
+    std::vector<float> partial(rows * 2 * (size_t)D.nf, -777.0f);  // every entry must be written by the kernel
+    launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask, partial.data());
+    launch_sum_axis0(nullptr, partial.data(), rows, 2 * (size_t)D.nf, 0.0f, sums);
+    return (int)rows;
 }
 
 int emu_intensity(size_t npix, int nt, float *data, float *img, int subtract_bias)

@@ -110,6 +110,7 @@ static inline void __syncthreads() { pthread_barrier_wait(&thz_emu::g_sync->bloc
 namespace thz {
 
 inline void wave_sync() { pthread_barrier_wait(&thz_emu::g_sync->waves[threadIdx.x / 64]); }
+inline void block_lds_barrier() { __syncthreads(); }
 inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline float wave_shfl(float v, int src)

@@ -468,6 +468,51 @@ def test_forward_inverse_with_store_barriers(emu, nt):
     assert np.abs(res[0][3]).max() > 0
 
 
+@pytest.mark.parametrize("bar,dbuf", [(0, -1), (3, -1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("mode", ["plain", "cmask"])
+@pytest.mark.parametrize("nt,npix", [(1024, 21), (2048, 9), (4096, 17), (4096, 3)])
+def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar, dbuf):
+    """k_f<pipe, kCfgSums>: the block's waves exchange amplitudes and unwrapped phases group by group and carry the
+    pixel sums in registers (FSums).  Every output equals the plain fused chain's bit for bit, and the sums equal the
+    column sums of the stored amplitude / phase arrays (another order of f32 additions: 2e-6).  Trace counts leave
+    ragged last rounds (idle waves take the barriers with zeros) and, for 3 traces, waves that never see a trace.
+    dbuf: one exchange area and two barriers per group (0), two areas and one barrier (1, at nt = 4096 with one wave
+    fewer), or the launcher's choice (-1)."""
+    emu.emu_allow_f(1)
+    emu.emu_set_f_bar(bar)
+    emu.emu_set_f_sum_dbuf(dbuf)
+    try:
+        time = synth.make_time(nt)
+        cube = synth.make_traces(np.arange(npix) + 17, nt).reshape(npix, 1, nt).copy()
+        chain = synth.default_chain(time, backend=None)
+        nf = nt // 2 + 1
+        H = _wiener_cmask(time, nf) if mode == "cmask" else None
+        outs = []
+        for with_sums in (False, True):
+            fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+            ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+            sums = np.full(2 * nf, np.nan, np.float32)
+            if with_sums:
+                rows = emu.emu_pipeline_sums(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                             _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img), _p(sums))
+                assert rows >= 1
+            else:
+                assert emu.emu_pipeline_ex(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                           _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img)) == 0
+            outs.append((fft, amp, ph, out, img, sums))
+        for a, b in zip(outs[0][:5], outs[1][:5]):
+            assert np.array_equal(a, b)
+        amp, ph, sums = outs[1][1], outs[1][2], outs[1][5]
+        assert np.isfinite(sums).all()
+        sa, sp = amp.astype(np.float64).sum(0), ph.astype(np.float64).sum(0)
+        assert np.abs(sums[:nf] - sa).max() <= 2e-6 * np.abs(sa).max()
+        assert np.abs(sums[nf:] - sp).max() <= 2e-6 * np.abs(sp).max()
+        assert np.abs(sa).max() > 0 and np.abs(sp).max() > 0
+    finally:
+        emu.emu_set_f_bar(-1)
+        emu.emu_set_f_sum_dbuf(-1)
+
+
 @pytest.mark.parametrize("pairs", [1, 2])
 @pytest.mark.parametrize("nt", [1001, 1000])
 def test_mixed_radix_pipeline_complex_multiplier(emu, nt, pairs):

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -430,17 +431,33 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
         if (io->d_sums) HIP_TRY(ctx, hipMemsetAsync(io->d_sums, 0, 2 * nf * sizeof(float), ctx->stream));
         return THZ_OK;
     }
+    // Pixel sums: a second pass over the two arrays just written (8 nf bytes per trace).  The F kernels can also
+    // take them inside the launch (fft_f.hpp, FSums: the block's waves exchange their values group by group through
+    // a small LDS area and carry the sums in registers; a small pass adds the blocks' rows) — built, parity-tested
+    // and measured in one process (scripts/gpu_sums_variants.py, profiles/r02_sums_in_kernel.txt): the two block
+    // barriers per 256-bin group and the eighth wave the exchange area displaces cost the fused kernel what the
+    // second pass costs (nt 4096: 18.2 against 18.3 ms per Mi traces; 2048: -7 %; 1024: +4 %), so it stays behind
+    // THZ_FUSED_SUMS=1.
+    const size_t sum_rows = (io->d_sums && getenv("THZ_FUSED_SUMS"))
+                                ? pipeline_sum_rows(ctx->plan_d, npix, io->d_fd_cmask != nullptr) : 0;
+    float *d_partial = nullptr;
+    if (sum_rows) {
+        if (int rc = ensure_ws(ctx, sum_rows * 2 * nf * sizeof(float))) return rc;
+        d_partial = reinterpret_cast<float *>(ctx->ws);
+    }
     {
         StageTimer t(ctx, THZ_STAGE_PIPELINE);
         launch_pipeline(ctx->stream, ctx->plan_d, npix, io->d_raw, io->d_pre_win, io->d_fd_mask, io->d_post_win,
                         reinterpret_cast<c32 *>(io->d_fft), io->d_amp, io->d_phase, io->d_data_out, io->d_img,
-                        reinterpret_cast<const c32 *>(io->d_fd_cmask));
+                        reinterpret_cast<const c32 *>(io->d_fd_cmask), d_partial);
         if (int rc = check_launch(ctx)) return rc;
     }
     if (!io->d_sums) return THZ_OK;
-    // The sums are a second pass over the two arrays just written (8 nf bytes per trace): block accumulators
-    // inside the fused launch were built and measured — 2 nf LDS float atomics per trace doubled the launch's
-    // time at nt = 4096 — and per-lane register accumulators do not fit beside the transform.
+    if (d_partial) {
+        StageTimer t(ctx, THZ_STAGE_MEAN);
+        launch_sum_axis0(ctx->stream, d_partial, sum_rows, 2 * nf, 0.0f, io->d_sums);
+        return check_launch(ctx);
+    }
     if (int rc = thz_pixel_sum(ctx, npix, nf, 1, io->d_amp, io->d_sums)) return rc;
     return thz_pixel_sum(ctx, npix, nf, 1, io->d_phase, io->d_sums + nf);
 }

@@ -143,6 +143,7 @@ __device__ __forceinline__ void st2(cx *p, cx a, cx b) { *reinterpret_cast<cx2 *
 enum : int {
     kCfgAmpPhase = 1,  // also write |X| and the unwrapped phase
     kCfgCMask = 2,     // the per-bin multiplier is complex (K13, reference-pulse Wiener filter)
+    kCfgSums = 4,      // the block also sums the stored amplitudes and unwrapped phases of its traces (FSums)
     kCfgBar = 8        // the block's waves meet at a barrier before each store phase (FArgs::bar says which)
 };
 
@@ -179,9 +180,13 @@ struct FPlan {
     static constexpr int WIN_SLOTS = (N >= 2048) ? 4 : 6;  // 160 KB LDS leaves room for 4 at nt = 4096
     static constexpr int EXTRA_ENTRIES = W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
     static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
-    static constexpr size_t lds_bytes(int waves, int cfg = 0)
+    // kCfgSums: + the exchange area of FSums behind the wave buffers, 8 values x 64 lanes per wave, once or
+    // (sum_dbuf) twice
+    static constexpr int SUM_XCH_ENTRIES = 8 * kWave / 2;  // per wave, in cx
+    static constexpr size_t lds_bytes(int waves, int cfg = 0, bool sum_dbuf = false)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + waves * WAVE_ENTRIES) * sizeof(cx);
+        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + waves * WAVE_ENTRIES
+                        + ((cfg & kCfgSums) ? (sum_dbuf ? 2 : 1) * waves * SUM_XCH_ENTRIES : 0)) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -431,6 +436,9 @@ struct FArgs {
     const float *post_win;  // (nt); may be null only when post_blocks == 0
     float *data_out;        // (npix, nt) final trace            [inv, pipeline]
     float *img;             // (npix) or null
+    float *sum_partial;     // (gridDim.x, 2 nf): every block's sums of its traces' stored amplitudes | unwrapped
+                            // phases, written whole by the block (zeros if it had no trace); kCfgSums only
+    int sum_dbuf;           // kCfgSums: the exchange area exists twice (one block barrier per group instead of two)
 };
 
 enum : int { kFwd = 0, kInv = 1, kPipe = 2 };
@@ -527,11 +535,109 @@ __device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
 // bin 0 and of the Nyquist bin forced to 0: the C2R precondition, math_tools.rs:510-512), the stored
 // amplitude |X H| (taken before the forcing); phases are those of X, as with the real band pass
 // (band_pass_fd.rs:184-212 leaves them alone).  buf keeps the unmultiplied X.
-template <class P, bool AMP_PHASE, bool CMASK = false>
+// kCfgSums — pixel sums of the ifft stage's amplitudes and phases (math_tools.rs:427-440: numerators of the
+// pixel means) inside the fused launch, without LDS atomics (measured: twice the kernel's time) and without 64
+// per-lane accumulators (the register file is full).  After every 256-bin group of the epilogue the W waves of
+// the block put their eight values per lane (four amplitudes, four unwrapped phases) into a small exchange area,
+// [value v][wave][lane]; behind a block barrier, wave v % W adds the W contributions of value v to its running sum
+// of (group, v) — so a wave carries NG (x 2 when W < 8) accumulators instead of 8 NG, every wave does the same
+// little work, and the sums come out in a fixed order (waves 0 .. W-1 within a round, rounds in order, blocks in
+// order in the final reduction): deterministic.  A second barrier frees the area for the next group — or, where
+// LDS has room for two areas used in turn (dbuf), none is needed: a wave reaches the writes of group g + 2 only
+// through the barrier of group g + 1, which the readers of group g pass after their reads.  The
+// barriers order LDS traffic only (block_lds_barrier): the group's global stores stay in flight.  Waves without a
+// trace in the block's last round take the same barriers with zeros (f_sums_idle_round).
+// The bin N (Nyquist) of every trace is summed per wave in lane 0 and exchanged once, after the trace loop.
+template <class P>
+struct FSums {
+    static constexpr int NG = P::NG;
+    float acc[NG][2];      // running sums of (group g, value v = wave + slot * W), per lane
+    float nyq_a, nyq_p;    // lane 0: bin N
+    float *xch0;           // the block's exchange area(s), W * 8 * 64 floats each
+    int wib, wpb, dbuf;
+    __device__ __forceinline__ void init(float *area, int wave_in_block, int waves_per_block, int two_areas)
+    {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = 0.0f;
+        nyq_a = nyq_p = 0.0f;
+        xch0 = area;
+        wib = wave_in_block;
+        wpb = waves_per_block;
+        dbuf = two_areas;
+    }
+    // one group's exchange; every wave of the block calls this NG times per round, in step
+    __device__ __forceinline__ void group(int g, const float (&a)[4], const float (&y)[4], int lane)
+    {
+        static_assert(NG % 2 == 0, "two areas in turn: a round's first group must not meet the last one's area");
+        float *xch = xch0 + ((dbuf && (g & 1)) ? 8 * wpb * kWave : 0);
+        float *mine = xch + wib * kWave + lane;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            mine[v * wpb * kWave] = a[v];
+            mine[(4 + v) * wpb * kWave] = y[v];
+        }
+        block_lds_barrier();
+        float s0 = 0.0f, s1 = 0.0f;
+        {
+            const float *col = xch + wib * wpb * kWave + lane;  // value v = wib
+            if (wib < 8)
+                for (int w = 0; w < wpb; ++w) s0 += col[w * kWave];
+            if (wib + wpb < 8) {                                // value v = wib + W (blocks of fewer than 8 waves)
+                const float *col1 = col + wpb * wpb * kWave;
+                for (int w = 0; w < wpb; ++w) s1 += col1[w * kWave];
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < NG; ++gg) {
+            acc[gg][0] = (gg == g) ? acc[gg][0] + s0 : acc[gg][0];
+            acc[gg][1] = (gg == g) ? acc[gg][1] + s1 : acc[gg][1];
+        }
+        if (!dbuf) block_lds_barrier();
+    }
+    // after the trace loop: bin N across the waves, then the block's row of sum_partial
+    __device__ __forceinline__ void finish(float *row, int nf, int lane)
+    {
+        float *xch = xch0;
+        block_lds_barrier();  // (dbuf) the last group's readers are done
+        if (lane == 0) {
+            xch[wib] = nyq_a;
+            xch[kWave + wib] = nyq_p;
+        }
+        block_lds_barrier();
+        if (wib == 0 && lane == 0) {
+            float sa = 0.0f, sp = 0.0f;
+            for (int w = 0; w < wpb; ++w) {
+                sa += xch[w];
+                sp += xch[kWave + w];
+            }
+            row[nf - 1] = sa;
+            row[2 * nf - 1] = sp;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int v = wib + slot * wpb;
+                if (v < 8) row[(v < 4 ? 0 : nf) + 256 * g + 4 * lane + (v & 3)] = acc[g][slot];
+            }
+    }
+};
+
+// a wave without a trace in the block's last round: the barriers of a whole epilogue, zeros as contribution
+template <class P>
+__device__ __forceinline__ void f_sums_idle_round(FSums<P> &sums, int lane)
+{
+    const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int g = 0; g < P::NG; ++g) sums.group(g, zero, zero, lane);
+}
+
+template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
                                                     const float *mask, size_t p, const FArgs &A,
-                                                    int lane)
+                                                    int lane, FSums<P> *sums = nullptr)
 {
+    static_assert(!SUMS || AMP_PHASE, "the sums are those of the amplitudes and phases");
     constexpr int N = P::N, NG = P::NG;
     static_assert(NG % 2 == 0, "pair ownership splits the groups in halves");
     const int nf = N + 1;
@@ -581,6 +687,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) X[c] = zf[fb[c]];
         }
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the stored amplitudes (AMP_PHASE)
         if constexpr (CMASK) {
             cx Y[4];
             {
@@ -590,7 +697,6 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
                 Y[2] = cx_mul(X[2], h23.a); Y[3] = cx_mul(X[3], h23.b);
             }
             if constexpr (AMP_PHASE) {
-                float a[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(Y[c].x, Y[c].x, Y[c].y * Y[c].y));
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
@@ -606,7 +712,6 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
                 m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
             }
             if constexpr (AMP_PHASE) {
-                float a[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
@@ -652,6 +757,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
                 last_unwrapped = wave_bcast<kWave - 1>(y[3]);
                 last_raw = prev_tail;
             }
+            if constexpr (SUMS) sums->group(g, a, y, lane);
         }
     }
     // Nyquist bin k = N (real): lane 0
@@ -674,6 +780,10 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
             float d = phn - last_raw;
             d += (d > kPi) ? -kTwoPi : ((d < -kPi) ? kTwoPi : 0.0f);
             A.ph_out[p * nf + N] = last_unwrapped + d;
+            if constexpr (SUMS) {
+                sums->nyq_a += aN;
+                sums->nyq_p += last_unwrapped + d;
+            }
         }
     }
 }
@@ -853,6 +963,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     constexpr int N = P::N, NT = P::NT, R1 = P::R1, C1 = P::C1;
     constexpr bool AMP_PHASE = (CFG & kCfgAmpPhase) != 0;
     constexpr bool CMASK = (CFG & kCfgCMask) != 0 && MODE != kInv;
+    constexpr bool SUMS = (CFG & kCfgSums) != 0;
+    static_assert(!SUMS || (MODE == kPipe && AMP_PHASE && (CFG & kCfgBar) != 0), "sums: fused chain, block-uniform trace loop");
     constexpr int ME = P::mask_entries(CFG);
     const int nf = N + 1;
     const int lane = lane_id();
@@ -927,6 +1039,10 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
 
     FAddr<P> ad;
     ad.init(lane);
+    FSums<P> sums;
+    if constexpr (SUMS)
+        sums.init(reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES), wib, wpb,
+                  THZ_UNIFORM(A.sum_dbuf));
     const size_t stride = (size_t)gridDim.x * wpb;
     size_t p = (size_t)blockIdx.x * wpb + wib;
     float raw[R1][2 * C1];
@@ -1031,8 +1147,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // spectrum stores (+ the inverse transform of the fused chain)
     auto part_b = [&]() {
         if constexpr (MODE != kInv) {
-            f_spectrum_epilogue<P, AMP_PHASE, CMASK>(buf, launder_uniform((const cx *)w2n_s),
-                                                     launder_uniform((const cx *)wg_s), mask_l, p, A, lane);
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS>(buf, launder_uniform((const cx *)w2n_s),
+                                                           launder_uniform((const cx *)wg_s), mask_l, p, A, lane, &sums);
             if constexpr (MODE == kPipe) {
                 cx r[C1][R1];
                 f_inverse_input<P, true, CMASK>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
@@ -1070,6 +1186,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             if (on) part_a();
             if (MODE != kInv && (bar & 1)) f_block_barrier(bar);
             if (on) part_b();
+            else if constexpr (SUMS) f_sums_idle_round<P>(sums, lane);
             if (MODE != kFwd && (bar & 2)) f_block_barrier(bar);
             if (on) part_c();
         }
@@ -1085,6 +1202,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     if constexpr ((CFG & kCfgBar) != 0) {
         if (pre_edge && post_edge && all_staged) trace_loop(FTrue{}, FTrue{});
         else trace_loop(FFalse{}, FTrue{});
+        if constexpr (SUMS) sums.finish(A.sum_partial + (size_t)blockIdx.x * (size_t)(2 * nf), nf, lane);
     } else {
         if (pre_edge && post_edge && all_staged) trace_loop(FTrue{}, FFalse{});
         else trace_loop(FFalse{}, FFalse{});

@@ -87,9 +87,14 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
                     float *amp_out, float *ph_out, const float *mask, const c32 *cmask = nullptr);
 void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *fft_in,
                     const float *win, float *out, float *img);
+// sum_partial: pipeline_sum_rows(P, npix, cmask != nullptr) rows of 2 nf floats, or null — every block's sums of the
+// stored amplitudes | unwrapped phases of its traces (the F kernels' kCfgSums, fft_f.hpp); a second small launch
+// (launch_sum_axis0 over the rows) makes the pixel sums of them
+size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask);
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
-                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr);
+                     float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr,
+                     float *sum_partial = nullptr);
 void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask);
 void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
                      const c32 *cmask);

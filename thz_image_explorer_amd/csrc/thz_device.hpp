@@ -35,6 +35,16 @@ __device__ __forceinline__ void wave_sync()
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
+// Block barrier that orders LDS traffic only: this wave's LDS writes are complete before it signals, and no LDS
+// read is moved above the barrier — but global stores stay in flight (`__syncthreads()` is a full workgroup fence:
+// it would drain every outstanding store of the wave at each call).
+__device__ __forceinline__ void block_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ float wave_shfl_up(float v, int d) { return __shfl_up(v, d, kWave); }
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, kWave); }
