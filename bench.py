@@ -40,7 +40,7 @@ def algorithmic_bytes_per_trace(nt):
     return 4 * nt + 16 * nf + 4 * nt + 4
 
 
-def measured_traffic(nt, traces_per_launch, wiener=False):
+def measured_traffic(nt, traces_per_launch, wiener=False, sums=False):
     """HBM bytes per launch of the fused kernel from the committed PMC passes
     (profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their
     own runs, gfx950 x2 correction on FETCH_SIZE).  Counters cannot be read from
@@ -53,7 +53,8 @@ def measured_traffic(nt, traces_per_launch, wiener=False):
             d = json.load(open(f))
         except Exception:
             continue
-        if "16,16,8" in d.get("kernel", "") and nt == 4096 and bool(d.get("wiener", False)) == wiener:
+        if ("16,16,8" in d.get("kernel", "") and nt == 4096 and bool(d.get("wiener", False)) == wiener
+                and bool(d.get("sums", False)) == sums):
             best = d
     if best is None:
         return None
@@ -224,7 +225,8 @@ def main():
     #  - the north star's 60 % target is quoted on the fused window + FFT + band-pass kernel (spectrum only,
     #    M_fwd = 8 nt + 8 bytes per trace);
     #  - BASELINE config 5's chain: the complex reference-pulse multiplier inside the same ONE launch.
-    fwd = wleg = None
+    fwd = wleg = nosum = None
+    fused_sums = (not args.no_means) and not os.environ.get("THZ_NO_FUSED_SUMS") and nt in (1024, 2048, 4096)
     if rank == 0:
         d_raw = gs.member_buffer(0, pkg.BUF_RAW)
         d_fft = gs.member_buffer(0, pkg.BUF_FFT); d_amp = gs.member_buffer(0, pkg.BUF_AMPLITUDES)
@@ -242,6 +244,18 @@ def main():
             fwd = {"kernel": "k_f<fwd> (window + R2C + band-pass, spectrum only)", "bytes_per_trace": 8 * nt + 8,
                    "avg_launch_ms": fwd_s * 1e3, "achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBPS,
                    "launches_timed": fwd_calls}
+        if fused_sums and not args.wiener:
+            # the same chain without the in-launch pixel sums (round 1's and the first round-2 builds' dominant kernel)
+            for _ in range(6):
+                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, None, None)
+            eng.sync()
+            n_ns, n_calls = eng.timing_collect(binding.STAGE_PIPELINE)
+            if n_calls:
+                n_s = n_ns / n_calls * 1e-9
+                n_gbs = npix * algorithmic_bytes_per_trace(nt) / n_s / 1e9
+                nosum = {"kernel": "k_f<pipe> (the fused chain without the pixel sums)", "bytes_per_trace": algorithmic_bytes_per_trace(nt),
+                         "avg_launch_ms": n_s * 1e3, "achieved": n_gbs, "frac": n_gbs / HBM_PEAK_GBPS, "launches_timed": n_calls,
+                         "traffic": measured_traffic(nt, npix, wiener=False, sums=False)}
         if not args.wiener:
             d_H = eng.to_device(wiener_multiplier(eng, tm))
             for _ in range(6):
@@ -285,13 +299,16 @@ def main():
                        "gather": args.gather, "step": "thz_group_session_recompute (UpdateType::Filter(1))",
                        "kernel_variant": eng.kernel_variant(),
                        "achieved_hbm_pct_whole_step": 100.0 * value / world * m_full / 1e9 / HBM_PEAK_GBPS},
-            "roofline": {"bound": "hbm", "kernel": "k_f<pipe> (fused default chain)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_f<pipe, sums> (fused default chain + amplitude / phase pixel sums in the same launch)"
+                                    if fused_sums else "k_f<pipe> (fused default chain)"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(nt, npix, wiener=args.wiener),
+                         "traffic": measured_traffic(nt, npix, wiener=args.wiener, sums=fused_sums),
                          "bytes_per_trace": m_full, "traces_per_launch": npix,
                          "avg_launch_ms": k_avg_s * 1e3, "launches_timed": pipe_calls,
                          "pixel_sum_passes_ms_per_step": (mean_ns / max(args.steps, 1)) * 1e-6 if mean_calls else None,
-                         "fused_forward_kernel": fwd, "wiener_leg": wleg},
+                         "fused_forward_kernel": fwd, "wiener_leg": wleg, "fused_chain_without_sums": nosum},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nt, ny, args.cpu_seconds)

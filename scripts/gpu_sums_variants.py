@@ -1,5 +1,5 @@
-"""Developer tool: the fused chain with its pixel sums — as two passes behind the launch, or inside it with one /
-two exchange areas and 8 / 7 / 6 waves per block — timed in ONE process on the same buffers, interleaved.
+"""Developer tool: the fused chain with its pixel sums — as two passes behind the launch, or inside it (FSums:
+ticket-ordered accumulation in LDS) — timed in ONE process on the same buffers, interleaved.
 Wall time of pipeline_ex + sync (what a recompute pays), median of several rounds."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,13 +18,11 @@ d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empt
 d_sums = eng.empty((2 * nf,))
 variants = [("no sums, 8 waves", {"NOSUMS": "1"}),
             ("no sums, 7 waves", {"NOSUMS": "1", "THZ_F_BLOCK": "448"}),
-            ("sums as two passes", {}),
-            ("in-kernel, auto", {"THZ_FUSED_SUMS": "1"}),
-            ("in-kernel, one area (7 waves at 4096)", {"THZ_FUSED_SUMS": "1", "THZ_F_SUM_DBUF": "0"}),
-            ("in-kernel, two areas (6 waves at 4096)", {"THZ_FUSED_SUMS": "1", "THZ_F_SUM_DBUF": "1"}),
-            ("in-kernel, one area, 6 waves", {"THZ_FUSED_SUMS": "1", "THZ_F_SUM_DBUF": "0", "THZ_F_BLOCK": "384"})]
+            ("sums as two passes", {"THZ_NO_FUSED_SUMS": "1"}),
+            ("sums in the launch (7 waves at nt 4096)", {}),
+            ("sums in the launch, 6 waves", {"THZ_F_BLOCK": "384"})]
 res = {}
-keys = ("THZ_F_BLOCK", "THZ_F_SUM_DBUF", "THZ_FUSED_SUMS")
+keys = ("THZ_F_BLOCK", "THZ_NO_FUSED_SUMS")
 for r in range(6):
     for name, env in variants:
         for k in keys:

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <pthread.h>
+#include <sched.h>
 
 #include <cmath>
 #include <cstdint>
@@ -111,6 +112,9 @@ namespace thz {
 
 inline void wave_sync() { pthread_barrier_wait(&thz_emu::g_sync->waves[threadIdx.x / 64]); }
 inline void block_lds_barrier() { __syncthreads(); }
+inline unsigned lds_flag_load(const unsigned *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void lds_flag_store(unsigned *p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline void spin_pause() { sched_yield(); }
 inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline float wave_shfl(float v, int src)

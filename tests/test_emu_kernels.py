@@ -468,19 +468,17 @@ def test_forward_inverse_with_store_barriers(emu, nt):
     assert np.abs(res[0][3]).max() > 0
 
 
-@pytest.mark.parametrize("bar,dbuf", [(0, -1), (3, -1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("bar", [0, 3])
 @pytest.mark.parametrize("mode", ["plain", "cmask"])
 @pytest.mark.parametrize("nt,npix", [(1024, 21), (2048, 9), (4096, 17), (4096, 3)])
-def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar, dbuf):
-    """k_f<pipe, kCfgSums>: the block's waves exchange amplitudes and unwrapped phases group by group and carry the
-    pixel sums in registers (FSums).  Every output equals the plain fused chain's bit for bit, and the sums equal the
-    column sums of the stored amplitude / phase arrays (another order of f32 additions: 2e-6).  Trace counts leave
-    ragged last rounds (idle waves take the barriers with zeros) and, for 3 traces, waves that never see a trace.
-    dbuf: one exchange area and two barriers per group (0), two areas and one barrier (1, at nt = 4096 with one wave
-    fewer), or the launcher's choice (-1)."""
+def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar):
+    """k_f<pipe, kCfgSums>: the block's waves add their amplitudes and unwrapped phases to ONE set of accumulators in
+    LDS, group by group in ticket order (FSums).  Every output equals the plain fused chain's bit for bit, and the
+    sums equal the column sums of the stored amplitude / phase arrays (another order of f32 additions: 2e-6).
+    Trace counts leave ragged last rounds (the waves without a trace stay away) and, for 3 traces, waves that never
+    see a trace."""
     emu.emu_allow_f(1)
     emu.emu_set_f_bar(bar)
-    emu.emu_set_f_sum_dbuf(dbuf)
     try:
         time = synth.make_time(nt)
         cube = synth.make_traces(np.arange(npix) + 17, nt).reshape(npix, 1, nt).copy()
@@ -510,7 +508,6 @@ def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar, dbuf):
         assert np.abs(sa).max() > 0 and np.abs(sp).max() > 0
     finally:
         emu.emu_set_f_bar(-1)
-        emu.emu_set_f_sum_dbuf(-1)
 
 
 @pytest.mark.parametrize("pairs", [1, 2])

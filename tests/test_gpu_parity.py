@@ -531,7 +531,7 @@ def _wiener_from_template(time, eps=1e-2):
 
 
 @pytest.mark.parametrize("bar", [0, 3])
-@pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums", "sums+inkernel", "cmask+sums+inkernel"])
+@pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums", "sums+passes", "cmask+sums+passes"])
 @pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (3, 5, 1001), (3, 5, 1000), (5, 5, 256)])
 def test_fused_pipeline_ex(engine, shape, mode, bar, monkeypatch):
     """thz_pipeline_ex: complex per-bin multiplier (K13) inside the fused launch, in-launch pixel sums, store-phase
@@ -539,8 +539,8 @@ def test_fused_pipeline_ex(engine, shape, mode, bar, monkeypatch):
     build-defined: the reference has no such filter).  Lengths without a fused kernel take the staged fallback."""
     nx, ny, nt = shape
     monkeypatch.setenv("THZ_F_BAR", str(bar))
-    if "inkernel" in mode:   # the F kernels' in-launch sums (FSums), opt-in: lengths without them take the passes
-        monkeypatch.setenv("THZ_FUSED_SUMS", "1")
+    if "passes" in mode:   # the F kernels take the sums inside the launch (FSums); this forces the two passes behind it
+        monkeypatch.setenv("THZ_NO_FUSED_SUMS", "1")
     time, cube = synth.make_cube(nx, ny, nt)
     e = engine
     e.set_time_axis(time)

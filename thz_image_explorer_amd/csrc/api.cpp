@@ -431,14 +431,12 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
         if (io->d_sums) HIP_TRY(ctx, hipMemsetAsync(io->d_sums, 0, 2 * nf * sizeof(float), ctx->stream));
         return THZ_OK;
     }
-    // Pixel sums: a second pass over the two arrays just written (8 nf bytes per trace).  The F kernels can also
-    // take them inside the launch (fft_f.hpp, FSums: the block's waves exchange their values group by group through
-    // a small LDS area and carry the sums in registers; a small pass adds the blocks' rows) — built, parity-tested
-    // and measured in one process (scripts/gpu_sums_variants.py, profiles/r02_sums_in_kernel.txt): the two block
-    // barriers per 256-bin group and the eighth wave the exchange area displaces cost the fused kernel what the
-    // second pass costs (nt 4096: 18.2 against 18.3 ms per Mi traces; 2048: -7 %; 1024: +4 %), so it stays behind
-    // THZ_FUSED_SUMS=1.
-    const size_t sum_rows = (io->d_sums && getenv("THZ_FUSED_SUMS"))
+    // Pixel sums: inside the launch where the plan's fused kernel can (the F kernels, nt = 1024 / 2048 / 4096: the
+    // block's waves add their amplitudes and unwrapped phases to one set of accumulators in LDS, group by group in
+    // ticket order — fft_f.hpp, FSums — and a small pass adds the blocks' rows: 15.4 against 17.8 ms per Mi traces of
+    // 4096 samples, profiles/r02_sums_in_kernel.txt), otherwise as a second pass over the two arrays just written
+    // (8 nf bytes per trace).  THZ_NO_FUSED_SUMS: developer knob, forces the second pass for A/B measurements.
+    const size_t sum_rows = (io->d_sums && !getenv("THZ_NO_FUSED_SUMS"))
                                 ? pipeline_sum_rows(ctx->plan_d, npix, io->d_fd_cmask != nullptr) : 0;
     float *d_partial = nullptr;
     if (sum_rows) {

@@ -180,13 +180,12 @@ struct FPlan {
     static constexpr int WIN_SLOTS = (N >= 2048) ? 4 : 6;  // 160 KB LDS leaves room for 4 at nt = 4096
     static constexpr int EXTRA_ENTRIES = W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
     static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
-    // kCfgSums: + the exchange area of FSums behind the wave buffers, 8 values x 64 lanes per wave, once or
-    // (sum_dbuf) twice
-    static constexpr int SUM_XCH_ENTRIES = 8 * kWave / 2;  // per wave, in cx
-    static constexpr size_t lds_bytes(int waves, int cfg = 0, bool sum_dbuf = false)
+    // kCfgSums: + the block's accumulators, tickets and scratch of FSums behind the wave buffers
+    static constexpr int SUM_ENTRIES = (2 * N + 16 + 32) / 2;  // in cx; = FSums::kAreaFloats / 2
+    static constexpr size_t lds_bytes(int waves, int cfg = 0)
     {
         return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + waves * WAVE_ENTRIES
-                        + ((cfg & kCfgSums) ? (sum_dbuf ? 2 : 1) * waves * SUM_XCH_ENTRIES : 0)) * sizeof(cx);
+                        + ((cfg & kCfgSums) ? SUM_ENTRIES : 0)) * sizeof(cx);
     }
 
     // E1[k1][m]: column bits 3..4 XORed with k1's low bits
@@ -438,7 +437,6 @@ struct FArgs {
     float *img;             // (npix) or null
     float *sum_partial;     // (gridDim.x, 2 nf): every block's sums of its traces' stored amplitudes | unwrapped
                             // phases, written whole by the block (zeros if it had no trace); kCfgSums only
-    int sum_dbuf;           // kCfgSums: the exchange area exists twice (one block barrier per group instead of two)
 };
 
 enum : int { kFwd = 0, kInv = 1, kPipe = 2 };
@@ -536,101 +534,88 @@ __device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
 // amplitude |X H| (taken before the forcing); phases are those of X, as with the real band pass
 // (band_pass_fd.rs:184-212 leaves them alone).  buf keeps the unmultiplied X.
 // kCfgSums — pixel sums of the ifft stage's amplitudes and phases (math_tools.rs:427-440: numerators of the
-// pixel means) inside the fused launch, without LDS atomics (measured: twice the kernel's time) and without 64
-// per-lane accumulators (the register file is full).  After every 256-bin group of the epilogue the W waves of
-// the block put their eight values per lane (four amplitudes, four unwrapped phases) into a small exchange area,
-// [value v][wave][lane]; behind a block barrier, wave v % W adds the W contributions of value v to its running sum
-// of (group, v) — so a wave carries NG (x 2 when W < 8) accumulators instead of 8 NG, every wave does the same
-// little work, and the sums come out in a fixed order (waves 0 .. W-1 within a round, rounds in order, blocks in
-// order in the final reduction): deterministic.  A second barrier frees the area for the next group — or, where
-// LDS has room for two areas used in turn (dbuf), none is needed: a wave reaches the writes of group g + 2 only
-// through the barrier of group g + 1, which the readers of group g pass after their reads.  The
-// barriers order LDS traffic only (block_lds_barrier): the group's global stores stay in flight.  Waves without a
-// trace in the block's last round take the same barriers with zeros (f_sums_idle_round).
-// The bin N (Nyquist) of every trace is summed per wave in lane 0 and exchanged once, after the trace loop.
+// pixel means) inside the fused launch.  The block keeps ONE set of accumulators in LDS (2 N floats: amplitude and
+// phase sums of the bins 0 .. N-1) and its waves add to it in turn: after every 256-bin group of the epilogue a wave
+// waits for its ticket of that group — round * W + wave, kept in an LDS counter per group — reads the group's
+// accumulators (two 16-byte reads per lane), adds its four amplitudes and four unwrapped phases, writes them back
+// and hands the ticket on.  No atomics (LDS float atomics doubled the kernel's time), no barriers (a barrier per
+// group put the block's waves of a memory-bound kernel in lock step: +2.5 ms per Mi traces): the waves only have to
+// come by in order, which staggers them by one short read-modify-write and otherwise leaves them a whole round of
+// slack (wave 0 of round r + 1 waits for the last wave of round r).  The order of every bin's additions is fixed —
+// waves 0 .. W-1 of round 0, then round 1, ...; the blocks' rows in order in the final reduction — so the sums are
+// deterministic.  The flag accesses and fences are LDS-scoped (lds_flag_load / lds_flag_store): nobody waits for
+// its global stores.  Waves without a trace in the block's last round are the last ones of the order and just stay
+// away.  The bin N (Nyquist) of every trace is summed per wave in lane 0 and combined once, after the trace loop.
 template <class P>
 struct FSums {
-    static constexpr int NG = P::NG;
-    float acc[NG][2];      // running sums of (group g, value v = wave + slot * W), per lane
+    static constexpr int N = P::N, NG = P::NG;
+    static constexpr int kTickets = 16;                                  // >= NG, keeps the area 16-byte sized
+    static constexpr int kAreaFloats = 2 * N + kTickets + 2 * 16;       // sums | tickets | bin-N scratch (16 waves)
+    static_assert(NG <= kTickets, "one ticket counter per group");
     float nyq_a, nyq_p;    // lane 0: bin N
-    float *xch0;           // the block's exchange area(s), W * 8 * 64 floats each
-    int wib, wpb, dbuf;
-    __device__ __forceinline__ void init(float *area, int wave_in_block, int waves_per_block, int two_areas)
+    float *area;           // [amplitude sums N][phase sums N][tickets][scratch]
+    unsigned round;        // the block's trace round this wave is in
+    int wib, wpb;
+    unsigned give_up;      // spin bound hit (never, unless a wave of the block died): poisons bin 0 of the row
+    // zeroes the area; the caller's __syncthreads() follows
+    static __device__ __forceinline__ void clear(float *area, int tid, int nthreads)
     {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = 0.0f;
+        for (int i = tid; i < kAreaFloats; i += nthreads) area[i] = 0.0f;
+    }
+    __device__ __forceinline__ void init(float *area_, int wave_in_block, int waves_per_block)
+    {
         nyq_a = nyq_p = 0.0f;
-        xch0 = area;
+        area = area_;
+        round = 0u;
         wib = wave_in_block;
         wpb = waves_per_block;
-        dbuf = two_areas;
+        give_up = 0u;
     }
-    // one group's exchange; every wave of the block calls this NG times per round, in step
+    // adds this wave's group-g values of its current trace to the block's sums, in ticket order
     __device__ __forceinline__ void group(int g, const float (&a)[4], const float (&y)[4], int lane)
     {
-        static_assert(NG % 2 == 0, "two areas in turn: a round's first group must not meet the last one's area");
-        float *xch = xch0 + ((dbuf && (g & 1)) ? 8 * wpb * kWave : 0);
-        float *mine = xch + wib * kWave + lane;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            mine[v * wpb * kWave] = a[v];
-            mine[(4 + v) * wpb * kWave] = y[v];
-        }
-        block_lds_barrier();
-        float s0 = 0.0f, s1 = 0.0f;
-        {
-            const float *col = xch + wib * wpb * kWave + lane;  // value v = wib
-            if (wib < 8)
-                for (int w = 0; w < wpb; ++w) s0 += col[w * kWave];
-            if (wib + wpb < 8) {                                // value v = wib + W (blocks of fewer than 8 waves)
-                const float *col1 = col + wpb * wpb * kWave;
-                for (int w = 0; w < wpb; ++w) s1 += col1[w * kWave];
+        unsigned *tick = reinterpret_cast<unsigned *>(area + 2 * N) + g;
+        const unsigned mine = round * (unsigned)wpb + (unsigned)wib;
+        unsigned spins = 0u;
+        while (lds_flag_load(tick) != mine) {
+            spin_pause();
+            if (++spins > (1u << 24)) {  // ~ seconds: something else is badly wrong; do not hang the GPU over it
+                give_up = 1u;
+                break;
             }
         }
-#pragma unroll
-        for (int gg = 0; gg < NG; ++gg) {
-            acc[gg][0] = (gg == g) ? acc[gg][0] + s0 : acc[gg][0];
-            acc[gg][1] = (gg == g) ? acc[gg][1] + s1 : acc[gg][1];
-        }
-        if (!dbuf) block_lds_barrier();
+        float *sa = area + 256 * g + 4 * lane, *sp = sa + N;
+        const float4 va = *reinterpret_cast<const float4 *>(sa), vp = *reinterpret_cast<const float4 *>(sp);
+        *reinterpret_cast<float4 *>(sa) = make_float4(va.x + a[0], va.y + a[1], va.z + a[2], va.w + a[3]);
+        *reinterpret_cast<float4 *>(sp) = make_float4(vp.x + y[0], vp.y + y[1], vp.z + y[2], vp.w + y[3]);
+        wave_sync();  // every lane's update is issued before lane 0 hands the ticket on
+        if (lane == 0) lds_flag_store(tick, mine + 1u);
     }
-    // after the trace loop: bin N across the waves, then the block's row of sum_partial
+    // after the trace loop (and a block barrier): bin N across the waves, then the block's row of sum_partial
     __device__ __forceinline__ void finish(float *row, int nf, int lane)
     {
-        float *xch = xch0;
-        block_lds_barrier();  // (dbuf) the last group's readers are done
+        float *scratch = area + 2 * N + kTickets;
         if (lane == 0) {
-            xch[wib] = nyq_a;
-            xch[kWave + wib] = nyq_p;
+            scratch[wib] = nyq_a;
+            scratch[16 + wib] = nyq_p;
+            if (give_up) area[0] = __builtin_nanf("");
         }
-        block_lds_barrier();
+        block_lds_barrier();  // all waves are through their last group and have left their bin-N sums
         if (wib == 0 && lane == 0) {
-            float sa = 0.0f, sp = 0.0f;
+            float a = 0.0f, ph = 0.0f;
             for (int w = 0; w < wpb; ++w) {
-                sa += xch[w];
-                sp += xch[kWave + w];
+                a += scratch[w];
+                ph += scratch[16 + w];
             }
-            row[nf - 1] = sa;
-            row[2 * nf - 1] = sp;
+            row[nf - 1] = a;
+            row[2 * nf - 1] = ph;
         }
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
-                const int v = wib + slot * wpb;
-                if (v < 8) row[(v < 4 ? 0 : nf) + 256 * g + 4 * lane + (v & 3)] = acc[g][slot];
-            }
+        for (int i = wib * kWave + lane; i < N; i += wpb * kWave) {
+            row[i] = area[i];
+            row[nf + i] = area[N + i];
+        }
     }
 };
-
-// a wave without a trace in the block's last round: the barriers of a whole epilogue, zeros as contribution
-template <class P>
-__device__ __forceinline__ void f_sums_idle_round(FSums<P> &sums, int lane)
-{
-    const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-    for (int g = 0; g < P::NG; ++g) sums.group(g, zero, zero, lane);
-}
 
 template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
@@ -991,6 +976,11 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     } else if (MODE != kInv) {
         for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
     }
+    float *sum_area = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES);
+    if constexpr (SUMS) {
+        static_assert(FSums<P>::kAreaFloats == 2 * P::SUM_ENTRIES, "LDS size of the sums area");
+        FSums<P>::clear(sum_area, (int)threadIdx.x, (int)blockDim.x);
+    }
     // window block bits (see f_edge_only), kept in the padding behind the mask
     unsigned int *bits = reinterpret_cast<unsigned int *>(mask_s + (2 * ME - 2));
     if (threadIdx.x < 2) bits[threadIdx.x] = 0u;
@@ -1040,9 +1030,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     FAddr<P> ad;
     ad.init(lane);
     FSums<P> sums;
-    if constexpr (SUMS)
-        sums.init(reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES), wib, wpb,
-                  THZ_UNIFORM(A.sum_dbuf));
+    if constexpr (SUMS) sums.init(sum_area, wib, wpb);
     const size_t stride = (size_t)gridDim.x * wpb;
     size_t p = (size_t)blockIdx.x * wpb + wib;
     float raw[R1][2 * C1];
@@ -1185,8 +1173,8 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             const bool on = p < A.npix;
             if (on) part_a();
             if (MODE != kInv && (bar & 1)) f_block_barrier(bar);
+            if constexpr (SUMS) sums.round = (unsigned)it;
             if (on) part_b();
-            else if constexpr (SUMS) f_sums_idle_round<P>(sums, lane);
             if (MODE != kFwd && (bar & 2)) f_block_barrier(bar);
             if (on) part_c();
         }

@@ -1497,7 +1497,6 @@ void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, cons
 // F family: 8 waves per block share the twiddle tables in LDS; persistent grid.  A configuration
 // whose tables do not leave room for eight wave buffers (nt = 4096 with a complex multiplier or with
 // block accumulators) runs with as many waves as fit.
-int g_f_sum_dbuf_override = -1;  // tests (the emulation harness): 0 one exchange area, 1 two, -1 automatic
 template <class PL, int CFG>
 static unsigned f_block_threads()
 {
@@ -1508,26 +1507,8 @@ static unsigned f_block_threads()
         if (v >= 64 && v <= 512 && v % 64 == 0) kBlock = (unsigned)v;
     }
 #endif
-    // kCfgSums: with one exchange area (two barriers per group) or two (one barrier); two where they cost no wave,
-    // unless THZ_F_SUM_DBUF forces the one (0) or the other (1, dropping waves until both fit) — developer knob
-    bool dbuf_forced = (CFG & kCfgSums) && g_f_sum_dbuf_override == 1;
-#ifndef THZ_EMU
-    if ((CFG & kCfgSums) && g_f_sum_dbuf_override < 0)
-        if (const char *e = getenv("THZ_F_SUM_DBUF")) dbuf_forced = atoi(e) == 1;
-#endif
-    while (kBlock > kWave && PL::lds_bytes((int)(kBlock / kWave), CFG, dbuf_forced) > kLdsBytesPerCU) kBlock -= kWave;
+    while (kBlock > kWave && PL::lds_bytes((int)(kBlock / kWave), CFG) > kLdsBytesPerCU) kBlock -= kWave;
     return kBlock;
-}
-
-template <class PL, int CFG>
-static bool f_sum_dbuf()
-{
-    if (!(CFG & kCfgSums)) return false;
-    if (g_f_sum_dbuf_override >= 0) return g_f_sum_dbuf_override == 1;
-#ifndef THZ_EMU
-    if (const char *e = getenv("THZ_F_SUM_DBUF")) return atoi(e) == 1;
-#endif
-    return PL::lds_bytes((int)(f_block_threads<PL, CFG>() / kWave), CFG, true) <= kLdsBytesPerCU;
 }
 
 // store-phase barriers of the F kernels (FArgs::bar); THZ_F_BAR overrides for A/B measurements
@@ -1545,7 +1526,7 @@ template <class PL, int MODE, int CFG>
 static size_t f_grid(size_t npix)
 {
     const unsigned kWpb = f_block_threads<PL, CFG>() / kWave;
-    const size_t lds = PL::lds_bytes((int)kWpb, CFG, f_sum_dbuf<PL, CFG>());
+    const size_t lds = PL::lds_bytes((int)kWpb, CFG);
     size_t per_cu = kLdsBytesPerCU / lds;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
@@ -1559,15 +1540,13 @@ template <class PL, int MODE, int CFG>
 static void launch_f(hipStream_t st, const PlanDev &P, const FArgs &A)
 {
     const unsigned kBlock = f_block_threads<PL, CFG>();
-    const bool dbuf = f_sum_dbuf<PL, CFG>();
-    const size_t lds = PL::lds_bytes((int)(kBlock / kWave), CFG, dbuf);
+    const size_t lds = PL::lds_bytes((int)(kBlock / kWave), CFG);
     const size_t g = f_grid<PL, MODE, CFG>(A.npix);
     FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
               reinterpret_cast<const cx *>(P.f_w2n)};
     allow_dynamic_lds(k_f<PL, MODE, CFG>, lds);
     FArgs B = A;
     B.bar = (CFG & kCfgBar) ? f_bar_mode() : 0;
-    B.sum_dbuf = dbuf ? 1 : 0;
     THZ_LAUNCH((k_f<PL, MODE, CFG>), (unsigned)g, kBlock, lds, st, B, T);
 }
 
@@ -1850,17 +1829,16 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 }
 
 // Rows of the partial-sum workspace (2 nf floats each) a fused launch with in-kernel pixel sums needs for npix
-// traces — one per block of its grid — or 0 when this plan's fused kernel cannot sum (other families; a block of
-// fewer than four waves, whose eight values per lane would need more than two accumulator slots per wave).
+// traces — one per block of its grid — or 0 when this plan has no fused kernel that sums (other families).
 template <class PL>
 static size_t f_sum_rows(size_t npix, bool cmask)
 {
     if (cmask) {
         constexpr int CFG = kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums;
-        return f_block_threads<PL, CFG>() / kWave >= 4 ? f_grid<PL, kPipe, CFG>(npix) : 0;
+        return f_grid<PL, kPipe, CFG>(npix);
     }
     constexpr int CFG = kCfgBar | kCfgAmpPhase | kCfgSums;
-    return f_block_threads<PL, CFG>() / kWave >= 4 ? f_grid<PL, kPipe, CFG>(npix) : 0;
+    return f_grid<PL, kPipe, CFG>(npix);
 }
 
 size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)

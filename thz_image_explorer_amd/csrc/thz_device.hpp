@@ -45,6 +45,21 @@ __device__ __forceinline__ void block_lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// A flag in LDS handed from wave to wave of a block: relaxed atomic accesses plus LDS-scoped fences, so that — like
+// block_lds_barrier — neither side waits for its global stores.
+__device__ __forceinline__ unsigned lds_flag_load(const unsigned *p)
+{
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return v;
+}
+__device__ __forceinline__ void lds_flag_store(unsigned *p, unsigned v)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ float wave_shfl_up(float v, int d) { return __shfl_up(v, d, kWave); }
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, kWave); }
