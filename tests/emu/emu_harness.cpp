@@ -75,14 +75,14 @@ int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, con
     return 0;
 }
 
-// fused chain with the pixel sums taken inside the launch (F family, kCfgSums): sums[0, nf) amplitudes, [nf, 2 nf)
+// fused chain with the pixel sums taken inside the launch (F family: kCfgSums / FSums; P family: PSums): sums[0, nf) amplitudes, [nf, 2 nf)
 // unwrapped phases, as thz_pipeline_ex does it (block rows + launch_sum_axis0).  Returns the number of block rows.
 int emu_pipeline_sums(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
                       const float *post, float *fft, float *amp, float *ph, float *out, float *img, float *sums)
 {
     PlanHost H;
     if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
-    if (H.family != kFamilyF) return -2;
+    if (H.family != kFamilyF && H.family != kFamilyP) return -2;
     PlanDev D = make_plan(H);
     const size_t rows = pipeline_sum_rows(D, npix, cmask != nullptr);
     if (rows == 0) return -3;

@@ -510,6 +510,46 @@ def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar):
         emu.emu_set_f_bar(-1)
 
 
+@pytest.mark.parametrize("mode", ["plain", "cmask"])
+@pytest.mark.parametrize("nt,npix", [(1001, 37), (1000, 40), (1001, 2), (1001, 1)])
+def test_mixed_radix_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode):
+    """k_p<pipe, SUMS> (PSums): the pixel sums of the stored amplitudes and unwrapped phases taken inside the launch
+    by ticket-ordered accumulation in LDS — outputs bit-identical to the launch without them, sums equal to the
+    column sums of the stored arrays; odd trace counts (a pair with one trace), more pairs than one block has waves
+    (several trips), fewer than two waves' worth"""
+    emu.emu_allow_f(1); emu.emu_allow_p(1)
+    emu.emu_set_p_pairs(1)
+    try:
+        assert emu.emu_family(nt) == 6
+        time = synth.make_time(nt)
+        cube = synth.make_traces(np.arange(npix) + 23, max(nt, 1024))[:, :nt].reshape(npix, 1, nt).copy()
+        chain = synth.default_chain(time)
+        nf = nt // 2 + 1
+        H = _wiener_cmask(time, nf) if mode == "cmask" else None
+        outs = []
+        for with_sums in (False, True):
+            fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+            ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+            sums = np.full(2 * nf, np.nan, np.float32)
+            if with_sums:
+                assert emu.emu_pipeline_sums(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                             _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img), _p(sums)) >= 1
+            else:
+                assert emu.emu_pipeline_ex(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(H),
+                                           _p(chain["w_post"]), _p(fft), _p(amp), _p(ph), _p(out), _p(img)) == 0
+            outs.append((fft, amp, ph, out, img, sums))
+        for a, b in zip(outs[0][:5], outs[1][:5]):
+            assert np.array_equal(a, b)
+        amp, ph, sums = outs[1][1], outs[1][2], outs[1][5]
+        assert np.isfinite(sums).all()
+        sa, sp = amp.astype(np.float64).sum(0), ph.astype(np.float64).sum(0)
+        assert np.abs(sums[:nf] - sa).max() <= 2e-6 * np.abs(sa).max()
+        assert np.abs(sums[nf:] - sp).max() <= 2e-6 * max(np.abs(sp).max(), 1.0)
+        assert np.abs(sa).max() > 0
+    finally:
+        emu.emu_set_p_pairs(0)
+
+
 @pytest.mark.parametrize("pairs", [1, 2])
 @pytest.mark.parametrize("nt", [1001, 1000])
 def test_mixed_radix_pipeline_complex_multiplier(emu, nt, pairs):

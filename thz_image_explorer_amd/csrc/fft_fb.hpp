@@ -33,6 +33,7 @@ struct FBArgs {
     const cx *w;            // nt: exp(-i pi n^2 / nt)
     const cx *bf;           // M : FFT_M(b) / M
     const cx *cmask;        // nf complex multipliers on top of `mask`, or nullptr (P kernels)
+    float *sum_partial;     // (gridDim.x, 2 nf): every block's sums of its traces' stored amplitudes | unwrapped phases (k_p<..., SUMS>)
 };
 
 // LDS per block, in floats behind the core tables: [mask nf][pre nt][post nt], each padded to 4
@@ -83,6 +84,9 @@ __device__ __forceinline__ void fb_multiply_swapped(const cx *buf, const cx *__r
 // value for the inverse.
 struct FBUnwrap {
     float carry = 0.0f, prev_tail = 0.0f, first = 0.0f;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, y[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the group just finished: stored amplitudes and
+                                                                            // unwrapped phases of this lane's four bins (0 where
+                                                                            // the bin does not exist) — for the in-launch pixel sums
 };
 
 // f / ao / po may each be null (stage entry points that do not want that output)
@@ -114,6 +118,8 @@ __device__ __forceinline__ void fb_phase_bins(const cx (&X)[4], const bool (&ok)
     const float base = u.carry + excl;
     u.carry += wave_bcast<kWave - 1>(incl);
     u.prev_tail = wave_bcast<kWave - 1>(ph[3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u.y[c] = ok[c] ? u.first + (base + s_[c]) : 0.0f;
     if (!po) return;
     if (ok[3]) {
         store_f4(po, u.first + (base + s_[0]), u.first + (base + s_[1]), u.first + (base + s_[2]),
@@ -156,6 +162,8 @@ __device__ __forceinline__ void fb_finish_bins(const cx (&X)[4], const float (&m
         Y[c] = cx{X[c].x * m[c], X[c].y * m[c]};
     }
     fb_store_bins(Y, a, ok, f, ao);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u.a[c] = ok[c] ? a[c] : 0.0f;
     fb_phase_bins(X, ok, g, lane, u, po);
 }
 
@@ -174,6 +182,8 @@ __device__ __forceinline__ void fb_finish_bins_c(const cx (&X)[4], const cx (&h)
         if (real_bin[c]) Y[c].y = 0.0f;
     }
     fb_store_bins(Y, a, ok, f, ao);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u.a[c] = ok[c] ? a[c] : 0.0f;
     fb_phase_bins(X, ok, g, lane, u, po);
 }
 

@@ -147,10 +147,13 @@ struct PPlan {
     // LDS per block: [T1: N cx, [k1][m]][T2: R2 R3 cx, [k2][j3]][per wave: N cx (+pad)][mask nf floats, or nf cx][pre N][post N]
     static constexpr int T1_ENTRIES = N, T2_ENTRIES = M1 + (M1 & 1);
     static constexpr int WAVE_ENTRIES = N + (N & 1);
-    static constexpr size_t lds_bytes(int waves, int pairs_per_wave = 1, bool cmask = false)
+    // in-launch pixel sums (PSums): amplitude | phase accumulators over the epilogue's 256-bin groups, tickets, spare
+    static constexpr int SUM_BINS = 256 * ((NF + 255) / 256);
+    static constexpr int SUM_FLOATS = 2 * SUM_BINS + 16;
+    static constexpr size_t lds_bytes(int waves, int pairs_per_wave = 1, bool cmask = false, bool sums = false)
     {
         return (size_t)(T1_ENTRIES + T2_ENTRIES + waves * pairs_per_wave * WAVE_ENTRIES) * sizeof(cx)
-               + (size_t)((cmask ? 2 : 1) * pad4(NF) + 2 * pad4(N)) * sizeof(float);
+               + (size_t)((cmask ? 2 : 1) * pad4(NF) + 2 * pad4(N) + (sums ? SUM_FLOATS : 0)) * sizeof(float);
     }
 };
 
@@ -289,13 +292,73 @@ __device__ __forceinline__ float p_zero_if(float v, bool zero)
     return __builtin_bit_cast(float, bits);
 }
 
+// In-launch pixel sums of the stored amplitudes and unwrapped phases (the numerators of the ifft stage's pixel means,
+// math_tools.rs:427-440), as in the F kernels (fft_f.hpp, FSums): the block keeps one set of accumulators in LDS and
+// its waves add to it group by group in TICKET order — wave w's visit of group g in its r-th trip has ticket
+// r W + w in the group's counter — so there are no atomics, no barriers, and the order of every bin's additions is
+// fixed (deterministic sums).  A wave adds both traces of its pair in one visit.  Waves without a pair in the
+// block's last trip are the last ones of the order and stay away.
+template <class P>
+struct PSums {
+    static constexpr int SB = P::SUM_BINS;
+    float *area;       // [amplitude sums SB][phase sums SB][16 tickets]
+    unsigned round;
+    int wib, wpb;
+    unsigned give_up;
+    static __device__ __forceinline__ void clear(float *area, int tid, int nthreads)
+    {
+        for (int i = tid; i < P::SUM_FLOATS; i += nthreads) area[i] = 0.0f;
+    }
+    __device__ __forceinline__ void init(float *area_, int wave_in_block, int waves_per_block)
+    {
+        area = area_; round = 0u; wib = wave_in_block; wpb = waves_per_block; give_up = 0u;
+    }
+    __device__ __forceinline__ void group(int g, const FBUnwrap &u1, const FBUnwrap &u2, bool has2, int lane)
+    {
+        unsigned *tick = reinterpret_cast<unsigned *>(area + 2 * SB) + g;
+        const unsigned mine = round * (unsigned)wpb + (unsigned)wib;
+        unsigned spins = 0u;
+        while (lds_flag_load(tick) != mine) {
+            spin_pause();
+            if (++spins > (1u << 24)) {  // never, unless a wave of the block died: do not hang the GPU over it
+                give_up = 1u;
+                break;
+            }
+        }
+        float *sa = area + 256 * g + 4 * lane, *sp = sa + SB;
+        float4 va = *reinterpret_cast<const float4 *>(sa), vp = *reinterpret_cast<const float4 *>(sp);
+        va = make_float4(va.x + u1.a[0], va.y + u1.a[1], va.z + u1.a[2], va.w + u1.a[3]);
+        vp = make_float4(vp.x + u1.y[0], vp.y + u1.y[1], vp.z + u1.y[2], vp.w + u1.y[3]);
+        if (has2) {  // wave-uniform
+            va = make_float4(va.x + u2.a[0], va.y + u2.a[1], va.z + u2.a[2], va.w + u2.a[3]);
+            vp = make_float4(vp.x + u2.y[0], vp.y + u2.y[1], vp.z + u2.y[2], vp.w + u2.y[3]);
+        }
+        *reinterpret_cast<float4 *>(sa) = va;
+        *reinterpret_cast<float4 *>(sp) = vp;
+        wave_sync();  // every lane's update is issued before lane 0 hands the ticket on
+        if (lane == 0) lds_flag_store(tick, mine + 1u);
+    }
+    // after the trip loop and a block barrier: the block's row of sum_partial
+    __device__ __forceinline__ void finish(float *row, int nf, int tid, int nthreads)
+    {
+        if (give_up && (tid & (kWave - 1)) == 0) area[0] = __builtin_nanf("");
+        block_lds_barrier();
+        for (int i = tid; i < nf; i += nthreads) {
+            row[i] = area[i];
+            row[nf + i] = area[SB + i];
+        }
+    }
+};
+
 // Same argument block as the chirp-z kernels (w / bf unused).  A wave takes Q consecutive pairs (a "unit" of
 // 2 Q traces) per trip.
 // CM: A.cmask holds nf complex multipliers H[k] applied on top of the real mask (stored spectrum X m H, amplitude
 // |X m H|, phase of X; see fb_finish_bins_c) — the reference-pulse deconvolution of a real scan in the same launch.
-template <class P, int MODE, int Q, bool CM = false>
+// SUMS (fused chain, Q = 1): the pixel sums of the stored amplitudes and phases in the same launch (PSums).
+template <class P, int MODE, int Q, bool CM = false, bool SUMS = false>
 __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 {
+    static_assert(!SUMS || (MODE == kPipe && Q == 1), "in-launch sums: the fused chain, one pair per wave");
     THZ_DYN_LDS(lds);
     constexpr int N = P::N, NF = P::NF, R1 = P::R1, M1 = P::M1, WE = P::WAVE_ENTRIES;
     constexpr int RD1 = PAddr<P, Q>::RD1;
@@ -308,6 +371,8 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + (size_t)wpb * (Q * WE));
     float *pre_s = mask_s + (CM ? 2 : 1) * P::pad4(NF);
     float *post_s = pre_s + P::pad4(N);
+    float *sum_area = post_s + P::pad4(N);
+    if constexpr (SUMS) PSums<P>::clear(sum_area, (int)threadIdx.x, (int)blockDim.x);
     for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     for (int i = (int)threadIdx.x; i < M1; i += (int)blockDim.x) t2[i] = T.t2[i];
     if constexpr (CM) {
@@ -328,6 +393,8 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 
     PAddr<P, Q> ad;
     ad.init(lane);
+    PSums<P> sums;
+    if constexpr (SUMS) sums.init(sum_area, wib, wpb);
     const DivConst by_nt((float)N);
     constexpr int n_groups = (NF + 255) / 256;  // epilogue groups of 256 bins: bin = 256 g + 4 lane + c
     const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
@@ -335,6 +402,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
 
     for (size_t u = (size_t)blockIdx.x * wpb + wib; u < n_units; u += stride) {
         const size_t p0 = 2 * Q * u;  // first trace of the unit
+        if constexpr (SUMS) sums.round = (unsigned)((u - ((size_t)blockIdx.x * wpb + wib)) / stride);
         ad.refresh();
         const cx *t1l = launder_uniform((const cx *)t1);
         const cx *t2l = launder_uniform((const cx *)t2);
@@ -433,6 +501,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                             fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
                                            A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr);
                     }
+                    if constexpr (SUMS) sums.group(g, u1, u2, has2, lane);
                     // input of the inverse, in place: conj(G[k]) and conj(G[N-k]) of G = Y1full + i Y2full
                     // (Yfull[n] = Y[n] up to N/2, conj(Y[N-n]) above) — bin k's owner is the only reader of
                     // slots k and N-k
@@ -543,6 +612,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
         }
         wave_sync();
     }
+    if constexpr (SUMS) sums.finish(A.sum_partial + (size_t)blockIdx.x * (size_t)(2 * NF), NF, (int)threadIdx.x, (int)blockDim.x);
 }
 
 }  // namespace thz

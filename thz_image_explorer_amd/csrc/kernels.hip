@@ -1642,25 +1642,42 @@ static int p_pairs()
     return kPPairsDefault;
 }
 
-template <class PL, int MODE, int Q, bool CM>
-static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
+template <class PL, int Q, bool CM, bool SUMS>
+static void p_geometry(size_t npix, unsigned *waves_out, size_t *grid_out, size_t *lds_out)
 {
     unsigned waves = 16 / Q;
-    while (waves > 1 && PL::lds_bytes((int)waves, Q, CM) > kLdsBytesPerCU) --waves;
-    const size_t lds = PL::lds_bytes((int)waves, Q, CM);
-    const size_t n_units = (A.npix + 2 * Q - 1) / (2 * Q);
+    while (waves > 1 && PL::lds_bytes((int)waves, Q, CM, SUMS) > kLdsBytesPerCU) --waves;
+    const size_t n_units = (npix + 2 * Q - 1) / (2 * Q);
     size_t g = (n_units + waves - 1) / waves;
     if (g > (size_t)kNumCU) g = kNumCU;
     if (g < 1) g = 1;
+    *waves_out = waves;
+    *grid_out = g;
+    *lds_out = PL::lds_bytes((int)waves, Q, CM, SUMS);
+}
+
+template <class PL, int MODE, int Q, bool CM, bool SUMS = false>
+static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
+{
+    unsigned waves;
+    size_t g, lds;
+    p_geometry<PL, Q, CM, SUMS>(A.npix, &waves, &g, &lds);
     PTables T{reinterpret_cast<const cx *>(P.p_t1), reinterpret_cast<const cx *>(P.p_t2)};
-    allow_dynamic_lds(k_p<PL, MODE, Q, CM>, lds);
-    THZ_LAUNCH((k_p<PL, MODE, Q, CM>), (unsigned)g, waves * kWave, lds, st, A, T);
+    allow_dynamic_lds(k_p<PL, MODE, Q, CM, SUMS>, lds);
+    THZ_LAUNCH((k_p<PL, MODE, Q, CM, SUMS>), (unsigned)g, waves * kWave, lds, st, A, T);
 }
 
 template <class PL, int MODE>
 static void launch_p_variant(hipStream_t st, const PlanDev &P, const FBArgs &A)
 {
     const bool two = p_pairs() == 2;
+    if constexpr (MODE == kPipe) {
+        if (A.sum_partial && !two) {  // pixel sums inside the launch (PSums)
+            if (A.cmask) launch_p<PL, MODE, 1, true, true>(st, P, A);
+            else launch_p<PL, MODE, 1, false, true>(st, P, A);
+            return;
+        }
+    }
     if constexpr (MODE != kInv) {
         if (A.cmask) {  // complex multiplier on top of the band pass
             if (two) launch_p<PL, MODE, 2, true>(st, P, A);
@@ -1670,6 +1687,18 @@ static void launch_p_variant(hipStream_t st, const PlanDev &P, const FBArgs &A)
     }
     if (two) launch_p<PL, MODE, 2, false>(st, P, A);
     else launch_p<PL, MODE, 1, false>(st, P, A);
+}
+
+// rows of the partial-sum workspace of a P launch with in-launch sums (one per block), 0 when it has none
+template <class PL>
+static size_t p_sum_rows(size_t npix, bool cmask)
+{
+    if (p_pairs() == 2) return 0;
+    unsigned waves;
+    size_t g, lds;
+    if (cmask) p_geometry<PL, 1, true, true>(npix, &waves, &g, &lds);
+    else p_geometry<PL, 1, false, true>(npix, &waves, &g, &lds);
+    return g;
 }
 
 template <int MODE>
@@ -1843,7 +1872,9 @@ static size_t f_sum_rows(size_t npix, bool cmask)
 
 size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
 {
-    if (P.family != kFamilyF || npix == 0) return 0;
+    if (npix == 0) return 0;
+    if (P.family == kFamilyP) return P.nt == 1001 ? p_sum_rows<PPlan1001>(npix, cmask) : p_sum_rows<PPlan1000>(npix, cmask);
+    if (P.family != kFamilyF) return 0;
     switch (P.nt) {
     case 4096: return f_sum_rows<FPlan4096>(npix, cmask);
     case 2048: return f_sum_rows<FPlan2048>(npix, cmask);
@@ -1886,6 +1917,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
         A.data_out = data_out; A.img = img;
         A.cmask = reinterpret_cast<const cx *>(cmask);
+        A.sum_partial = sum_partial;
         dispatch_p<kPipe>(st, P, A);
         return;
     }
