@@ -6,7 +6,7 @@
 
 using namespace thz;
 
-namespace thz { extern int g_f_bar_override; extern int g_p_pairs_override; }
+namespace thz { extern int g_f_bar_override; extern int g_p_pairs_override; extern int g_grid_cap_override; }
 
 static int g_allow_f = 1, g_allow_p = 1;
 static std::vector<float> g_ones;
@@ -62,6 +62,7 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 
 void emu_set_f_bar(int mode) { thz::g_f_bar_override = mode; }
 void emu_set_p_pairs(int q) { thz::g_p_pairs_override = q; }
+void emu_set_grid_cap(int blocks) { thz::g_grid_cap_override = blocks; }
 
 // fused chain with a complex multiplier (F and P families); FArgs::bar via emu_set_f_bar
 int emu_pipeline_ex(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,

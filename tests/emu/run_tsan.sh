@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the emulated kernels with a sanitizer and runs tests/emu/tsan_driver.cpp.
-# Usage: [SAN=thread|address,undefined] tests/emu/run_tsan.sh [f|g|fb|fbc|rl|dc|helpers|voxel]
+# Usage: [SAN=thread|address,undefined] tests/emu/run_tsan.sh [f|sums|g|fb|fbc|rl|dc|helpers|voxel]
 # (SAN defaults to thread; no argument: every kernel family)
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"

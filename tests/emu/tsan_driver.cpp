@@ -15,7 +15,10 @@ int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const flo
 int emu_fft_inv(int nt, size_t npix, const float *fft, const float *win, float *out, float *img);
 int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *post,
                  float *fft, float *amp, float *ph, float *out, float *img);
+int emu_pipeline_sums(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
+                      const float *post, float *fft, float *amp, float *ph, float *out, float *img, float *sums);
 void emu_allow_f(int on);
+void emu_set_grid_cap(int blocks);
 int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d, const float *u,
                      int tiled, float *t_out, float *u_out);
 int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, const float *in, const float *H,
@@ -71,6 +74,24 @@ int main(int argc, char **argv)
         return false;
     };
     if (want("f")) { chain(1024, 11, 1); chain(2048, 9, 1); chain(4096, 9, 1); }
+    if (want("sums")) {  // the fused chain with its pixel sums taken inside the launch: ticket-ordered LDS accumulation
+        emu_allow_f(1);   // (FSums / PSums) — lock-free hand-over between the waves of a block, the case for this tool
+        emu_set_grid_cap(1);  // one block: its waves go through several rounds, the last one ragged
+        for (int nt : {1024, 4096, 1001}) {
+            for (int cm = 0; cm < 2; ++cm) {
+                const size_t npix = nt == 4096 ? 17 : (nt == 1001 ? 75 : 21), nf = (size_t)nt / 2 + 1;
+                auto x = noise(npix * nt, (unsigned)nt + 77);
+                auto pre = noise((size_t)nt, 1, 0.5f, 1.0f), post = noise((size_t)nt, 2, 0.5f, 1.0f), mask = noise(nf, 3, 0.0f, 1.0f);
+                auto H = noise(2 * nf, 4, -1.0f, 1.0f);
+                std::vector<float> fft(npix * nf * 2), amp(npix * nf), ph(npix * nf), out(npix * nt), img(npix), sums(2 * nf);
+                const int rows = emu_pipeline_sums(nt, npix, x.data(), pre.data(), mask.data(), cm ? H.data() : nullptr, post.data(),
+                                                   fft.data(), amp.data(), ph.data(), out.data(), img.data(), sums.data());
+                std::printf("sums nt=%d cmask=%d rows=%d done\n", nt, cm, rows);
+                std::fflush(stdout);
+            }
+        }
+        emu_set_grid_cap(0);
+    }
     if (want("g")) { chain(256, 7, 0); chain(1024, 5, 0); }
     if (want("fb")) { chain(1001, 5, 1); chain(300, 6, 1); }
     if (want("fbc")) { chain(1500, 3, 1); chain(3000, 3, 1); chain(5000, 3, 1); }

@@ -470,15 +470,17 @@ def test_forward_inverse_with_store_barriers(emu, nt):
 
 @pytest.mark.parametrize("bar", [0, 3])
 @pytest.mark.parametrize("mode", ["plain", "cmask"])
-@pytest.mark.parametrize("nt,npix", [(1024, 21), (2048, 9), (4096, 17), (4096, 3)])
-def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar):
+@pytest.mark.parametrize("nt,npix,cap", [(1024, 21, 0), (2048, 9, 0), (4096, 17, 0), (4096, 3, 0), (4096, 17, 1), (1024, 37, 2)])
+def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, cap, mode, bar):
     """k_f<pipe, kCfgSums>: the block's waves add their amplitudes and unwrapped phases to ONE set of accumulators in
     LDS, group by group in ticket order (FSums).  Every output equals the plain fused chain's bit for bit, and the
     sums equal the column sums of the stored amplitude / phase arrays (another order of f32 additions: 2e-6).
     Trace counts leave ragged last rounds (the waves without a trace stay away) and, for 3 traces, waves that never
-    see a trace."""
+    see a trace; cap: at most that many blocks, so that a block's waves go through several rounds (tickets of
+    successive rounds, the last round ragged)."""
     emu.emu_allow_f(1)
     emu.emu_set_f_bar(bar)
+    emu.emu_set_grid_cap(cap)
     try:
         time = synth.make_time(nt)
         cube = synth.make_traces(np.arange(npix) + 17, nt).reshape(npix, 1, nt).copy()
@@ -508,17 +510,19 @@ def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode, bar):
         assert np.abs(sa).max() > 0 and np.abs(sp).max() > 0
     finally:
         emu.emu_set_f_bar(-1)
+        emu.emu_set_grid_cap(0)
 
 
 @pytest.mark.parametrize("mode", ["plain", "cmask"])
-@pytest.mark.parametrize("nt,npix", [(1001, 37), (1000, 40), (1001, 2), (1001, 1)])
-def test_mixed_radix_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode):
+@pytest.mark.parametrize("nt,npix,cap", [(1001, 37, 0), (1000, 40, 0), (1001, 2, 0), (1001, 1, 0), (1001, 75, 1)])
+def test_mixed_radix_pipeline_in_kernel_pixel_sums(emu, nt, npix, cap, mode):
     """k_p<pipe, SUMS> (PSums): the pixel sums of the stored amplitudes and unwrapped phases taken inside the launch
     by ticket-ordered accumulation in LDS — outputs bit-identical to the launch without them, sums equal to the
     column sums of the stored arrays; odd trace counts (a pair with one trace), more pairs than one block has waves
-    (several trips), fewer than two waves' worth"""
+    (cap = 1: one block, three trips, the last one ragged), fewer than two waves' worth"""
     emu.emu_allow_f(1); emu.emu_allow_p(1)
     emu.emu_set_p_pairs(1)
+    emu.emu_set_grid_cap(cap)
     try:
         assert emu.emu_family(nt) == 6
         time = synth.make_time(nt)
@@ -548,6 +552,7 @@ def test_mixed_radix_pipeline_in_kernel_pixel_sums(emu, nt, npix, mode):
         assert np.abs(sa).max() > 0
     finally:
         emu.emu_set_p_pairs(0)
+        emu.emu_set_grid_cap(0)
 
 
 @pytest.mark.parametrize("pairs", [1, 2])

@@ -20,6 +20,7 @@ def _run(san, families=()):
 
 
 REACHED = ("chain nt=4096 allow_f=1 done", "chain nt=1001 allow_f=1 done", "chain nt=5000 allow_f=1 done",
+           "sums nt=4096 cmask=1", "sums nt=1001 cmask=1",   # the in-launch pixel sums: lock-free ticket hand-over in LDS
            "rl done", "dc done", "helpers done", "voxel done")
 
 
@@ -44,7 +45,7 @@ def test_kernels_stay_in_bounds():
     launch's dynamic-LDS size, so a lane reading or writing past it (the GPU would hand back zeros or a
     neighbour's data) is an error here, as is any global access outside the caller's arrays"""
     # the cooperative chirp-z kernels (nt = 3000, 5000) take minutes under this sanitizer: the other families
-    p = _run("address,undefined", ("f", "g", "fb", "rl", "dc", "helpers", "voxel"))
+    p = _run("address,undefined", ("f", "sums", "g", "fb", "rl", "dc", "helpers", "voxel"))
     out = p.stdout
     if "unsupported option" in out:
         pytest.skip("sanitizer runtime not available")

@@ -1522,6 +1522,8 @@ static int f_bar_mode()
     return kFBarDefault;
 }
 
+int g_grid_cap_override = 0;  // tests (the emulation harness): at most this many blocks for the F / P transform kernels,
+                              // so that a handful of traces already takes a block through several rounds
 template <class PL, int MODE, int CFG>
 static size_t f_grid(size_t npix)
 {
@@ -1532,6 +1534,7 @@ static size_t f_grid(size_t npix)
     if (per_cu > 2) per_cu = 2;
     size_t g = (npix + kWpb - 1) / kWpb;
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (g_grid_cap_override > 0 && g > (size_t)g_grid_cap_override) g = (size_t)g_grid_cap_override;
     if (g < 1) g = 1;
     return g;
 }
@@ -1650,6 +1653,7 @@ static void p_geometry(size_t npix, unsigned *waves_out, size_t *grid_out, size_
     const size_t n_units = (npix + 2 * Q - 1) / (2 * Q);
     size_t g = (n_units + waves - 1) / waves;
     if (g > (size_t)kNumCU) g = kNumCU;
+    if (g_grid_cap_override > 0 && g > (size_t)g_grid_cap_override) g = (size_t)g_grid_cap_override;
     if (g < 1) g = 1;
     *waves_out = waves;
     *grid_out = g;
