@@ -89,7 +89,7 @@ int emu_pipeline_sums(int nt, size_t npix, const float *raw, const float *pre, c
     if (rows == 0) return -3;
     std::vector<float> partial(rows * 2 * (size_t)D.nf, -777.0f);  // every entry must be written by the kernel
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask, partial.data());
-    launch_sum_axis0(nullptr, partial.data(), rows, 2 * (size_t)D.nf, 0.0f, sums);
+    launch_sum_rows_f64(nullptr, partial.data(), rows, 2 * (size_t)D.nf, sums);
     return (int)rows;
 }
 

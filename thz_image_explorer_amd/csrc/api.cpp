@@ -453,7 +453,7 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
     if (!io->d_sums) return THZ_OK;
     if (d_partial) {
         StageTimer t(ctx, THZ_STAGE_MEAN);
-        launch_sum_axis0(ctx->stream, d_partial, sum_rows, 2 * nf, 0.0f, io->d_sums);
+        launch_sum_rows_f64(ctx->stream, d_partial, sum_rows, 2 * nf, io->d_sums);
         return check_launch(ctx);
     }
     if (int rc = thz_pixel_sum(ctx, npix, nf, 1, io->d_amp, io->d_sums)) return rc;

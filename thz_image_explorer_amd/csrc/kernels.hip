@@ -557,6 +557,27 @@ __global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr
     }
 }
 
+// the rows the fused launches leave per block (in-launch pixel sums): few and short, so the adds run in double and
+// add nothing to the f32 error of the blocks' own chains
+__global__ __launch_bounds__(256) void k_sum_rows_f64(const float *__restrict__ arr, size_t n0, size_t inner,
+                                                      float *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        size_t a = 0;
+        const float *col = arr + i;
+        for (; a + 16 <= n0; a += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = col[(a + u) * inner];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (double)v[u];
+        }
+        for (; a < n0; ++a) s += (double)col[a * inner];
+        out[i] = (float)s;
+    }
+}
+
 // Column sums with memory-level parallelism (pixel-mean partials of big cubes):
 // one block per row group; thread t owns the 16-byte column chunks t, t+256, ...
 // of every row (a full row is read by consecutive chunk-iterations, 4 KiB each)
@@ -1990,6 +2011,11 @@ void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner,
                       float *out)
 {
     THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out);
+}
+
+void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inner, float *out)
+{
+    THZ_LAUNCH(k_sum_rows_f64, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, out);
 }
 
 // returns the number of partial rows written to `partial` (each L floats); 0 if L is

@@ -107,6 +107,7 @@ void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *i
                       int subtract_bias);
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
                       float *out);
+void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inner, float *out);  // column sums of a few rows, adds in double
 size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,
                              float *partial, size_t max_groups);
 void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_min, uint64_t x_max,
