@@ -150,6 +150,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("THZ_BENCH_DEVICE"):   # rehearsal knob: every rank on this device (with THZ_RCCL_LIB = tests/mock_rccl)
+        local_rank = int(os.environ["THZ_BENCH_DEVICE"])
     if args.gpus != world and args.gpus > 1:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got WORLD_SIZE={world})")
     import torch

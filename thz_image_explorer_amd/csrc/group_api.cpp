@@ -46,10 +46,13 @@ bool rccl_load()
 {
     Rccl &r = rccl();
     if (r.h) return true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.h) break;
-    }
+    // THZ_RCCL_LIB: developer knob — the library to open in RCCL's place (tests/mock_rccl: several ranks on ONE GPU)
+    if (const char *override_path = getenv("THZ_RCCL_LIB")) r.h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+    else
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
     if (!r.h) {
         r.err = std::string("cannot open librccl: ") + dlerror();
         return false;
