@@ -295,9 +295,9 @@ __device__ __forceinline__ float p_zero_if(float v, bool zero)
 // In-launch pixel sums of the stored amplitudes and unwrapped phases (the numerators of the ifft stage's pixel means,
 // math_tools.rs:427-440), as in the F kernels (fft_f.hpp, FSums): the block keeps one set of accumulators in LDS and
 // its waves add to it group by group in TICKET order — wave w's visit of group g in its r-th trip has ticket
-// r W + w in the group's counter — so there are no atomics, no barriers, and the order of every bin's additions is
-// fixed (deterministic sums).  A wave adds both traces of its pair in one visit.  Waves without a pair in the
-// block's last trip are the last ones of the order and stay away.
+// 2 (r W + w) (+ 1 for the pair's second trace) in the group's counter — so there are no atomics, no barriers, and the order of every bin's additions is
+// fixed (deterministic sums).  Waves without a pair in the block's last trip are the last ones of the order and stay
+// away.
 template <class P>
 struct PSums {
     static constexpr int SB = P::SUM_BINS;
@@ -313,10 +313,14 @@ struct PSums {
     {
         area = area_; round = 0u; wib = wave_in_block; wpb = waves_per_block; give_up = 0u;
     }
-    __device__ __forceinline__ void group(int g, const FBUnwrap &u1, const FBUnwrap &u2, bool has2, int lane)
+    // adds one trace's group-g values (t = 0 / 1: the pair's first / second trace; live = false: the pair has no second
+    // trace, only the ticket moves on).  A wave's two visits hold consecutive tickets, (round W + wave) 2 + t, so the
+    // second never waits for another wave — and only one trace's eight values are alive at a time (the kernel sits at
+    // the 128-VGPR cap of a 1 024-thread block).
+    __device__ __forceinline__ void group(int g, int t, const FBUnwrap &u, bool live, int lane)
     {
         unsigned *tick = reinterpret_cast<unsigned *>(area + 2 * SB) + g;
-        const unsigned mine = round * (unsigned)wpb + (unsigned)wib;
+        const unsigned mine = (round * (unsigned)wpb + (unsigned)wib) * 2u + (unsigned)t;
         unsigned spins = 0u;
         while (lds_flag_load(tick) != mine) {
             spin_pause();
@@ -325,16 +329,12 @@ struct PSums {
                 break;
             }
         }
-        float *sa = area + 256 * g + 4 * lane, *sp = sa + SB;
-        float4 va = *reinterpret_cast<const float4 *>(sa), vp = *reinterpret_cast<const float4 *>(sp);
-        va = make_float4(va.x + u1.a[0], va.y + u1.a[1], va.z + u1.a[2], va.w + u1.a[3]);
-        vp = make_float4(vp.x + u1.y[0], vp.y + u1.y[1], vp.z + u1.y[2], vp.w + u1.y[3]);
-        if (has2) {  // wave-uniform
-            va = make_float4(va.x + u2.a[0], va.y + u2.a[1], va.z + u2.a[2], va.w + u2.a[3]);
-            vp = make_float4(vp.x + u2.y[0], vp.y + u2.y[1], vp.z + u2.y[2], vp.w + u2.y[3]);
+        if (live) {  // wave-uniform
+            float *sa = area + 256 * g + 4 * lane, *sp = sa + SB;
+            const float4 va = *reinterpret_cast<const float4 *>(sa), vp = *reinterpret_cast<const float4 *>(sp);
+            *reinterpret_cast<float4 *>(sa) = make_float4(va.x + u.a[0], va.y + u.a[1], va.z + u.a[2], va.w + u.a[3]);
+            *reinterpret_cast<float4 *>(sp) = make_float4(vp.x + u.y[0], vp.y + u.y[1], vp.z + u.y[2], vp.w + u.y[3]);
         }
-        *reinterpret_cast<float4 *>(sa) = va;
-        *reinterpret_cast<float4 *>(sp) = vp;
         wave_sync();  // every lane's update is issued before lane 0 hands the ticket on
         if (lane == 0) lds_flag_store(tick, mine + 1u);
     }
@@ -386,7 +386,9 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
         for (int i = (int)threadIdx.x; i < NF; i += (int)blockDim.x) mask_s[i] = A.mask[i];
     }
     for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
-        pre_s[i] = A.pre_win ? A.pre_win[i] : 1.0f;
+        // the 1/2 of the spectrum split X1 = (Z[k] + conj Z[N-k]) / 2 rides on the window: exact (a power of two), and
+        // eight multiplies per bin quad fewer in the epilogue
+        pre_s[i] = 0.5f * (A.pre_win ? A.pre_win[i] : 1.0f);
         post_s[i] = A.post_win ? A.post_win[i] : 1.0f;
     }
     __syncthreads();
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
             }
             p_pass23<P, Q>(buf, t2l, ad, lane);  // buf[q WE + k] = Z_q[k] = X1[k] + i X2[k] of pair q
 
-            // ---- spectrum epilogue, pair by pair: X1 = (Z[k] + conj Z[N-k]) / 2, X2 = (Z[k] - conj Z[N-k]) / 2i
+            // ---- spectrum epilogue, pair by pair: X1 = (Z[k] + conj Z[N-k]) / 2, X2 = (Z[k] - conj Z[N-k]) / 2i (buf holds Z / 2)
 #pragma unroll 1
             for (int q = 0; q < Q; ++q) {
                 if (2 * q >= n_tr) break;  // wave-uniform
@@ -470,8 +472,8 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                         const int km = kc == 0 ? 0 : N - kc;  // Z[N] = Z[0]
                         kcs[c] = kc;
                         const cx Fk = bq[kc], Fm = bq[km];
-                        X1[c] = cx{0.5f * (Fk.x + Fm.x), 0.5f * (Fk.y - Fm.y)};
-                        X2[c] = cx{0.5f * (Fk.y + Fm.y), -0.5f * (Fk.x - Fm.x)};
+                        X1[c] = cx{Fk.x + Fm.x, Fk.y - Fm.y};   // Z carries the factor 1/2 already (pre_s)
+                        X2[c] = cx{Fk.y + Fm.y, Fm.x - Fk.x};
                         if constexpr (CM) h[c] = reinterpret_cast<const cx *>(mask_l)[kc];
                         else m[c] = mask_l[kc];
                         // real input: DC / Nyquist bins are real, with a POSITIVE zero as imaginary part (realfft writes
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                     if constexpr (CM) {
                         fb_finish_bins_c(X1, h, rb, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
                                          A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr, Y1);
+                        if constexpr (SUMS) sums.group(g, 0, u1, true, lane);
                         if (has2)
                             fb_finish_bins_c(X2, h, rb, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
                                              A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr, Y2);
@@ -497,11 +500,12 @@ __global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
                     } else {
                         fb_finish_bins(X1, m, ok, g, lane, u1, A.fft_out ? A.fft_out + o1 : nullptr,
                                        A.amp_out ? A.amp_out + o1 : nullptr, A.ph_out ? A.ph_out + o1 : nullptr);
+                        if constexpr (SUMS) sums.group(g, 0, u1, true, lane);
                         if (has2)
                             fb_finish_bins(X2, m, ok, g, lane, u2, A.fft_out ? A.fft_out + o1 + NF : nullptr,
                                            A.amp_out ? A.amp_out + o1 + NF : nullptr, A.ph_out ? A.ph_out + o1 + NF : nullptr);
                     }
-                    if constexpr (SUMS) sums.group(g, u1, u2, has2, lane);
+                    if constexpr (SUMS) sums.group(g, 1, u2, has2, lane);
                     // input of the inverse, in place: conj(G[k]) and conj(G[N-k]) of G = Y1full + i Y2full
                     // (Yfull[n] = Y[n] up to N/2, conj(Y[N-n]) above) — bin k's owner is the only reader of
                     // slots k and N-k
