@@ -755,3 +755,34 @@ def test_fused_chain_inverts_exactly_the_stored_spectrum(engine, nt, cmask):
     assert np.abs(a).max() > 0
     assert np.array_equal(a, b)
     assert np.array_equal(d_img.download((npix,), np.float32), d_img2.download((npix,), np.float32))
+
+
+@pytest.mark.parametrize("nt,counts", [(4096, (1, 6, 7, 8, 13, 1792 + 5, 2 * 1792 + 1)), (1024, (1, 9, 2048 + 3, 4096 + 2049)),
+                                       (2048, (7, 2048 + 1)), (1001, (1, 2, 3, 33, 8192 + 3, 16384 + 1)), (1000, (5, 8192 + 2))])
+def test_in_launch_pixel_sums_ragged_trace_counts(engine, nt, counts):
+    """The ticket order of the in-launch pixel sums (FSums / PSums) over trace counts that leave every kind of ragged
+    last round: fewer traces than one block has waves, one more than a whole number of rounds of the whole grid, waves
+    and whole blocks that never see a trace.  Sums against float64 column sums of the stored arrays; a miscounted
+    ticket would hang (bounded: the kernel poisons bin 0 instead) or drop a trace."""
+    e = engine
+    time = synth.make_time(nt)
+    e.set_time_axis(time)
+    chain = synth.default_chain(time)
+    nf = nt // 2 + 1
+    nmax = max(counts)
+    d_t = e.to_device(time); d_raw = e.empty((nmax, nt)); e.synth_cube(d_raw, nmax, 0, d_t)
+    d_pre = e.to_device(chain["w_pre"]); d_fd = e.to_device(chain["fd_mask"]); d_post = e.to_device(chain["w_post"])
+    d_fft = e.empty((nmax, nf, 2)); d_amp = e.empty((nmax, nf)); d_ph = e.empty((nmax, nf)); d_out = e.empty((nmax, nt))
+    d_img = e.empty((nmax,)); d_sums = e.empty((2 * nf,))
+    for npix in counts:
+        e.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums)
+        e.sync()
+        sums = d_sums.download((2 * nf,), np.float32)
+        amp = d_amp.download((nmax, nf), np.float32)[:npix].astype(np.float64)
+        ph = d_ph.download((nmax, nf), np.float32)[:npix].astype(np.float64)
+        assert np.isfinite(sums).all(), npix
+        sa, sp = amp.sum(0), ph.sum(0)
+        assert np.abs(sums[:nf] - sa).max() <= 2e-6 * np.abs(sa).max(), npix
+        assert np.abs(sums[nf:] - sp).max() <= 2e-6 * max(np.abs(sp).max(), 1.0), npix
+    for b in (d_t, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums):
+        b.free()
