@@ -232,12 +232,12 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
  *               ONE pass over HBM: spectrum = X * (cmask * mask), imaginary parts of bin 0 and (even
  *               nt) of the last bin forced to 0 (math_tools.rs:510-512), amplitudes = |X cmask mask|,
  *               phases those of X (band_pass_fd.rs:184-212 does not touch them either).  Fused for nt = 1024 / 2048 /
- *               4096 and 1001 / 1000 (the F and P kernel families); trace lengths
+ *               4096 and 1001 / 1000 / 1200 / 1500 / 2000 (the F and P kernel families); trace lengths
  *               without a fused kernel for it run fft -> thz_apply_fd_cmask -> ifft internally.
  *   d_sums      (2 nf) or NULL: sum over the npix traces of the stored amplitudes [0, nf) and of the
  *               unwrapped phases [nf, 2 nf) — the numerators of the pixel means of the ifft stage
  *               (math_tools.rs:427-440; divide by nx ny, or all-reduce the sums of the tiles first).  For
- *               nt = 1024 / 2048 / 4096 and 1001 / 1000 they are taken INSIDE the launch (every block adds its
+ *               nt = 1024 / 2048 / 4096 and 1001 / 1000 / 1200 / 1500 / 2000 they are taken INSIDE the launch (every block adds its
  *               traces' values to accumulators in LDS, wave by wave in a fixed order; a small pass adds the
  *               blocks' rows), for other lengths by thz_pixel_sum passes over d_amp / d_phase behind it.
  *               Deterministic; the summation order differs from the reference's sequential one (<= 2e-6

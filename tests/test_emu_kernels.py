@@ -45,6 +45,9 @@ def _fwd(emu, x, wa, mask, nt):
     return dout, fft, amp, ph
 
 
+P_LENGTHS = (1001, 1000, 1200, 1500, 2000)   # trace lengths with a mixed-radix (P) kernel, plan_host.hpp p_factors
+
+
 @pytest.mark.parametrize("family", ["auto", "g", "nop"])
 @pytest.mark.parametrize("nt", [4, 16, 64, 256, 1024, 2048, 4096, 1001, 1000, 30, 1500, 3000])
 def test_forward_inverse_vs_oracle(emu, nt, family):
@@ -52,14 +55,14 @@ def test_forward_inverse_vs_oracle(emu, nt, family):
     emu.emu_allow_p(1 if family == "auto" else 0)
     if family == "g" and nt not in (1024, 2048, 4096):
         pytest.skip("only one family exists for this length")
-    if family == "nop" and nt not in (1001, 1000):
+    if family == "nop" and nt not in P_LENGTHS:
         pytest.skip("no P kernel for this length anyway")
     # auto: F for 1024/2048/4096, P (mixed radix) for 1001 / 1000, FB / FB2 / FB4 (chirp-z over the F core) for
     # the other lengths below 4096 that are not a power of two; nop: the same without the P kernels
     want = 0
     if family != "g":
         want = 1 if nt in (1024, 2048, 4096) else ((2 if nt < 1024 else 3 if nt < 2048 else 4) if nt & (nt - 1) else 0)
-        if family == "auto" and nt in (1001, 1000):
+        if family == "auto" and nt in P_LENGTHS:
             want = 6
     assert emu.emu_family(nt) == want
     npix = 11  # > waves per block: exercises the grid-stride loop and a ragged last block
@@ -142,13 +145,16 @@ def test_chirpz_pipeline_vs_oracle(emu, nt):
 
 
 @pytest.mark.parametrize("pairs", [1, 2])
-@pytest.mark.parametrize("nt,npix_shape", [(1001, (5, 1)), (1001, (2, 3)), (1001, (1, 1)), (1001, (7, 1)), (1000, (5, 1)), (1000, (3, 6))])
+@pytest.mark.parametrize("nt,npix_shape", [(1001, (5, 1)), (1001, (2, 3)), (1001, (1, 1)), (1001, (7, 1)), (1000, (5, 1)), (1000, (3, 6)),
+                                           (1200, (5, 1)), (1500, (3, 1)), (2000, (3, 1))])
 def test_mixed_radix_pipeline_vs_oracle(emu, nt, npix_shape, pairs):
     """P kernels (fft_p.hpp): nt = 1001 = 7 x 11 x 13 (the length of real scans) and 1000 = 10 x 10 x 10 as one
     direct three-pass mixed-radix transform per pair of traces; odd and even trace counts, more pairs than one
     block has waves"""
     emu.emu_allow_f(1)
     emu.emu_allow_p(1)
+    if pairs == 2 and nt > 1001:
+        pytest.skip("the round lengths 1200 / 1500 / 2000 are built with one pair per wave only")
     emu.emu_set_p_pairs(pairs)   # one or two pairs of traces per wave: units of 2 or 4 traces, ragged last unit
     assert emu.emu_family(nt) == 6
     nx, ny = npix_shape

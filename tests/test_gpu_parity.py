@@ -532,7 +532,8 @@ def _wiener_from_template(time, eps=1e-2):
 
 @pytest.mark.parametrize("bar", [0, 3])
 @pytest.mark.parametrize("mode", ["sums", "cmask", "cmask+sums", "sums+passes", "cmask+sums+passes"])
-@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (3, 5, 1001), (3, 5, 1000), (5, 5, 256)])
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 7, 2048), (5, 9, 4096), (4, 4, 1001), (3, 5, 1001), (3, 5, 1000), (3, 5, 2000),
+                                   (5, 5, 256)])
 def test_fused_pipeline_ex(engine, shape, mode, bar, monkeypatch):
     """thz_pipeline_ex: complex per-bin multiplier (K13) inside the fused launch, in-launch pixel sums, store-phase
     barriers — vs the oracle (plain chain) / a numpy fp64 model of the definition in DESIGN.md §7 (K13 is
@@ -652,18 +653,19 @@ def test_chirpz_fused_pipeline_lengths(engine, shape):
 
 
 @pytest.mark.parametrize("family", [0, 2])
-@pytest.mark.parametrize("shape", [(4, 4, 1001), (5, 1, 1001), (37, 19, 1001), (3, 3, 1000), (64, 33, 1000)])
+@pytest.mark.parametrize("shape", [(4, 4, 1001), (5, 1, 1001), (37, 19, 1001), (3, 3, 1000), (64, 33, 1000),
+                                   (5, 3, 1200), (7, 3, 1500), (33, 5, 2000), (1, 1, 2000)])
 def test_mixed_radix_fused_pipeline(engine, shape, family):
-    """nt = 1001 = 7 x 11 x 13 and 1000 = 10 x 10 x 10: the P kernels (one direct mixed-radix transform per pair
-    of traces) and, with family 2, the chirp-z kernels they replace — same oracle, same tolerances; trace counts
-    odd and even, fewer and more pairs than a block has waves"""
+    """nt = 1001 = 7 x 11 x 13, 1000 = 10 x 10 x 10 and the round lengths 1200 / 1500 / 2000 = 10 x 10 x 12 / 15 / 20:
+    the P kernels (one direct mixed-radix transform per pair of traces) and, with family 2, the chirp-z kernels they
+    replace — same oracle, same tolerances; trace counts odd and even, fewer and more pairs than a block has waves"""
     nx, ny, nt = shape
     time = synth.make_time(nt)
     cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 1024))[:, :nt].reshape(nx, ny, nt).copy()
     engine.set_kernel_family(family)
     try:
         engine.set_time_axis(time)
-        assert engine.kernel_variant().startswith("p-mixed-radix" if family == 0 else "fb-bluestein")
+        assert engine.kernel_variant().startswith("p-mixed-radix" if family == 0 else ("fb-bluestein" if nt < 1024 else "fb2-"))
         got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
         # the stage entry points use the same kernels in forward-only / inverse-only form
         st_g = gpu_fft_stage(engine, cube, pkg.host_fft_window(time, 0, 1.0, 7.0))
@@ -731,7 +733,7 @@ def test_polar_ifft_of_averaged_spectra(engine, nt):
 
 
 @pytest.mark.parametrize("cmask", [False, True])
-@pytest.mark.parametrize("nt", [1001, 1000, 1024, 2048, 4096, 1500, 640])
+@pytest.mark.parametrize("nt", [1001, 1000, 1024, 2048, 4096, 1500, 2000, 1502, 640])
 def test_fused_chain_inverts_exactly_the_stored_spectrum(engine, nt, cmask):
     """The reference's ifft stage reads the fft stage's stored output (data_thread.rs:1090-1105); a Filter(6 / 7)
     update re-runs the stand-alone inverse on the resident spectrum.  So the fused launch's time-domain output must
@@ -758,7 +760,8 @@ def test_fused_chain_inverts_exactly_the_stored_spectrum(engine, nt, cmask):
 
 
 @pytest.mark.parametrize("nt,counts", [(4096, (1, 6, 7, 8, 13, 1792 + 5, 2 * 1792 + 1)), (1024, (1, 9, 2048 + 3, 4096 + 2049)),
-                                       (2048, (7, 2048 + 1)), (1001, (1, 2, 3, 33, 8192 + 3, 16384 + 1)), (1000, (5, 8192 + 2))])
+                                       (2048, (7, 2048 + 1)), (1001, (1, 2, 3, 33, 8192 + 3, 16384 + 1)), (1000, (5, 8192 + 2)),
+                                       (2000, (1, 9, 2048 + 3)), (1500, (7, 6144 + 1))])
 def test_in_launch_pixel_sums_ragged_trace_counts(engine, nt, counts):
     """The ticket order of the in-launch pixel sums (FSums / PSums) over trace counts that leave every kind of ragged
     last round: fewer traces than one block has waves, one more than a whole number of rounds of the whole grid, waves

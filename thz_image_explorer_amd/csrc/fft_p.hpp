@@ -160,6 +160,24 @@ struct PPlan {
 constexpr int kPPairsDefault = 1;  // pairs of traces per wave unless THZ_P_PAIRS says otherwise
 using PPlan1001 = PPlan<7, 11, 13>;
 using PPlan1000 = PPlan<10, 10, 10>;
+using PPlan1200 = PPlan<10, 10, 12>;  // round lengths beyond the reference's sample data (one pair per wave only)
+using PPlan1500 = PPlan<10, 10, 15>;
+using PPlan2000 = PPlan<10, 10, 20>;
+
+// threads of the largest block a launch of plan P with Q pairs per wave can have (the launcher fits the waves to LDS;
+// the table-only configuration fits the most)
+// waves of a block: as many as LDS holds — except that 13 to 15 waves become 12: a thirteenth wave puts four waves on
+// one SIMD and so costs every wave of the block a quarter of its registers (170 -> 128), which only a full sixteen
+// are worth
+template <class P>
+constexpr int p_block_waves(int q, bool cmask, bool sums)
+{
+    int w = 16 / q;
+    while (w > 1 && P::lds_bytes(w, q, cmask, sums) > (size_t)160 * 1024) --w;
+    return (w >= 13 && w < 16) ? 12 : w;
+}
+template <class P>
+constexpr int p_max_threads(int q) { return p_block_waves<P>(q, false, false) * kWave; }
 
 struct PTables {
     const cx *t1;  // [k1][m]  W_N^(m k1),           N entries
@@ -356,7 +374,7 @@ struct PSums {
 // |X m H|, phase of X; see fb_finish_bins_c) — the reference-pulse deconvolution of a real scan in the same launch.
 // SUMS (fused chain, Q = 1): the pixel sums of the stored amplitudes and phases in the same launch (PSums).
 template <class P, int MODE, int Q, bool CM = false, bool SUMS = false>
-__global__ __launch_bounds__(Q == 1 ? 1024 : 512) void k_p(FBArgs A, PTables T)
+__global__ __launch_bounds__(p_max_threads<P>(Q)) void k_p(FBArgs A, PTables T)
 {
     static_assert(!SUMS || (MODE == kPipe && Q == 1), "in-launch sums: the fused chain, one pair per wave");
     THZ_DYN_LDS(lds);

@@ -1669,8 +1669,7 @@ static int p_pairs()
 template <class PL, int Q, bool CM, bool SUMS>
 static void p_geometry(size_t npix, unsigned *waves_out, size_t *grid_out, size_t *lds_out)
 {
-    unsigned waves = 16 / Q;
-    while (waves > 1 && PL::lds_bytes((int)waves, Q, CM, SUMS) > kLdsBytesPerCU) --waves;
+    const unsigned waves = (unsigned)p_block_waves<PL>(Q, CM, SUMS);
     const size_t n_units = (npix + 2 * Q - 1) / (2 * Q);
     size_t g = (n_units + waves - 1) / waves;
     if (g > (size_t)kNumCU) g = kNumCU;
@@ -1692,10 +1691,10 @@ static void launch_p(hipStream_t st, const PlanDev &P, const FBArgs &A)
     THZ_LAUNCH((k_p<PL, MODE, Q, CM, SUMS>), (unsigned)g, waves * kWave, lds, st, A, T);
 }
 
-template <class PL, int MODE>
+template <class PL, int MODE, bool ALLOW_TWO = true>
 static void launch_p_variant(hipStream_t st, const PlanDev &P, const FBArgs &A)
 {
-    const bool two = p_pairs() == 2;
+    const bool two = ALLOW_TWO && p_pairs() == 2;
     if constexpr (MODE == kPipe) {
         if (A.sum_partial && !two) {  // pixel sums inside the launch (PSums)
             if (A.cmask) launch_p<PL, MODE, 1, true, true>(st, P, A);
@@ -1705,20 +1704,22 @@ static void launch_p_variant(hipStream_t st, const PlanDev &P, const FBArgs &A)
     }
     if constexpr (MODE != kInv) {
         if (A.cmask) {  // complex multiplier on top of the band pass
-            if (two) launch_p<PL, MODE, 2, true>(st, P, A);
-            else launch_p<PL, MODE, 1, true>(st, P, A);
+            if constexpr (ALLOW_TWO)
+                if (two) { launch_p<PL, MODE, 2, true>(st, P, A); return; }
+            launch_p<PL, MODE, 1, true>(st, P, A);
             return;
         }
     }
-    if (two) launch_p<PL, MODE, 2, false>(st, P, A);
-    else launch_p<PL, MODE, 1, false>(st, P, A);
+    if constexpr (ALLOW_TWO)
+        if (two) { launch_p<PL, MODE, 2, false>(st, P, A); return; }
+    launch_p<PL, MODE, 1, false>(st, P, A);
 }
 
 // rows of the partial-sum workspace of a P launch with in-launch sums (one per block), 0 when it has none
-template <class PL>
+template <class PL, bool ALLOW_TWO = true>
 static size_t p_sum_rows(size_t npix, bool cmask)
 {
-    if (p_pairs() == 2) return 0;
+    if (ALLOW_TWO && p_pairs() == 2) return 0;
     unsigned waves;
     size_t g, lds;
     if (cmask) p_geometry<PL, 1, true, true>(npix, &waves, &g, &lds);
@@ -1733,6 +1734,9 @@ static void dispatch_p(hipStream_t st, const PlanDev &P, FBArgs &A)
     A.nf = P.nf;
     switch (P.nt) {
     case 1001: launch_p_variant<PPlan1001, MODE>(st, P, A); break;
+    case 1200: launch_p_variant<PPlan1200, MODE, false>(st, P, A); break;
+    case 1500: launch_p_variant<PPlan1500, MODE, false>(st, P, A); break;
+    case 2000: launch_p_variant<PPlan2000, MODE, false>(st, P, A); break;
     default: launch_p_variant<PPlan1000, MODE>(st, P, A); break;
     }
 }
@@ -1898,7 +1902,15 @@ static size_t f_sum_rows(size_t npix, bool cmask)
 size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
 {
     if (npix == 0) return 0;
-    if (P.family == kFamilyP) return P.nt == 1001 ? p_sum_rows<PPlan1001>(npix, cmask) : p_sum_rows<PPlan1000>(npix, cmask);
+    if (P.family == kFamilyP) {
+        switch (P.nt) {
+        case 1001: return p_sum_rows<PPlan1001>(npix, cmask);
+        case 1200: return p_sum_rows<PPlan1200, false>(npix, cmask);
+        case 1500: return p_sum_rows<PPlan1500, false>(npix, cmask);
+        case 2000: return p_sum_rows<PPlan2000, false>(npix, cmask);
+        default: return p_sum_rows<PPlan1000>(npix, cmask);
+        }
+    }
     if (P.family != kFamilyF) return 0;
     switch (P.nt) {
     case 4096: return f_sum_rows<FPlan4096>(npix, cmask);

@@ -29,6 +29,9 @@ inline bool p_factors(size_t nt, int &r1, int &r2, int &r3)
     switch (nt) {
     case 1001: r1 = 7; r2 = 11; r3 = 13; return true;   // every real scan of the reference's sample data
     case 1000: r1 = 10; r2 = 10; r3 = 10; return true;
+    case 1200: r1 = 10; r2 = 10; r3 = 12; return true;  // round lengths of other instruments: same kernels,
+    case 1500: r1 = 10; r2 = 10; r3 = 15; return true;  // one pair of traces per wave only
+    case 2000: r1 = 10; r2 = 10; r3 = 20; return true;
     default: return false;
     }
 }
@@ -178,7 +181,10 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
     if (allow_f && allow_p && p_factors(nt, q1, q2, q3)) {
         // the chirp-z tables above stay (stage entry points without a P kernel fall back to them)
         P.family = kFamilyP;
-        P.variant = nt == 1001 ? "p-mixed-radix-7x11x13-regs-lds" : "p-mixed-radix-10x10x10-regs-lds";
+        static const char *const kVariants[] = {"p-mixed-radix-7x11x13-regs-lds", "p-mixed-radix-10x10x10-regs-lds",
+                                                "p-mixed-radix-10x10x12-regs-lds", "p-mixed-radix-10x10x15-regs-lds",
+                                                "p-mixed-radix-10x10x20-regs-lds"};
+        P.variant = kVariants[nt == 1001 ? 0 : nt == 1000 ? 1 : nt == 1200 ? 2 : nt == 1500 ? 3 : 4];
         const size_t m1 = (size_t)q2 * q3;
         P.p_t1.resize(nt);
         for (int k1 = 0; k1 < q1; ++k1)
