@@ -100,7 +100,7 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
 /* Kernel family selection: 0 = automatic (register-resident three-pass "F"
  * kernels for nt = 1024/2048/4096; mixed-radix "P" kernels for the lengths that
  * factor into three small radices — nt = 1001 = 7 x 11 x 13, the length of the
- * reference's real scans, and 1000; chirp-z over the F core — "FB" kernels —
+ * reference's real scans, and 1000 / 1200 / 1500 / 2000; chirp-z over the F core — "FB" kernels —
  * for the other lengths that are not a power of two; LDS Stockham "G" kernels
  * for the remaining powers of two), 1 = G kernels (Stockham / Bluestein in LDS)
  * for every length, 2 = automatic without the P kernels (A/B measurements, tests).
