@@ -789,3 +789,33 @@ def test_in_launch_pixel_sums_ragged_trace_counts(engine, nt, counts):
         assert np.abs(sums[nf:] - sp).max() <= 2e-6 * max(np.abs(sp).max(), 1.0), npix
     for b in (d_t, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums):
         b.free()
+
+
+@pytest.mark.parametrize("nt,npix", [(4096, 40000), (1001, 50001)])
+def test_in_launch_pixel_sums_are_deterministic(engine, nt, npix):
+    """The tickets fix the order of every bin's additions (waves of a block in turn, rounds in order, blocks' rows in
+    order), so repeated launches give the SAME bits — which an atomics-based accumulation would not.  Twenty launches
+    over tens of rounds per block; also a soak of the hand-over itself."""
+    e = engine
+    time = synth.make_time(nt)
+    e.set_time_axis(time)
+    chain = synth.default_chain(time)
+    nf = nt // 2 + 1
+    d_t = e.to_device(time); d_raw = e.empty((npix, nt)); e.synth_cube(d_raw, npix, 0, d_t)
+    d_pre = e.to_device(chain["w_pre"]); d_fd = e.to_device(chain["fd_mask"]); d_post = e.to_device(chain["w_post"])
+    d_fft = e.empty((npix, nf, 2)); d_amp = e.empty((npix, nf)); d_ph = e.empty((npix, nf)); d_out = e.empty((npix, nt))
+    d_img = e.empty((npix,)); d_sums = e.empty((2 * nf,))
+    first = None
+    for _ in range(20):
+        e.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums)
+        e.sync()
+        sums = d_sums.download((2 * nf,), np.float32)
+        assert np.isfinite(sums).all()
+        if first is None:
+            first = sums
+        else:
+            assert np.array_equal(sums, first)
+    amp = d_amp.download((npix, nf), np.float32).astype(np.float64)
+    assert np.abs(first[:nf] - amp.sum(0)).max() <= 2e-6 * np.abs(amp.sum(0)).max()
+    for b in (d_t, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums):
+        b.free()
