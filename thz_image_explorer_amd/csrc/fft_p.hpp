@@ -555,15 +555,30 @@ __global__ __launch_bounds__(p_max_threads<P>(Q)) void k_p(FBArgs A, PTables T)
                 const bool live = 2 * q < n_tr, has2 = 2 * q + 1 < n_tr;
                 const cx *f1 = A.fft_in + (p0 + (live ? 2 * (size_t)q : 0)) * (size_t)NF;
                 cx *bq = buf + q * WE;
-                for (int k = lb1; k < NF; k += kWave) {
-                    cx y1 = ld_off(f1, (unsigned)k);
-                    cx y2 = has2 ? ld_off(f1, (unsigned)(NF + k)) : cx{0.0f, 0.0f};
-                    if (k == 0 || ((N & 1) == 0 && k == NF - 1)) {
-                        y1.y = 0.0f;
-                        y2.y = 0.0f;
+                // every bin's loads are issued before the first is used: one trip to HBM per pair (the loop form waited
+                // for each pair of loads in turn — with the 7 to 12 waves of the longer plans that latency showed)
+                constexpr int KI = (NF + kWave - 1) / kWave;
+                cx y1v[KI], y2v[KI];
+#pragma unroll
+                for (int i = 0; i < KI; ++i) {
+                    const int k = lb1 + kWave * i;
+                    const unsigned kc = (unsigned)(k < NF ? k : NF - 1);  // in bounds; unused when k >= NF
+                    y1v[i] = ld_off(f1, kc);
+                    y2v[i] = ld_off(f1, has2 ? (unsigned)NF + kc : kc);
+                }
+#pragma unroll
+                for (int i = 0; i < KI; ++i) {
+                    const int k = lb1 + kWave * i;
+                    if (k < NF) {
+                        cx y1 = y1v[i];
+                        cx y2 = has2 ? y2v[i] : cx{0.0f, 0.0f};
+                        if (k == 0 || ((N & 1) == 0 && k == NF - 1)) {
+                            y1.y = 0.0f;
+                            y2.y = 0.0f;
+                        }
+                        bq[k] = cx{y1.x - y2.y, -y1.y - y2.x};
+                        if (k != 0 && 2 * k != N) bq[N - k] = cx{y1.x + y2.y, y1.y - y2.x};
                     }
-                    bq[k] = cx{y1.x - y2.y, -y1.y - y2.x};
-                    if (k != 0 && 2 * k != N) bq[N - k] = cx{y1.x + y2.y, y1.y - y2.x};
                 }
             }
             wave_sync();
