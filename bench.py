@@ -310,7 +310,10 @@ def main():
                          "bytes_per_trace": m_full, "traces_per_launch": npix,
                          "avg_launch_ms": k_avg_s * 1e3, "launches_timed": pipe_calls,
                          "pixel_sum_passes_ms_per_step": (mean_ns / max(args.steps, 1)) * 1e-6 if mean_calls else None,
-                         "fused_forward_kernel": fwd, "wiener_leg": wleg, "fused_chain_without_sums": nosum},
+                         "fused_forward_kernel": fwd, "wiener_leg": wleg, "fused_chain_without_sums": nosum,
+                         "note": ("the dominant kernel carries the pixel sums since late round 2 (they were a 3.1 ms second pass over "
+                                  "16 GiB): compare `fused_chain_without_sums` with earlier rounds' roofline.frac, and `config."
+                                  "achieved_hbm_pct_whole_step` for the step as a whole") if fused_sums else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nt, ny, args.cpu_seconds)
