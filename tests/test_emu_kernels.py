@@ -333,6 +333,12 @@ def test_helper_kernels(emu):
     out = np.empty_like(x)
     assert emu.emu_td_window(C.c_size_t(npix), nt, _p(x), _p(wv), _p(out)) == 0
     assert np.array_equal(out, x * wv)
+    for nt2 in (256, 1024, 4096):   # whole rounds of a wave's 16-byte accesses: the window chunks live in registers
+        x2 = rng.standard_normal((npix, nt2)).astype(np.float32)
+        w2 = rng.random(nt2).astype(np.float32)
+        o2 = np.empty_like(x2)
+        assert emu.emu_td_window(C.c_size_t(npix), nt2, _p(x2), _p(w2), _p(o2)) == 0
+        assert np.array_equal(o2, x2 * w2)
     # K8 sums: rows of nf and 2 nf floats (only 4-byte aligned), above and below the two-level threshold
     for nrows, L in ((300, 513), (70, 1026), (40, 129), (9000, 130)):
         a = rng.standard_normal((nrows, L)).astype(np.float32)

@@ -494,6 +494,31 @@ __global__ __launch_bounds__(256) void k_td_window(size_t npix, int nt,
     }
 }
 
+// The same for trace lengths that are CH whole rounds of a wave's 16-byte accesses (nt = 256 CH, CH <= 16): a lane meets
+// the same CH window chunks in every trace, so it keeps them in registers — the loop then issues one load and one
+// store per chunk instead of two loads and a store, and all CH loads of a trace before its first store.
+template <int CH>
+__global__ __launch_bounds__(256) void k_td_window_regs(size_t npix, const float *__restrict__ in, const float *__restrict__ win,
+                                                        float *__restrict__ out)
+{
+    constexpr int nt = 256 * CH;
+    const int lane = lane_id();
+    const int wpb = (int)(blockDim.x >> 6);
+    float4 w[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) w[c] = *reinterpret_cast<const float4 *>(win + 4 * lane + 256 * c);
+    for (size_t p = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = in + p * (size_t)nt + 4 * lane;
+        float *y = out + p * (size_t)nt + 4 * lane;
+        float4 v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = *reinterpret_cast<const float4 *>(x + 256 * c);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<float4 *>(y + 256 * c) = make_float4(v[c].x * w[c].x, v[c].y * w[c].y, v[c].z * w[c].z, v[c].w * w[c].w);
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_intensity(size_t npix, int nt, float *__restrict__ data,
                                                    float *__restrict__ img, int subtract_bias)
@@ -2005,6 +2030,16 @@ void launch_td_window(hipStream_t st, size_t npix, int nt, const float *in, cons
 {
     const bool vec = nt % 4 == 0 && ((uintptr_t)in | (uintptr_t)win | (uintptr_t)out) % 16 == 0;
     const unsigned grid = grid_1d(npix * kWave, 256, kNumCU * 8);
+    if (vec && nt % 256 == 0 && nt <= 4096) {  // the window chunks of a lane in registers
+        switch (nt / 256) {
+        case 1: THZ_LAUNCH(k_td_window_regs<1>, grid, 256, 0, st, npix, in, win, out); return;
+        case 2: THZ_LAUNCH(k_td_window_regs<2>, grid, 256, 0, st, npix, in, win, out); return;
+        case 4: THZ_LAUNCH(k_td_window_regs<4>, grid, 256, 0, st, npix, in, win, out); return;
+        case 8: THZ_LAUNCH(k_td_window_regs<8>, grid, 256, 0, st, npix, in, win, out); return;
+        case 16: THZ_LAUNCH(k_td_window_regs<16>, grid, 256, 0, st, npix, in, win, out); return;
+        default: break;
+        }
+    }
     if (vec) THZ_LAUNCH(k_td_window<true>, grid, 256, 0, st, npix, nt, in, win, out);
     else THZ_LAUNCH(k_td_window<false>, grid, 256, 0, st, npix, nt, in, win, out);
 }
