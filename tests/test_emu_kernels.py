@@ -363,6 +363,11 @@ def test_helper_kernels(emu):
     o = np.empty((nx // sf, ny // sf, L), np.float32)
     assert emu.emu_scale3d(_p(a), C.c_size_t(nx), C.c_size_t(ny), C.c_size_t(L), C.c_size_t(sf), _p(o)) == 0
     assert np.array_equal(o, ob.scale3d(a, sf))
+    for L2, sf2 in ((132, 2), (1024, 3)):   # rows of whole 16-byte chunks: the vector path; s = 3: a divisor that is no power of two
+        a2 = rng.standard_normal((nx, ny, L2)).astype(np.float32)
+        o2 = np.empty((nx // sf2, ny // sf2, L2), np.float32)
+        assert emu.emu_scale3d(_p(a2), C.c_size_t(nx), C.c_size_t(ny), C.c_size_t(L2), C.c_size_t(sf2), _p(o2)) == 0
+        assert np.array_equal(o2, ob.scale3d(a2, sf2))
     # K11 tilt copy: front fill with the first sample, tapered trace at its insert index, clipped at the end
     npix, nt_in, nt_out = 13, 300, 340
     x = rng.standard_normal((npix, nt_in)).astype(np.float32)

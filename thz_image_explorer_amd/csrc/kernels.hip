@@ -757,26 +757,44 @@ __global__ __launch_bounds__(256) void k_tilt(size_t npix, int nt_in, int nt_out
 
 // Block mean over s x s pixels (math_tools.rs:273-301): one wave per output pixel, sample axis
 // across the lanes, the s*s inputs added in the reference's i-outer / j-inner order.
+// VEC: rows are whole 16-byte chunks at 16-byte-aligned addresses — four samples per lane and access.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_scale3d(const float *__restrict__ arr, size_t nx,
                                                  size_t ny, size_t L, size_t s,
                                                  float *__restrict__ out)
 {
     const size_t nw = nx / s, nh = ny / s;
-    const float sf = (float)(s * s);
+    const DivConst by_ss((float)(s * s));  // the exact quotient (thz_device.hpp), not a reciprocal multiply
     const int lane = lane_id();
     const int wpb = (int)(blockDim.x >> 6);
     for (size_t q = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); q < nw * nh; q += (size_t)gridDim.x * wpb) {
         const size_t ax = q / nh, ay = q % nh;
         float *o = out + q * L;
+        if constexpr (VEC) {
+#pragma unroll 2
+            for (size_t z = 4 * (size_t)lane; z < L; z += 4 * kWave) {
+                float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (size_t i = 0; i < s; ++i)
+                    for (size_t j = 0; j < s; ++j) {
+                        const size_t ox = ax * s + i, oy = ay * s + j;
+                        if (ox < nx && oy < ny) {
+                            const float4 v = *reinterpret_cast<const float4 *>(arr + (ox * ny + oy) * L + z);
+                            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                        }
+                    }
+                *reinterpret_cast<float4 *>(o + z) = make_float4(by_ss(sum.x), by_ss(sum.y), by_ss(sum.z), by_ss(sum.w));
+            }
+        } else {
 #pragma unroll 4
-        for (size_t z = (size_t)lane; z < L; z += kWave) {
-            float sum = 0.0f;
-            for (size_t i = 0; i < s; ++i)
-                for (size_t j = 0; j < s; ++j) {
-                    const size_t ox = ax * s + i, oy = ay * s + j;
-                    if (ox < nx && oy < ny) sum += arr[(ox * ny + oy) * L + z];
-                }
-            o[z] = sum / sf;
+            for (size_t z = (size_t)lane; z < L; z += kWave) {
+                float sum = 0.0f;
+                for (size_t i = 0; i < s; ++i)
+                    for (size_t j = 0; j < s; ++j) {
+                        const size_t ox = ax * s + i, oy = ay * s + j;
+                        if (ox < nx && oy < ny) sum += arr[(ox * ny + oy) * L + z];
+                    }
+                o[z] = by_ss(sum);
+            }
         }
     }
 }
@@ -2104,7 +2122,9 @@ void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size
                     float *out)
 {
     const size_t pixels = (nx / s) * (ny / s);
-    THZ_LAUNCH(k_scale3d, grid_1d(pixels * kWave, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+    const bool vec = L % 4 == 0 && ((uintptr_t)arr | (uintptr_t)out) % 16 == 0;
+    if (vec) THZ_LAUNCH(k_scale3d<true>, grid_1d(pixels * kWave, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
+    else THZ_LAUNCH(k_scale3d<false>, grid_1d(pixels * kWave, 256, kNumCU * 8), 256, 0, st, arr, nx, ny, L, s, out);
 }
 
 void launch_tilt(hipStream_t st, size_t npix, int nt_in, int nt_out, const float *in,
