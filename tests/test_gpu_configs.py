@@ -224,5 +224,10 @@ def test_config5_synthetic_cube_with_reference_wiener_filter(engine, shape):
         avg = sess.download(pkg.BUF_AVG_FFT)
         want = fft.astype(np.float64).mean(0)
         assert np.abs(avg - want).max() / np.abs(want).max() < 1e-5
+        # ... and the amplitude / phase means, summed inside the same launch (k_f<pipe, complex multiplier, sums>)
+        want_a = amp.astype(np.float64).mean(0)
+        assert np.abs(sess.download(pkg.BUF_AVG_AMPLITUDES) - want_a).max() / want_a.max() < 2e-6
+        want_p = sess.download(pkg.BUF_PHASES).reshape(npix, nf).astype(np.float64).mean(0)
+        assert np.abs(sess.download(pkg.BUF_AVG_PHASES) - want_p).max() / np.abs(want_p).max() < 2e-6
     finally:
         sess.close()
