@@ -139,6 +139,11 @@ int main(int argc, char **argv)
         auto x = noise(npix * nt, 11), wv = noise((size_t)nt, 12);
         std::vector<float> o(npix * nt);
         emu_td_window(npix, nt, x.data(), wv.data(), o.data());
+        {   // nt = 256 CH: the window chunks of a lane live in registers
+            auto x2 = noise(npix * 1024, 31), w2 = noise((size_t)1024, 32);
+            std::vector<float> o2(npix * 1024);
+            emu_td_window(npix, 1024, x2.data(), w2.data(), o2.data());
+        }
         auto a = noise((size_t)300 * 130, 13);
         std::vector<float> s(130);
         emu_pixel_sum(300, 130, a.data(), s.data());
@@ -147,6 +152,11 @@ int main(int argc, char **argv)
         auto c = noise((size_t)5 * 7 * 66, 14);
         std::vector<float> sc((size_t)2 * 3 * 66);
         emu_scale3d(c.data(), 5, 7, 66, 2, sc.data());
+        {   // rows of whole 16-byte chunks: the vector path
+            auto c2 = noise((size_t)5 * 7 * 132, 34);
+            std::vector<float> sc2((size_t)2 * 3 * 132);
+            emu_scale3d(c2.data(), 5, 7, 132, 2, sc2.data());
+        }
         std::vector<int> ins = {0, 3, 10, 39, 40, 1, 2, 7, 20};
         std::vector<float> to(npix * 373);
         emu_tilt(npix, nt, 373, x.data(), wv.data(), ins.data(), to.data());
