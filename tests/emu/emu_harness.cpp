@@ -147,8 +147,10 @@ int emu_voxel_instances(size_t npix, int nt, size_t gh, const float *opacity, co
 // One Richardson-Lucy iteration (both steps) of ONE band on padded images d, u (H x W, H = h + 2 (pr/2),
 // W = w + 2 (pc/2)), through the untiled kernel (tiled = 0) or the LDS-tiled one: t_out = d / (u (*) psf + eps),
 // u_out = u * (t (*) mirror).  Workspace laid out as thz_deconvolve does it.
-extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d,
-                                const float *u, int tiled, float *t_out, float *u_out)
+// tiled = 2: psf is the outer product fx (pr) x fy (pc) and the step runs as two 1-D passes (k_rl_step_sep)
+extern "C" int emu_rl_iteration_sep(int h, int w, int pr, int pc, int mode, const float *psf, const float *fx,
+                                    const float *fy, const float *d, const float *u, int tiled, float *t_out,
+                                    float *u_out)
 {
     RlBand B{};
     B.h = h; B.w = w; B.pr = pr; B.pc = pc; B.pad_y = pr / 2; B.pad_x = pc / 2;
@@ -157,7 +159,14 @@ extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const fl
     const size_t img = (size_t)B.H * B.W, taps = (size_t)pr * pc;
     B.off_d = 0; B.off_u = (unsigned)img; B.off_t = (unsigned)(2 * img);
     B.off_psf = (unsigned)(3 * img); B.off_mirror = (unsigned)(3 * img + taps);
-    std::vector<float> ws(3 * img + 2 * taps + 32, 0.0f);
+    B.off_zero = (unsigned)(3 * img + 2 * taps);  // the 32 zeros behind the taps
+    std::vector<float> ws(3 * img + 2 * taps + 32 + (size_t)pr + (size_t)pc, 0.0f);
+    if (fx && fy) {
+        B.off_fx = (unsigned)(3 * img + 2 * taps + 32);
+        B.off_fy = B.off_fx + (unsigned)pr;
+        std::memcpy(ws.data() + B.off_fx, fx, (size_t)pr * sizeof(float));
+        std::memcpy(ws.data() + B.off_fy, fy, (size_t)pc * sizeof(float));
+    } else if (tiled == 2) return -2;
     std::memcpy(ws.data() + B.off_d, d, img * sizeof(float));
     std::memcpy(ws.data() + B.off_u, u, img * sizeof(float));
     for (size_t i = 0; i < taps; ++i) {
@@ -169,12 +178,19 @@ extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const fl
     const unsigned tiles_n = rl_tile_block_count(pr, pc, (unsigned)B.n_tiles);  // blocks of the tiled grid
     std::vector<RlTileRef> tiles(tiles_n, RlTileRef{B});
     for (int step = 0; step < 2; ++step) {
-        if (tiled) launch_rl_step_tiled(nullptr, mode != 0, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());
+        if (tiled == 2) launch_rl_step_tiled(nullptr, kRlSeparable, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc, true), nullptr, 0, step, ws.data());
+        else if (tiled) launch_rl_step_tiled(nullptr, mode != 0 ? kRlWide : kRlNarrow, tiles.data(), tiles_n, rl_tile_lds_bytes(pr, pc), nullptr, 0, step, ws.data());
         else launch_rl_step(nullptr, &B, 1, blocks, nullptr, 0, step, ws.data());
     }
     std::memcpy(t_out, ws.data() + B.off_t, img * sizeof(float));
     std::memcpy(u_out, ws.data() + B.off_u, img * sizeof(float));
     return 0;
+}
+
+extern "C" int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d,
+                                const float *u, int tiled, float *t_out, float *u_out)
+{
+    return emu_rl_iteration_sep(h, w, pr, pc, mode, psf, nullptr, nullptr, d, u, tiled, t_out, u_out);
 }
 
 // The deconvolution's transform kernels on the padded length M (a power of two): forward transform of the

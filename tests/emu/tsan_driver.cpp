@@ -21,6 +21,8 @@ void emu_allow_f(int on);
 void emu_set_grid_cap(int blocks);
 int emu_rl_iteration(int h, int w, int pr, int pc, int mode, const float *psf, const float *d, const float *u,
                      int tiled, float *t_out, float *u_out);
+int emu_rl_iteration_sep(int h, int w, int pr, int pc, int mode, const float *psf, const float *fx, const float *fy,
+                         const float *d, const float *u, int tiled, float *t_out, float *u_out);
 int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, const float *in, const float *H,
                  const float *gain, int use_f, float *energy, float *out, float *img);
 int emu_td_window(size_t npix, int nt, const float *in, const float *win, float *out);
@@ -112,6 +114,16 @@ int main(int argc, char **argv)
             auto psf = noise((size_t)pr * pc, 27, 0.0f, 1.0f);
             std::vector<float> t((size_t)H * W), un((size_t)H * W);
             emu_rl_iteration(h, w, pr, pc, 0, psf.data(), d.data(), u.data(), 1, t.data(), un.data());
+        }
+        {   // a wide kernel given as an outer product: the two 1-D passes, halo rows not a multiple of 16
+            const int h = 12, w = 22, pr = 19, pc = 21;
+            const int H = h + 2 * (pr / 2), W = w + 2 * (pc / 2);
+            auto d = noise((size_t)H * W, 35, 0.5f, 1.5f), u = noise((size_t)H * W, 36, 0.5f, 1.5f);
+            auto fx = noise((size_t)pr, 37, 0.0f, 1.0f), fy = noise((size_t)pc, 38, 0.0f, 1.0f);
+            std::vector<float> psf((size_t)pr * pc), t((size_t)H * W), un((size_t)H * W);
+            for (int m = 0; m < pr; ++m)
+                for (int n = 0; n < pc; ++n) psf[(size_t)m * pc + n] = fx[(size_t)m] * fy[(size_t)n];
+            emu_rl_iteration_sep(h, w, pr, pc, 1, psf.data(), fx.data(), fy.data(), d.data(), u.data(), 2, t.data(), un.data());
         }
         std::printf("rl done\n");
     }

@@ -292,6 +292,49 @@ def test_rl_step_kernels(emu, case):
         assert np.abs(res[1][1] - ru).max() / np.abs(ru).max() < 1e-5
 
 
+@pytest.mark.parametrize("case", [dict(h=11, w=13, pr=19, pc=21), dict(h=20, w=37, pr=47, pc=57),
+                                  dict(h=9, w=40, pr=17, pc=33), dict(h=40, w=9, pr=53, pc=5)])
+def test_rl_step_separable_kernel(emu, case):
+    """k_rl_step_sep: a wide kernel that is an outer product fx x fy (every band PSF of the reference is one)
+    as a pass along the rows and a pass down the columns — against the reference's loops over the 2-D array and
+    against the 2-D tiled kernel, within rounding; tiles at the ragged edges, halo rows not a multiple of 16,
+    a profile that fills its last chunk exactly (pc = 33 -> 48 staged taps) and one shorter than a chunk"""
+    h, w, pr, pc = (case[k] for k in ("h", "w", "pr", "pc"))
+    assert pr * pc > 256
+    rng = np.random.default_rng(pr * 1000 + pc)
+    H, W = h + 2 * (pr // 2), w + 2 * (pc // 2)
+    d = (0.5 + rng.random((H, W))).astype(np.float32)
+    u = (0.5 + rng.random((H, W))).astype(np.float32)
+    x, y = np.arange(pr) - pr // 2, np.arange(pc) - pc // 2
+    fx = np.exp(-(x - 0.7) ** 2 / (2 * (pr / 5) ** 2)).astype(np.float32)   # off-centre: the mirror differs
+    fy = np.exp(-(y + 1.3) ** 2 / (2 * (pc / 6) ** 2)).astype(np.float32)
+    psf = np.outer(fx, fy).astype(np.float32)
+    res = {}
+    for tiled in (0, 1, 2):
+        t, un = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+        assert emu.emu_rl_iteration_sep(h, w, pr, pc, 1, _p(psf), _p(fx), _p(fy), _p(d), _p(u), tiled, _p(t), _p(un)) == 0
+        res[tiled] = (t, un)
+    a64 = lambda a, k: _conv_same_f64(a, k)
+    t64 = d / (a64(u, psf) + 1e-12)
+    u64 = u * a64(t64, psf[::-1, ::-1])
+    for tiled in (0, 1, 2):
+        et = np.abs(res[tiled][0] - t64).max() / np.abs(t64).max()
+        eu = np.abs(res[tiled][1] - u64).max() / np.abs(u64).max()
+        assert et < 2e-6 and eu < 4e-6, (tiled, et, eu)
+    # the two passes round no worse than the 2-D sums do
+    e2 = np.abs(res[1][1] - u64).max()
+    es = np.abs(res[2][1] - u64).max()
+    assert es <= 2 * e2 + 1e-7 * np.abs(u64).max()
+
+
+def _conv_same_f64(a, k):
+    """'same' linear convolution in float64: rows / columns [(b-1)/2, (b-1)/2 + a) of the full one"""
+    from scipy.signal import convolve2d
+    full = convolve2d(a.astype(np.float64), k.astype(np.float64), mode="full")
+    sr, sc = (k.shape[0] - 1) // 2, (k.shape[1] - 1) // 2
+    return full[sr:sr + a.shape[0], sc:sc + a.shape[1]]
+
+
 @pytest.mark.parametrize("M,nt", [(1024, 300), (2048, 1001), (4096, 2000)])
 def test_deconvolution_transform_kernels(emu, M, nt):
     """k_dc_fft -> k_dc_energy(_f) -> k_dc_combine(_f): band energies of FIR-filtered traces over the 'same'

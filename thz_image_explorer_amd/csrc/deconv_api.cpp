@@ -224,6 +224,9 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     size_t tile_lds = 0;
     int max_iter = 0;
     std::vector<BandPsf> psfs((size_t)nbs);
+    // the band PSFs are outer products of two profiles: their wide kernels run as two 1-D passes (k_rl_step_sep);
+    // THZ_RL_NO_SEPARABLE (developer knob, for A/B timing) keeps the 2-D sums of k_rl_step_tiled<true>
+    const bool separable = getenv("THZ_RL_NO_SEPARABLE") == nullptr;
     for (int b = 0; b < nbs; ++b) {
         psfs[(size_t)b] = band_psf(*psf, centers[(size_t)b], dx, dy, (int)nx, (int)ny);
         const BandPsf &bp = psfs[(size_t)b];
@@ -241,7 +244,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
         B.tiles_w = (B.W + 15) / 16;
         B.n_tiles = B.tiles_w * ((B.H + 15) / 16);
-        tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc));
+        tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc, separable && B.mode != 0));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;
         B.off_u = (unsigned)ws_floats; ws_floats += img;
@@ -258,7 +261,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // blocks for 512 places), the chains' launches take turns, and more chains only add launches.
     constexpr int kRlChains = 4;
     struct TileList {
-        bool wide = false;
+        int kind = kRlNarrow;
         std::vector<int> order;                           // bands of this chain, by falling n_iter
         std::vector<std::pair<int, unsigned>> live_steps;  // (n_iter of a band, blocks up to and including it)
         unsigned blocks = 0, first = 0;                   // blocks of the list / where it starts in d_tiles
@@ -285,7 +288,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             end = std::min(end, wide_bands.size());
             if (end <= at) continue;
             TileList L;
-            L.wide = true;
+            L.kind = separable ? kRlSeparable : kRlWide;
             L.order.assign(wide_bands.begin() + (long)at, wide_bands.begin() + (long)end);
             lists.push_back(L);
             at = end;
@@ -304,7 +307,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             B.tblk0 = L.blocks;
             L.blocks += rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
             L.live_steps.emplace_back(B.n_iter, L.blocks);
-            L.lds = std::max(L.lds, rl_tile_lds_bytes(B.pr, B.pc));
+            L.lds = std::max(L.lds, rl_tile_lds_bytes(B.pr, B.pc, L.kind == kRlSeparable));
         }
         tblk += L.blocks;
     }
@@ -315,12 +318,17 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         psf_pack.insert(psf_pack.end(), bp.v.begin(), bp.v.end());
         B.off_mirror = (unsigned)(ws_floats + psf_pack.size());
         for (size_t i = bp.v.size(); i-- > 0;) psf_pack.push_back(bp.v[i]);  // psf[::-1, ::-1]
+        B.off_fx = (unsigned)(ws_floats + psf_pack.size());
+        psf_pack.insert(psf_pack.end(), bp.fx.begin(), bp.fx.end());
+        B.off_fy = (unsigned)(ws_floats + psf_pack.size());
+        psf_pack.insert(psf_pack.end(), bp.fy.begin(), bp.fy.end());
     }
     if (getenv("THZ_DEBUG_BANDS"))  // developer knob: the band table on stderr
         for (int b = 0; b < nbs; ++b)
             fprintf(stderr, "band %2d  f=%.3f THz  psf %3d x %3d  n_iter %4d  tiles %u\n", b, centers[(size_t)b],
                     bands[(size_t)b].pr, bands[(size_t)b].pc, bands[(size_t)b].n_iter,
                     rl_tile_block_count(bands[(size_t)b].pr, bands[(size_t)b].pc, (unsigned)bands[(size_t)b].n_tiles));
+    for (RlBand &B : bands) B.off_zero = (unsigned)(ws_floats + psf_pack.size());  // the first of the zeros below
     psf_pack.insert(psf_pack.end(), 32, 0.0f);  // the tiled step reads taps a whole chunk at a time
     HIP_TRY(ctx, mem.alloc(&d_ws, (ws_floats + psf_pack.size()) * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_ws + ws_floats, psf_pack.data(), psf_pack.size() * sizeof(float),
@@ -358,10 +366,10 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // image tile + halo + taps fit in LDS (THZ_NO_TILE: developer knob, forces the fallback for tests)
     const bool tiled = tile_lds <= (size_t)150 * 1024 && !getenv("THZ_NO_TILE");
     if (tiled) {
-        size_t lds_kind[2] = {0, 0};
-        for (const TileList &L : lists) lds_kind[L.wide ? 1 : 0] = std::max(lds_kind[L.wide ? 1 : 0], L.lds);
-        for (int k = 0; k < 2; ++k)
-            if (lds_kind[k]) prepare_rl_step_tiled(k == 1, lds_kind[k]);
+        size_t lds_kind[3] = {0, 0, 0};
+        for (const TileList &L : lists) lds_kind[L.kind] = std::max(lds_kind[L.kind], L.lds);
+        for (int k = 0; k < 3; ++k)
+            if (lds_kind[k]) prepare_rl_step_tiled(k, lds_kind[k]);
     }
     const bool use_graph = !getenv("THZ_NO_GRAPH");      // developer knobs: plain launches / the whole grid
     const bool compact = !getenv("THZ_RL_FULL_GRID");    // every time (serial path), for A/B timing
@@ -407,7 +415,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         const TileList &L = lists[c];
         for (int o = o0; o < o1; ++o)
             for (int step = 0; step < 2; ++step)
-                launch_rl_step_tiled(st, L.wide, d_tiles + L.first, grid, L.lds, it_base, o, step, d_ws);
+                launch_rl_step_tiled(st, L.kind, d_tiles + L.first, grid, L.lds, it_base, o, step, d_ws);
     };
     auto graph_of = [&](size_t c) -> hipGraphExec_t {
         if (cg.tried[c]) return cg.exec[c];
@@ -495,7 +503,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         if (timing) {
             for (size_t c = 0; c < lists.size(); ++c) {
                 fprintf(stderr, "thz_deconvolve: chain %zu (%s, %u blocks, %zu bands) batches end at [ms]:", c,
-                        lists[c].wide ? "wide" : "narrow", lists[c].blocks, lists[c].order.size());
+                        lists[c].kind == kRlSeparable ? "separable" : lists[c].kind == kRlWide ? "wide" : "narrow", lists[c].blocks, lists[c].order.size());
                 for (hipEvent_t e : marks[c]) {
                     float ms = 0.0f;
                     (void)hipEventElapsedTime(&ms, t_start, e);

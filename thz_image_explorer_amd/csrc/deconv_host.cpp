@@ -239,10 +239,10 @@ BandPsf band_psf(const thz_psf &P, float center_freq, float dx, float dy, int im
     out.rows = (int)(2 * x_max + 1);
     out.cols = (int)(2 * y_max + 1);
     out.v.resize((size_t)out.rows * out.cols);
-    for (long i = -x_max; i <= x_max; ++i)
-        for (long j = -y_max; j <= y_max; ++j)
-            out.v[(size_t)(i + x_max) * out.cols + (size_t)(j + y_max)] =
-                interp_lin(x, gx, (float)i * dx) * interp_lin(y, gy, (float)j * dy);
+    for (long i = -x_max; i <= x_max; ++i) out.fx.push_back(interp_lin(x, gx, (float)i * dx));
+    for (long j = -y_max; j <= y_max; ++j) out.fy.push_back(interp_lin(y, gy, (float)j * dy));
+    for (int i = 0; i < out.rows; ++i)
+        for (int j = 0; j < out.cols; ++j) out.v[(size_t)i * out.cols + (size_t)j] = out.fx[(size_t)i] * out.fy[(size_t)j];
     return out;
 }
 

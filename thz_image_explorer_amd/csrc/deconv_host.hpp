@@ -21,7 +21,8 @@ void filter_bank(int n_filters, double start_freq, double end_freq, double win_w
 struct BandPsf {
     int rows = 0, cols = 0;   // (x, y) extents, odd
     float wx = 0.0f;
-    std::vector<float> v;     // rows*cols, row-major [x][y]
+    std::vector<float> v;     // rows*cols, row-major [x][y]: v[i][j] = fx[i] * fy[j]
+    std::vector<float> fx, fy;  // the two profiles the array is the outer product of (rows / cols floats)
 };
 // per-band PSF, deconvolution.rs:906-960 + psf.rs:228-313
 BandPsf band_psf(const thz_psf &P, float center_freq, float dx, float dy, int img_rows, int img_cols);

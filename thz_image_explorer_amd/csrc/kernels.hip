@@ -1284,6 +1284,23 @@ __host__ __device__ inline unsigned rl_tile_blocks(bool turned, unsigned n_tiles
     return turned ? n_tiles : (n_tiles + kRlTilesPerBlock - 1) / kRlTilesPerBlock;
 }
 
+// A block's band record and the batch's first iteration number, requested together as three scalar loads and
+// waited for once (want_scalars_now): two round trips at the head of the kernel — the arguments, then everything
+// else — where the compiler's field-by-field loads made six.
+__device__ __forceinline__ RlBand rl_block_band(const RlTileRef *__restrict__ tiles, const int *__restrict__ it_base, int &iteration)
+{
+    const int *rec = reinterpret_cast<const int *>(tiles + blockIdx.x);
+    const thz_i16 lo = *reinterpret_cast<const thz_i16 *>(rec);
+    const thz_i8 hi = *reinterpret_cast<const thz_i8 *>(rec + 16);
+    const int base = *(it_base ? it_base : rec);  // a load either way: no branch in front of the others
+    want_scalars_now(lo, hi, base);
+    struct { thz_i16 lo; thz_i8 hi; } both{lo, hi};
+    RlBand B;
+    __builtin_memcpy(&B, &both, sizeof(B));
+    if (it_base) iteration += base;
+    return B;
+}
+
 // The grid of a launch is a list of tiles of ONE kind (WIDE: kernels of more than 256 taps), the bands in it by
 // falling iteration count, so that the tiles still iterating are a prefix of the list.  Two kernels rather than
 // one with a branch: the wide path fits 64 VGPRs, which lets two 1024-thread blocks share a CU — one block's
@@ -1295,15 +1312,15 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
                                                                             int step, float *__restrict__ ws)
 {
     THZ_DYN_LDS(smem);
-    if (it_base) iteration += *it_base;
     // the tile's band record, by value in the per-tile table: the tiles of finished bands leave after a single
     // memory latency
-    const RlBand B = tiles[blockIdx.x].band;
+    const RlBand B = rl_block_band(tiles, it_base, iteration);
     if (iteration >= B.n_iter) return;  // block-uniform
     const int pr = B.pr, pc = B.pc;
     const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;  // halo tile
     const int nch = rl_chunks(pc);
-    const float *a = ws + (step == 0 ? B.off_u : B.off_t);
+    const unsigned a_off = step == 0 ? B.off_u : B.off_t;
+    const float *a = ws + a_off;
     const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
     if constexpr (!WIDE) {
         // ---- narrow kernel: four tiles, one per 256-thread group; the taps are staged once for all four
@@ -1316,35 +1333,59 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
         float *k_s = reinterpret_cast<float *>(smem) + kRlTilesPerBlock * tile_fl;
         // first image row / column of the halo: x = i + m - pr/2
         const int r0 = ti0 - pr / 2, c0 = tj0 - pc / 2;
-        if (live) {  // zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was
-            const int wv = px >> 6, ln = px & 63;
-#pragma unroll 4
-            for (int r = wv; r < hs; r += 4) {
-                const int x = r0 + r;
-                const bool xin = x >= 0 && x < B.H;
-                for (int c = ln; c < wsz; c += kWave) {
-                    const int y = c0 + c;
-                    a_s[r * wsz + c] = (xin && y >= 0 && y < B.W) ? a[(size_t)x * B.W + y] : 0.0f;
-                }
-            }
-        }
-        {   // the order rl_tile_taps consumes them in
-            const int n_el = pr * nch * kRlChunk;
-            for (int e = (int)threadIdx.x; e < n_el; e += kRlThreads) {
-                const int t = e / kRlChunk, q = e % kRlChunk;
-                const int m = t / nch, c = t - m * nch;
-                const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
-                k_s[e] = src >= 0 ? k[src] : 0.0f;
-            }
-        }
-        __syncthreads();
         const int ti = px / kRlTile, tj = px % kRlTile;
         const int i = ti0 + ti, j = tj0 + tj;
-        if (!live || i >= B.H || j >= B.W) return;  // no barrier below on this path
-        const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);
+        const bool writer = live && i < B.H && j < B.W;
         const int idx = i * B.W + j;
-        if (step == 0) ws[B.off_t + idx] = ws[B.off_d + idx] / (sum + 1e-12f);
-        else ws[B.off_u + idx] = ws[B.off_u + idx] * sum;
+        // Everything is requested from memory before anything is waited for (the inputs were written by other CUs
+        // one launch ago: every dependent load is two microseconds of a launch that computes for three): a tap in
+        // the order rl_tile_taps consumes them, the update's other operand, then the halo, eight rows per wave at a time.
+        const int n_el = pr * nch * kRlChunk;
+        const unsigned k_off = step == 0 ? B.off_psf : B.off_mirror;
+        auto tap_at = [&](int e) {
+            const int t = e / kRlChunk, q = e % kRlChunk;
+            const int m = t / nch, c = t - m * nch;
+            const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
+            return ws[src >= 0 && e < n_el ? k_off + (unsigned)src : B.off_zero];
+        };
+        float other = 0.0f;
+        const float k_v = tap_at((int)threadIdx.x);
+        if (writer) other = ws[(step == 0 ? B.off_d : B.off_u) + idx];
+        if (live) {  // zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was
+            constexpr int kRows = 8;
+            const int wvu = THZ_UNIFORM(px >> 6), ln = px & 63;
+            auto stage = [&](int rb, int c) {
+                    float v[kRows];
+                    const int y = c0 + c;
+                    const bool yin = y >= 0 && y < B.W;
+#pragma unroll
+                    for (int q = 0; q < kRows; ++q) {
+                        // rows are wave-uniform (scalar tests); a position outside the image loads a stored zero, so
+                        // the loads are unconditional, issue back to back and leave no masks to keep
+                        const int r = rb + 4 * q, x = r0 + r;
+                        const bool row_ok = r < hs && x >= 0 && x < B.H;
+                        v[q] = ws[row_ok && yin ? a_off + (unsigned)(x * B.W) + (unsigned)y : B.off_zero];
+                    }
+#pragma unroll
+                    for (int q = 0; q < kRows; ++q) {
+                        const int r = rb + 4 * q;
+                        if (r < hs) a_s[r * wsz + c] = v[q];
+                    }
+            };
+            // the first batch (the whole halo for kernels of up to 17 x 49 taps) stands in front of the loops: at a
+            // loop head the compiler waits for every load in flight, the tap's and the operand's included
+            if (ln < wsz) stage(wvu, ln);
+            for (int c = ln + kWave; c < wsz; c += kWave) stage(wvu, c);
+            for (int rb = wvu + 4 * kRows; rb < hs; rb += 4 * kRows)
+                for (int c = ln; c < wsz; c += kWave) stage(rb, c);
+        }
+        if ((int)threadIdx.x < n_el) k_s[threadIdx.x] = k_v;
+        for (int e = (int)threadIdx.x + kRlThreads; e < n_el; e += kRlThreads) k_s[e] = tap_at(e);
+        __syncthreads();
+        if (!writer) return;  // no barrier below on this path
+        const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);
+        if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
+        else ws[B.off_u + idx] = other * sum;
         return;
     } else {
     // ---- wide kernel: one tile, stored turned by 180 degrees, the kernel's rows dealt to the 16 waves
@@ -1399,6 +1440,147 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
     if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
     else ws[B.off_u + idx] = other * sum;
     }
+}
+
+// ---- separable wide kernels ---------------------------------------------------------------------------------
+// Every band PSF of the reference is an outer product of two 1-D profiles (create_psf_2d, psf.rs:228-313:
+// psf[m][n] = fx[m] fy[n]), so the wide kernels' "same" convolution — in the reference an FFT convolution, whose
+// rounding is that of no summation order — factors into a pass along the rows and a pass down the columns:
+//     T[x][j]   = sum_n a[x][j + sc - n] fy[n]          (halo rows x, the tile's 16 columns)
+//     out[i][j] = sum_m T[i + sr - m][j] fx[m]
+// pr + pc multiply-adds per pixel and half-step instead of pr pc (104 against 2 679 for the 47 x 57 band), which
+// turns a tile from ALU/LDS-bound into what its halo costs to fetch.  One 16 x 16 tile per block of 256 threads
+// (25 KB of LDS for the largest band: six tiles share a CU), the halo stored as it lies in the image and the
+// profiles stored reversed, so both passes walk upwards: out[ti][tj] = sum_m' sum_n' a_s[ti + m'][tj + n']
+// fx[pr-1-m'] fy[pc-1-n'].  The mirrored PSF of the second half-step has the profiles the other way round.
+// Pass A reuses the wide kernel's window arithmetic (four pixels side by side per thread, packed FMAs): a
+// quarter wave reads 16 consecutive halo rows at one column group, conflict-free for an odd row stride in 16-byte
+// units.
+constexpr int kRlSepThreads = 256;
+constexpr int kRlSepRows = 16;  // halo rows a wave has in flight while staging
+
+__host__ __device__ inline int rl_sep_stride(int pc)
+{
+    // the last column group's window ends at column 12 + 16 chunks + 3; everything up to the stride is initialised
+    int w = kRlChunk * ((pc + kRlChunk - 1) / kRlChunk + 1);
+    if (w / 4 % 2 == 0) w += 4;
+    return w;
+}
+// LDS floats of a block: halo rows | fy (whole chunks) | fx | T
+__host__ __device__ inline size_t rl_sep_floats(int pr, int pc)
+{
+    const int hs = kRlTile + pr - 1;
+    return (size_t)hs * rl_sep_stride(pc) + (size_t)((pc + kRlChunk - 1) / kRlChunk) * kRlChunk + (size_t)(pr + 3) / 4 * 4
+           + (size_t)hs * kRlTile;
+}
+
+__global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *__restrict__ tiles,
+                                                               const int *__restrict__ it_base, int iteration, int step,
+                                                               float *__restrict__ ws)
+{
+    THZ_DYN_LDS(smem);
+    const RlBand B = rl_block_band(tiles, it_base, iteration);
+    if (iteration >= B.n_iter) return;  // block-uniform
+    const int pr = B.pr, pc = B.pc;
+    const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;
+    const int nch = rl_chunks(pc), wsp = rl_sep_stride(pc);
+    const unsigned a_off = step == 0 ? B.off_u : B.off_t;
+    const float *fx = ws + B.off_fx, *fy = ws + B.off_fy;
+    float *a_s = reinterpret_cast<float *>(smem);
+    float *fy_s = a_s + (size_t)hs * wsp;
+    float *fx_s = fy_s + nch * kRlChunk;
+    float *t_s = fx_s + (pr + 3) / 4 * 4;
+    const unsigned lt = blockIdx.x - B.tblk0;
+    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+    // first image row / column of the halo: x = i + (pr-1)/2 - m
+    const int r0 = ti0 + (pr - 1) / 2 - (pr - 1), c0 = tj0 + (pc - 1) / 2 - (pc - 1);
+    const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+    const int px = (int)threadIdx.x;
+    const int ti = px / kRlTile, tj = px % kRlTile;
+    const int i = ti0 + ti, j = tj0 + tj;
+    const bool writer = i < B.H && j < B.W;
+    const int idx = i * B.W + j;
+    // Everything the block reads from memory is requested before anything is waited for — one round trip, not four:
+    // the profiles (step 0 convolves with the PSF: reversed profiles in this upward walk; step 1 with its mirror
+    // image), the update's other operand, which does not depend on the sums, and then the halo.
+    float fy_v = 0.0f, fx_v = 0.0f, other = 0.0f;
+    if (px < pc) fy_v = fy[step == 0 ? pc - 1 - px : px];
+    if (px < pr) fx_v = fx[step == 0 ? pr - 1 - px : px];
+    if (writer) other = ws[(step == 0 ? B.off_d : B.off_u) + idx];
+    {   // a wave per halo row, lanes along the row; zeros outside the image and beyond the halo's last column.
+        // The tile's input was written by other CUs in the launch before, so every load is a trip to the far side
+        // of the L2s: kRlSepRows rows x 2 column passes of loads are issued before the first is waited for (with the
+        // plain loop the compiler kept four in flight, and the staging alone lasted eight round trips).
+        // Rows are wave-uniform (scalar tests), the column tests of a pass are made once; a position outside the image
+        // loads a stored zero, so the loads are unconditional, issue back to back and leave no masks to keep.
+        const int wvu = THZ_UNIFORM(wv);
+        auto stage = [&](int rb, int cb) {
+                float v[kRlSepRows][2];
+                bool cok[2];
+                unsigned yv[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int c = cb + p * kWave, y = c0 + c;
+                    cok[p] = c < wsz && y >= 0 && y < B.W;
+                    yv[p] = (unsigned)y;
+                }
+#pragma unroll
+                for (int k = 0; k < kRlSepRows; ++k) {
+                    const int r = rb + k * (kRlSepThreads / kWave), x = r0 + r;
+                    const bool row_ok = r < hs && x >= 0 && x < B.H;
+                    const unsigned row_at = a_off + (unsigned)(x * B.W);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) v[k][p] = ws[row_ok && cok[p] ? row_at + yv[p] : B.off_zero];
+                }
+#pragma unroll
+                for (int k = 0; k < kRlSepRows; ++k) {
+                    const int r = rb + k * (kRlSepThreads / kWave);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int c = cb + p * kWave;
+                        if (r < hs && c < wsp) a_s[r * wsp + c] = v[k][p];
+                    }
+                }
+        };
+        // the first batch — the whole halo for kernels of up to 49 x 113 taps — stands in front of the loops: at a
+        // loop head the compiler waits for every load in flight, which would put the profiles' round trip in
+        // front of the halo's
+        constexpr int kRowsPerBatch = kRlSepRows * (kRlSepThreads / kWave);
+        stage(wvu, ln);
+        for (int cb = ln + 2 * kWave; cb < wsp; cb += 2 * kWave) stage(wvu, cb);
+        for (int rb = wvu + kRowsPerBatch; rb < hs; rb += kRowsPerBatch)
+            for (int cb = ln; cb < wsp; cb += 2 * kWave) stage(rb, cb);
+        if (px < nch * kRlChunk) fy_s[px] = fy_v;
+        if (px < pr) fx_s[px] = fx_v;
+        for (int n = px + kRlSepThreads; n < nch * kRlChunk; n += kRlSepThreads)  // profiles of more than 256 taps
+            fy_s[n] = n < pc ? fy[step == 0 ? pc - 1 - n : n] : 0.0f;
+        for (int m = px + kRlSepThreads; m < pr; m += kRlSepThreads) fx_s[m] = fx[step == 0 ? pr - 1 - m : m];
+    }
+    __syncthreads();
+    // pass A: (halo row, column group of four) per thread
+    for (int task = px; task < (hs + 15) / 16 * 64; task += kRlSepThreads) {
+        const int r = task / 64 * 16 + (task & 15), q = (task >> 4) & 3;
+        if (r >= hs) continue;
+        float acc[kRlPix];
+        rl_tile_taps_split(a_s + r * wsp + 4 * q, wsp, fy_s, pc, 0, 1, acc);  // acc[p] = sum_n w[3 - p + n] fy_s[n]
+        *reinterpret_cast<float4 *>(t_s + r * kRlTile + 4 * q) = float4{acc[3], acc[2], acc[1], acc[0]};
+    }
+    __syncthreads();
+    if (!writer) return;
+    // pass B: a pixel per thread, four partial sums
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    const float *col = t_s + ti * kRlTile + tj;
+    int m = 0;
+    for (; m + 4 <= pr; m += 4) {
+        s0 = fmaf(col[(m + 0) * kRlTile], fx_s[m + 0], s0);
+        s1 = fmaf(col[(m + 1) * kRlTile], fx_s[m + 1], s1);
+        s2 = fmaf(col[(m + 2) * kRlTile], fx_s[m + 2], s2);
+        s3 = fmaf(col[(m + 3) * kRlTile], fx_s[m + 3], s3);
+    }
+    for (; m < pr; ++m) s0 = fmaf(col[m * kRlTile], fx_s[m], s0);
+    const float sum = (s0 + s1) + (s2 + s3);
+    if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
+    else ws[B.off_u + idx] = other * sum;
 }
 
 __global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restrict__ filters, int n_bands,
@@ -2356,26 +2538,29 @@ void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
     THZ_LAUNCH(k_rl_step, total_blocks, 256, 0, st, d_bands, n_bands, it_base, iteration, step, ws);
 }
 
-size_t rl_tile_lds_bytes(int pr, int pc)
+size_t rl_tile_lds_bytes(int pr, int pc, bool separable)
 {
     const bool turned = rl_turned(pr, pc);
+    if (separable) return rl_sep_floats(pr, pc) * sizeof(float);
     if (!turned) return (kRlTilesPerBlock * rl_tile_floats(pr, pc, false) + rl_tap_floats(pr, pc)) * sizeof(float);
     return (rl_tile_floats(pr, pc, true) + rl_tap_floats(pr, pc) + (size_t)kRlSplit * 256) * sizeof(float);
 }
 
 unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles) { return rl_tile_blocks(rl_turned(pr, pc), n_tiles); }
 
-void prepare_rl_step_tiled(bool wide, size_t lds_bytes)
+void prepare_rl_step_tiled(int kind, size_t lds_bytes)
 {
-    if (wide) allow_dynamic_lds(k_rl_step_tiled<true>, lds_bytes);
+    if (kind == kRlSeparable) allow_dynamic_lds(k_rl_step_sep, lds_bytes);
+    else if (kind == kRlWide) allow_dynamic_lds(k_rl_step_tiled<true>, lds_bytes);
     else allow_dynamic_lds(k_rl_step_tiled<false>, lds_bytes);
 }
 
-void launch_rl_step_tiled(hipStream_t st, bool wide, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
+void launch_rl_step_tiled(hipStream_t st, int kind, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
                           const int *it_base, int iteration, int step, float *ws)
 {
     if (total_tiles == 0) return;
-    if (wide) THZ_LAUNCH(k_rl_step_tiled<true>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    if (kind == kRlSeparable) THZ_LAUNCH(k_rl_step_sep, total_tiles, kRlSepThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    else if (kind == kRlWide) THZ_LAUNCH(k_rl_step_tiled<true>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
     else THZ_LAUNCH(k_rl_step_tiled<false>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
 }
 

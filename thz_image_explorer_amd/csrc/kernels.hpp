@@ -54,7 +54,12 @@ struct RlBand {
     int tiles_w;        // tiles per row of the padded image
     int n_tiles;        // tiles of the padded image (a block holds one, or four for kernels of <= 256 taps)
     unsigned off_d, off_u, off_t, off_psf, off_mirror;
+    // a wide kernel that is an outer product psf[m][n] = fx[m] fy[n] (every band PSF of the reference is one,
+    // psf.rs:228-313): the two profiles, pr and pc floats — 0 / 0 when the kernel is only known as a 2-D array
+    unsigned off_fx, off_fy;
+    unsigned off_zero;  // a float that is 0.0f: what a halo position outside the image loads (no select, no mask to keep)
 };
+enum : int { kRlNarrow = 0, kRlWide = 1, kRlSeparable = 2 };  // kinds of tile lists (one kernel each)
 
 void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands, int n_taps, const double *cs,
                               const double *sn, unsigned M, unsigned nk, c32 *H);
@@ -69,15 +74,17 @@ void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned
 void launch_rl_step(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
                     const int *it_base, int iteration, int step, float *ws);
 // LDS-tiled form of the same step: total_tiles blocks, lds_bytes = rl_tile_lds_bytes of the largest band
-size_t rl_tile_lds_bytes(int pr, int pc);
+size_t rl_tile_lds_bytes(int pr, int pc, bool separable = false);
 unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles);  // blocks of the tiled grid a band's tiles take
-void prepare_rl_step_tiled(bool wide, size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
+void prepare_rl_step_tiled(int kind, size_t lds_bytes);  // raises the kernel's dynamic-LDS limit (not capturable)
 // per tile of the tiled grid: its band's record by value — a block needs one (scalar) load to know
 // whether its band still iterates and everything else about it, not a chain of two
-struct RlTileRef {
+struct alignas(16) RlTileRef {
     RlBand band;
+    int pad[24 - sizeof(RlBand) / sizeof(int)];  // 96 bytes: the kernels fetch a record as sixteen + eight dwords
 };
-void launch_rl_step_tiled(hipStream_t st, bool wide, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
+static_assert(sizeof(RlBand) == 22 * sizeof(int) && sizeof(RlTileRef) == 96, "rl_block_band reads the record as 24 dwords");
+void launch_rl_step_tiled(hipStream_t st, int kind, const RlTileRef *d_tiles, unsigned total_tiles, size_t lds_bytes,
                           const int *it_base, int iteration, int step, float *ws);
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,
                     const float *energy, const float *ws, float *gain);

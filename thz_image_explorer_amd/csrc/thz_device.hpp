@@ -59,6 +59,12 @@ __device__ __forceinline__ void lds_flag_store(unsigned *p, unsigned v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+// Block-uniform values the compiler must have in scalar registers HERE, all of them at once.  Used on a per-block
+// record in front of the block's first branch: left alone, the compiler loads such a record piece by piece, each
+// piece behind the branch that first needs it — five dependent scalar round trips at the head of a 10 us kernel.
+typedef int thz_i8 __attribute__((ext_vector_type(8)));
+typedef int thz_i16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void want_scalars_now(thz_i16 a, thz_i8 b, int c) { asm volatile("" ::"s"(a), "s"(b), "s"(c)); }
 
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ float wave_shfl_up(float v, int d) { return __shfl_up(v, d, kWave); }
