@@ -129,6 +129,20 @@ inline float wave_shfl(float v, int src)
     wave_sync();
     return r;
 }
+inline void row_bcast16(float v, float (&out)[16])
+{
+    float *s = thz_emu::g_sync->slots.data() + (threadIdx.x / 64) * 64;
+    s[threadIdx.x & 63] = v;
+    wave_sync();
+    for (int q = 0; q < 16; ++q) out[q] = s[(threadIdx.x & 48) + q];
+    wave_sync();
+}
+inline void row_mul16(const float (&a)[16], float k, float (&prod)[16])
+{
+    float kv[16];
+    row_bcast16(k, kv);
+    for (int q = 0; q < 16; ++q) prod[q] = a[q] * kv[q];
+}
 inline float wave_shfl_up(float v, int d)
 {
     int l = lane_id();

@@ -1123,9 +1123,10 @@ constexpr int kRlTile = 16;
 // operands are requested before chunk t's arithmetic starts; LDS returns in order, so the wait in
 // front of a chunk leaves the next chunk's reads in flight.  Every fetch is a full chunk: a row's
 // last chunk is the row's LAST kRlChunk taps (it overlaps the chunk before it, or starts in front
-// of the row when the row is shorter than a chunk) and its first `skip` products are left out of
-// the sum.  The image-side surplus is read from the neighbouring row of the tile or from the slack
-// the tile carries on either side, and is never used.
+// of the row when the row is shorter than a chunk) and the positions in front of the row's own taps
+// are staged as ZERO taps: sum + a * 0 is sum, bit for bit.  The image-side surplus is read from the
+// neighbouring row of the tile or from the slack the tile carries on either side (zeroed: 0 * stale
+// LDS could be a NaN).
 constexpr int kRlChunk = 16;
 
 // chunks per row / first tap of chunk c of a row
@@ -1135,45 +1136,41 @@ __device__ __forceinline__ int rl_chunk_n0(int c, int nch, int pc) { return c + 
 __device__ __forceinline__ float rl_tile_taps(const float *origin, int wsz, const float *k_s, int pr, int pc)
 {
 #pragma clang fp contract(off)
+    // A chunk's 16 taps are held one per lane (lane l of every row of 16 lanes has tap l) and reach the products
+    // through DPP row broadcasts inside the multiplies (row_mul16): one 4-byte LDS read per lane and chunk instead of
+    // sixteen dwords broadcast to every lane — the tap loop was bound by the LDS port (72 clocks per tap with 16
+    // waves on a CU), half of it these broadcasts.  Every lane of the wave must call this (the edge tiles' lanes
+    // outside the image included: they hold taps for their row).
     const int nch = rl_chunks(pc);
-    const int last_skip = nch * kRlChunk - pc;  // taps of a row's last chunk that belong to the chunk before
     const int total = pr * nch;
+    const int lane16 = (int)(threadIdx.x & 15);
     int f_a = 0, f_c = 0, f_m = 0, f_t = 0;  // fetch position: row start in the tile, chunk of the row, row, chunk of the sequence
-    auto fetch = [&](float (&av)[kRlChunk], float (&kv)[kRlChunk]) {
+    auto fetch = [&](float (&av)[kRlChunk], float &kl) {
         const float *row = origin + (f_a + rl_chunk_n0(f_c, nch, pc));
-        const float *kr = k_s + f_t * kRlChunk;
+        kl = k_s[f_t * kRlChunk + lane16];  // first: LDS returns in order, and the tap is what a chunk's first multiply waits for
 #pragma unroll
         for (int q = 0; q < kRlChunk; ++q) av[q] = row[q];
-#pragma unroll
-        for (int q = 0; q < kRlChunk; ++q) kv[q] = kr[q];
         ++f_t;
         ++f_c;
         if (f_c == nch) {
             f_c = 0;
-            if (f_m + 1 < pr) {  // the fetches after the last chunk repeat the last row (never used)
+            if (f_m + 1 < pr) {  // the fetches after the last chunk repeat the last row (their taps are zeros)
                 ++f_m;
                 f_a += wsz;
             }
         }
     };
     float sum = 0.0f;
-    int s_c = 0, s_t = 0;  // chunk of its row / of the sequence the next accumulate handles
-    auto accumulate = [&](const float (&av)[kRlChunk], const float (&kv)[kRlChunk]) {
-        int skip = (s_c + 1 == nch) ? last_skip : 0;
-        if (s_t >= total) skip = kRlChunk;  // an odd sequence's filler chunk
-        ++s_t;
-        ++s_c;
-        if (s_c == nch) s_c = 0;
-        if (skip == 0) {
+    // Positions that are not taps — the front of a row's end-aligned last chunk, which belongs to the chunk before,
+    // and an odd sequence's filler chunk — are staged as zeros: sum + a * 0 is sum, bit for bit (a is finite: the
+    // iteration divides by sums + 1e-12), so the loop has no cases and every broadcast has one consumer to fold into.
+    auto accumulate = [&](const float (&av)[kRlChunk], float kl) {
+        float prod[kRlChunk];
+        row_mul16(av, kl, prod);
 #pragma unroll
-            for (int q = 0; q < kRlChunk; ++q) sum += av[q] * kv[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < kRlChunk; ++q)
-                if (q >= skip) sum += av[q] * kv[q];  // wave-uniform
-        }
+        for (int q = 0; q < kRlChunk; ++q) sum += prod[q];
     };
-    float a0[kRlChunk], k0[kRlChunk], a1[kRlChunk], k1[kRlChunk];
+    float a0[kRlChunk], a1[kRlChunk], k0, k1;
     fetch(a0, k0);
     for (int t = 0; t < total; t += 2) {
         fetch(a1, k1);
@@ -1200,7 +1197,10 @@ __device__ __forceinline__ float rl_tile_taps(const float *origin, int wsz, cons
 constexpr int kRlSplit = 16;            // waves per tile
 constexpr int kRlThreads = 64 * kRlSplit;
 constexpr int kRlPix = 4;               // pixels per thread
-constexpr int kRlTilesPerBlock = 4;     // narrow-kernel tiles per block (one per 256 threads)
+constexpr int kRlTilesPerBlock = 1;     // narrow-kernel tiles per block (one per 256 threads).  Four (round 2's first
+                                        // arrangement: the taps staged once for four tiles) put four waves on every
+                                        // SIMD of a CU while other CUs idled: a launch lasts as long as its fullest CU
+constexpr int kRlNarrowThreads = 256 * kRlTilesPerBlock;
 
 __host__ __device__ inline int rl_turned_stride(int wsz)
 {
@@ -1275,10 +1275,9 @@ __host__ __device__ inline size_t rl_tap_floats(int pr, int pc)
 }
 __host__ __device__ inline bool rl_turned(int pr, int pc) { return pr * pc > 256; }  // RlBand::mode == 1
 
-// A block of the tiled grid: one tile of a wide-kernel band (all 16 waves share it, see above), or
-// kRlTilesPerBlock = 4 consecutive tiles of a narrow-kernel band, one per group of 256 threads — a narrow
-// kernel keeps the reference's one-chain-per-pixel sums, so a tile can use 256 threads only, and a block
-// of 1024 that held one such tile left three quarters of its waves with nothing to do but stage.
+// A block of the tiled grid: one tile of a wide-kernel band (2-D sums: all 16 waves share it, see above), or
+// kRlTilesPerBlock consecutive tiles of a narrow-kernel band, one per group of 256 threads — a narrow kernel keeps
+// the reference's one-chain-per-pixel sums, so a tile can use 256 threads only.
 __host__ __device__ inline unsigned rl_tile_blocks(bool turned, unsigned n_tiles)
 {
     return turned ? n_tiles : (n_tiles + kRlTilesPerBlock - 1) / kRlTilesPerBlock;
@@ -1307,7 +1306,7 @@ __device__ __forceinline__ RlBand rl_block_band(const RlTileRef *__restrict__ ti
 // staging and partial-sum reduction then run under the other's tap loop — while the narrow path's double-buffered
 // chunks need more registers and less LDS.
 template <bool WIDE>
-__global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
+__global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1) void k_rl_step_tiled(const RlTileRef *__restrict__ tiles,
                                                                             const int *__restrict__ it_base, int iteration,
                                                                             int step, float *__restrict__ ws)
 {
@@ -1323,7 +1322,7 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
     const float *a = ws + a_off;
     const float *k = ws + (step == 0 ? B.off_psf : B.off_mirror);
     if constexpr (!WIDE) {
-        // ---- narrow kernel: four tiles, one per 256-thread group; the taps are staged once for all four
+        // ---- narrow kernel: kRlTilesPerBlock tiles, one per 256-thread group, the taps staged once per block
         const int grp = (int)(threadIdx.x >> 8), px = (int)(threadIdx.x & 255);
         const unsigned lt = (blockIdx.x - B.tblk0) * kRlTilesPerBlock + (unsigned)grp;
         const bool live = lt < (unsigned)B.n_tiles;
@@ -1340,16 +1339,18 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
         // Everything is requested from memory before anything is waited for (the inputs were written by other CUs
         // one launch ago: every dependent load is two microseconds of a launch that computes for three): a tap in
         // the order rl_tile_taps consumes them, the update's other operand, then the halo, eight rows per wave at a time.
-        const int n_el = pr * nch * kRlChunk;
+        const int n_el = (pr * nch + 2) * kRlChunk;  // the taps' chunks and the zeros of the filler chunks behind them
         const unsigned k_off = step == 0 ? B.off_psf : B.off_mirror;
+        const int last_skip = nch * kRlChunk - pc;  // positions in front of a row's end-aligned last chunk: not taps
         auto tap_at = [&](int e) {
             const int t = e / kRlChunk, q = e % kRlChunk;
             const int m = t / nch, c = t - m * nch;
-            const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;  // < 0 only in a skipped position
-            return ws[src >= 0 && e < n_el ? k_off + (unsigned)src : B.off_zero];
+            const int src = m * pc + rl_chunk_n0(c, nch, pc) + q;
+            const bool is_tap = m < pr && !(c + 1 == nch && q < last_skip);
+            return ws[is_tap ? k_off + (unsigned)src : B.off_zero];
         };
         float other = 0.0f;
-        const float k_v = tap_at((int)threadIdx.x);
+        const float k_v = tap_at((int)threadIdx.x), k_v1 = tap_at((int)threadIdx.x + kRlNarrowThreads);  // up to 30 chunks
         if (writer) other = ws[(step == 0 ? B.off_d : B.off_u) + idx];
         if (live) {  // zeros outside the image — the reference skips those taps, and sum + 0*k leaves the sum as it was
             constexpr int kRows = 8;
@@ -1379,11 +1380,17 @@ __global__ __launch_bounds__(kRlThreads, WIDE ? 8 : 4) void k_rl_step_tiled(cons
             for (int rb = wvu + 4 * kRows; rb < hs; rb += 4 * kRows)
                 for (int c = ln; c < wsz; c += kWave) stage(rb, c);
         }
+        if (live) {  // the slack on either side of the tile meets zero taps only, but must be finite
+            if (px < kRlChunk) a_s[px - kRlChunk] = 0.0f;
+            if (px < (int)tile_fl - 2 * kRlChunk - hs * wsz + kRlChunk) a_s[hs * wsz + px] = 0.0f;
+        }
         if ((int)threadIdx.x < n_el) k_s[threadIdx.x] = k_v;
-        for (int e = (int)threadIdx.x + kRlThreads; e < n_el; e += kRlThreads) k_s[e] = tap_at(e);
+        if ((int)threadIdx.x + kRlNarrowThreads < n_el) k_s[threadIdx.x + kRlNarrowThreads] = k_v1;
+        for (int e = (int)threadIdx.x + 2 * kRlNarrowThreads; e < n_el; e += kRlNarrowThreads) k_s[e] = tap_at(e);
         __syncthreads();
-        if (!writer) return;  // no barrier below on this path
-        const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);
+        if (!live) return;  // whole waves; no barrier below on this path
+        const float sum = rl_tile_taps(a_s + ti * wsz + tj, wsz, k_s, pr, pc);  // every lane: see there
+        if (!writer) return;
         if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
         else ws[B.off_u + idx] = other * sum;
         return;
@@ -2561,7 +2568,7 @@ void launch_rl_step_tiled(hipStream_t st, int kind, const RlTileRef *d_tiles, un
     if (total_tiles == 0) return;
     if (kind == kRlSeparable) THZ_LAUNCH(k_rl_step_sep, total_tiles, kRlSepThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
     else if (kind == kRlWide) THZ_LAUNCH(k_rl_step_tiled<true>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
-    else THZ_LAUNCH(k_rl_step_tiled<false>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    else THZ_LAUNCH(k_rl_step_tiled<false>, total_tiles, kRlNarrowThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
 }
 
 void launch_dc_gain(hipStream_t st, const RlBand *d_bands, int n_bands, size_t npix,

@@ -70,6 +70,40 @@ __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, 
 __device__ __forceinline__ float wave_shfl_up(float v, int d) { return __shfl_up(v, d, kWave); }
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, kWave); }
 
+// out[q] = v of lane q of the caller's row of 16 lanes, q = 0..15 (DPP row_newbcast: each folds into the VALU
+// instruction that consumes it, so a value held one per lane is handed to a whole row at no cost).  All 16 lanes of
+// the row must be active.
+template <int Q>
+__device__ __forceinline__ float row_lane(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + Q, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void row_bcast16(float v, float (&out)[16])
+{
+    out[0] = row_lane<0>(v); out[1] = row_lane<1>(v); out[2] = row_lane<2>(v); out[3] = row_lane<3>(v);
+    out[4] = row_lane<4>(v); out[5] = row_lane<5>(v); out[6] = row_lane<6>(v); out[7] = row_lane<7>(v);
+    out[8] = row_lane<8>(v); out[9] = row_lane<9>(v); out[10] = row_lane<10>(v); out[11] = row_lane<11>(v);
+    out[12] = row_lane<12>(v); out[13] = row_lane<13>(v); out[14] = row_lane<14>(v); out[15] = row_lane<15>(v);
+}
+
+// prod[q] = a[q] * (k of lane q of the caller's row of 16 lanes): sixteen v_mul_f32_dpp.  Written out because the
+// compiler, left to fold row_lane<q>() into the multiplies, pairs the multiplies into v_pk_mul_f32 first (which takes
+// no DPP operand) and keeps most broadcasts as separate moves.  k must come from memory or LDS (a VALU result read
+// by DPP needs two wait states, which inline assembly does not get inserted for it; the s_nop covers a copy).
+__device__ __forceinline__ void row_mul16(const float (&a)[16], float k, float (&prod)[16])
+{
+#define THZ_DPP_MUL(d, s, q) "v_mul_f32_dpp " d ", %8, " s " row_newbcast:" #q " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm("s_nop 1\n" THZ_DPP_MUL("%0", "%9", 0) THZ_DPP_MUL("%1", "%10", 1) THZ_DPP_MUL("%2", "%11", 2) THZ_DPP_MUL("%3", "%12", 3)
+            THZ_DPP_MUL("%4", "%13", 4) THZ_DPP_MUL("%5", "%14", 5) THZ_DPP_MUL("%6", "%15", 6) THZ_DPP_MUL("%7", "%16", 7)
+        : "=&v"(prod[0]), "=&v"(prod[1]), "=&v"(prod[2]), "=&v"(prod[3]), "=&v"(prod[4]), "=&v"(prod[5]), "=&v"(prod[6]), "=&v"(prod[7])
+        : "v"(k), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+    asm("s_nop 1\n" THZ_DPP_MUL("%0", "%9", 8) THZ_DPP_MUL("%1", "%10", 9) THZ_DPP_MUL("%2", "%11", 10) THZ_DPP_MUL("%3", "%12", 11)
+            THZ_DPP_MUL("%4", "%13", 12) THZ_DPP_MUL("%5", "%14", 13) THZ_DPP_MUL("%6", "%15", 14) THZ_DPP_MUL("%7", "%16", 15)
+        : "=&v"(prod[8]), "=&v"(prod[9]), "=&v"(prod[10]), "=&v"(prod[11]), "=&v"(prod[12]), "=&v"(prod[13]), "=&v"(prod[14]), "=&v"(prod[15])
+        : "v"(k), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+#undef THZ_DPP_MUL
+}
+
 // ---- cross-lane moves on the DPP path (no LDS crossbar traffic, unlike __shfl)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_or_zero(float v)
