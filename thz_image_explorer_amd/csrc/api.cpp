@@ -50,6 +50,7 @@ void thz_destroy(thz_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &b : ctx->dc_pool) (void)hipFree(b.p);
     for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

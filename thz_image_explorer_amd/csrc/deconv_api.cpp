@@ -14,20 +14,46 @@ using namespace thz;
 
 namespace {
 
+// The call's device blocks come from the context's pool (ctx.hpp: dc_pool) and go back to it when the call ends;
+// everything the call enqueued has either been waited for by then or sits on the context's stream, in front of
+// whatever the next call enqueues.
 struct DevFree {
-    std::vector<void *> ptrs;
+    thz_ctx *ctx;
+    explicit DevFree(thz_ctx *c) : ctx(c)
+    {
+        for (auto &b : ctx->dc_pool) b.used_this_call = false;
+    }
     ~DevFree()
     {
-        for (void *p : ptrs) (void)hipFree(p);
+        auto &pool = ctx->dc_pool;
+        for (size_t i = 0; i < pool.size();) {
+            pool[i].in_use = false;
+            if (!pool[i].used_this_call) {  // left over from another geometry
+                (void)hipFree(pool[i].p);
+                pool.erase(pool.begin() + (long)i);
+            } else ++i;
+        }
     }
     template <class T>
     hipError_t alloc(T **out, size_t bytes)
     {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = reinterpret_cast<T *>(p);
-        return e;
+        if (bytes == 0) bytes = 16;
+        thz_ctx::Block *best = nullptr;
+        for (auto &b : ctx->dc_pool)  // the smallest free block that is large enough, and not wastefully so
+            if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (!best || b.bytes < best->bytes)) best = &b;
+        if (!best) {
+            void *p = nullptr;
+            const hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) {
+                *out = nullptr;
+                return e;
+            }
+            ctx->dc_pool.push_back({p, bytes, false, false});
+            best = &ctx->dc_pool.back();
+        }
+        best->in_use = best->used_this_call = true;
+        *out = reinterpret_cast<T *>(best->p);
+        return hipSuccess;
     }
 };
 
@@ -162,7 +188,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     if (M > 16384 || !build_plan(M, H, true))  // with the F core's tables where M has them (band energies)
         return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
     const size_t N = M / 2, nk = N + 1;
-    DevFree mem;
+    DevFree mem(ctx);
     c32 *d_tw = nullptr, *d_spec = nullptr, *d_H = nullptr;
     float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
     RlBand *d_bands = nullptr;
