@@ -115,8 +115,8 @@ inline void block_lds_barrier() { __syncthreads(); }
 inline unsigned lds_flag_load(const unsigned *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline void lds_flag_store(unsigned *p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline void spin_pause() { sched_yield(); }
-typedef int thz_i8 __attribute__((ext_vector_type(8)));
-typedef int thz_i16 __attribute__((ext_vector_type(16)));
+typedef int thz_i8 __attribute__((ext_vector_type(8), aligned(16)));   // 16-byte alignment: what a record has
+typedef int thz_i16 __attribute__((ext_vector_type(16), aligned(16)));
 inline void want_scalars_now(thz_i16, thz_i8, int) {}
 inline int lane_id() { return (int)(threadIdx.x & 63); }
 

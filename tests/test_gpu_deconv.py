@@ -212,3 +212,67 @@ def test_untiled_fallback_matches_tiled(engine, monkeypatch):
         else:
             assert np.abs(outs[0] - outs[1]).max() / np.abs(outs[1]).max() < 1e-5
         d_in.free(); d_out.free()
+
+
+def test_separable_wide_kernels_match_the_2d_sums(engine, monkeypatch):
+    """every band PSF is an outer product of two profiles, so the wide kernels run as a pass along the rows and a
+    pass down the columns (k_rl_step_sep); THZ_RL_NO_SEPARABLE=1 keeps the 2-D sums of round 1 — the two must
+    agree within rounding, and the host's 2-D array must BE the outer product the device factors it into"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nx, ny, nt, d = 48, 40, 128, 1.0
+    cfg = pkg.DeconvCfg(30, 4, 0.25, 2.0, 0.5)
+    time, cube = _bar_target_cube(nx, ny, nt)
+    wide = 0
+    for f in pkg.host_filter_bank(time, cfg)[1]:
+        k = pkg.host_band_psf(psf, f, d, d, nx, ny)
+        wide += k.size > 256
+        c = np.unravel_index(np.argmax(k), k.shape)   # normalised profiles: the peak row / column are the factors
+        assert np.abs(np.outer(k[:, c[1]], k[c[0], :]) / k[c] - k).max() <= 4e-7 * k.max()
+    assert wide >= 1
+    engine.set_time_axis(time)
+    d_in = engine.to_device(cube); d_out = engine.empty((nx * ny, nt)); d_g = engine.empty((4, nx * ny))
+    res = []
+    for knob in (None, "1"):
+        if knob:
+            monkeypatch.setenv("THZ_RL_NO_SEPARABLE", knob)
+        else:
+            monkeypatch.delenv("THZ_RL_NO_SEPARABLE", raising=False)
+        assert engine.deconvolve(psf, cfg, nx, ny, d, d, d_in, d_out, None, d_g) == 0
+        res.append((d_out.download((nx, ny, nt), np.float32), d_g.download((4, nx, ny), np.float32)))
+    monkeypatch.delenv("THZ_RL_NO_SEPARABLE", raising=False)
+    assert not np.array_equal(res[0][1], res[1][1])          # two different kernels did run
+    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < 5e-6
+    assert np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max() < 5e-6
+    d_in.free(); d_out.free(); d_g.free()
+
+
+def test_repeated_calls_reuse_and_release_device_blocks():
+    """the call's device blocks stay in the context for the next call (ctx.hpp: dc_pool): a second call of the same
+    geometry, a call of another geometry in between and a guarded call (which uses none) must all give what a
+    fresh context gives, bit for bit"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    cases = [dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 4, 0.8, 3.0, 0.5)),
+             dict(nx=48, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5)),
+             dict(nx=12, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5))]   # guarded: nx < 16
+
+    def run(eng, c):
+        time, cube = _bar_target_cube(c["nx"], c["ny"], c["nt"])
+        eng.set_time_axis(time)
+        d_in = eng.to_device(cube); d_out = eng.empty((c["nx"] * c["ny"], c["nt"]))
+        st = eng.deconvolve(psf, c["cfg"], c["nx"], c["ny"], c["d"], c["d"], d_in, d_out)
+        out = d_out.download((c["nx"], c["ny"], c["nt"]), np.float32)
+        d_in.free(); d_out.free()
+        return st, out
+
+    fresh = []
+    for c in cases:
+        eng = pkg.Engine(0)
+        fresh.append(run(eng, c))
+        eng.close()
+    eng = pkg.Engine(0)
+    for i in (0, 0, 1, 0, 2, 1, 1, 0):
+        st, out = run(eng, cases[i])
+        assert st == fresh[i][0] and np.array_equal(out, fresh[i][1]), i
+    eng.close()

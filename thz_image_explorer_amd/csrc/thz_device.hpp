@@ -62,8 +62,8 @@ __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 // Block-uniform values the compiler must have in scalar registers HERE, all of them at once.  Used on a per-block
 // record in front of the block's first branch: left alone, the compiler loads such a record piece by piece, each
 // piece behind the branch that first needs it — five dependent scalar round trips at the head of a 10 us kernel.
-typedef int thz_i8 __attribute__((ext_vector_type(8)));
-typedef int thz_i16 __attribute__((ext_vector_type(16)));
+typedef int thz_i8 __attribute__((ext_vector_type(8), aligned(16)));   // 16-byte alignment: what a record has
+typedef int thz_i16 __attribute__((ext_vector_type(16), aligned(16)));
 __device__ __forceinline__ void want_scalars_now(thz_i16 a, thz_i8 b, int c) { asm volatile("" ::"s"(a), "s"(b), "s"(c)); }
 
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, kWave); }
