@@ -269,7 +269,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.blk0 = blk;
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
         B.tiles_w = (B.W + 15) / 16;
-        B.n_tiles = B.tiles_w * ((B.H + 15) / 16);
+        const int tile_rows = rl_tile_rows(separable && B.mode != 0 ? kRlSeparable : kRlNarrow);
+        B.n_tiles = B.tiles_w * ((B.H + tile_rows - 1) / tile_rows);
         tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc, separable && B.mode != 0));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;

@@ -1456,15 +1456,15 @@ __global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1)
 //     T[x][j]   = sum_n a[x][j + sc - n] fy[n]          (halo rows x, the tile's 16 columns)
 //     out[i][j] = sum_m T[i + sr - m][j] fx[m]
 // pr + pc multiply-adds per pixel and half-step instead of pr pc (104 against 2 679 for the 47 x 57 band), which
-// turns a tile from ALU/LDS-bound into what its halo costs to fetch.  One 16 x 16 tile per block of 256 threads
-// (25 KB of LDS for the largest band: six tiles share a CU), the halo stored as it lies in the image and the
+// turns a tile from ALU/LDS-bound into what its halo costs to fetch — hence tiles of 32 x 16 pixels (kRlSepTileRows;
+// 512 threads, 31 KB of LDS for the largest band), which load 11 floats per pixel where 16 x 16 load 20.  The halo is stored as it lies in the image and the
 // profiles stored reversed, so both passes walk upwards: out[ti][tj] = sum_m' sum_n' a_s[ti + m'][tj + n']
 // fx[pr-1-m'] fy[pc-1-n'].  The mirrored PSF of the second half-step has the profiles the other way round.
 // Pass A reuses the wide kernel's window arithmetic (four pixels side by side per thread, packed FMAs): a
 // quarter wave reads 16 consecutive halo rows at one column group, conflict-free for an odd row stride in 16-byte
 // units.
-constexpr int kRlSepThreads = 256;
-constexpr int kRlSepRows = 16;  // halo rows a wave has in flight while staging
+constexpr int kRlSepThreads = kRlTile * kRlSepTileRows;  // a thread per pixel of the 32 x 16 tile
+constexpr int kRlSepRows = 10;  // halo rows a wave has in flight while staging (78 rows of the largest band / 8 waves)
 
 __host__ __device__ inline int rl_sep_stride(int pc)
 {
@@ -1476,7 +1476,7 @@ __host__ __device__ inline int rl_sep_stride(int pc)
 // LDS floats of a block: halo rows | fy (whole chunks) | fx | T
 __host__ __device__ inline size_t rl_sep_floats(int pr, int pc)
 {
-    const int hs = kRlTile + pr - 1;
+    const int hs = kRlSepTileRows + pr - 1;
     return (size_t)hs * rl_sep_stride(pc) + (size_t)((pc + kRlChunk - 1) / kRlChunk) * kRlChunk + (size_t)(pr + 3) / 4 * 4
            + (size_t)hs * kRlTile;
 }
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *
     const RlBand B = rl_block_band(tiles, it_base, iteration);
     if (iteration >= B.n_iter) return;  // block-uniform
     const int pr = B.pr, pc = B.pc;
-    const int hs = kRlTile + pr - 1, wsz = kRlTile + pc - 1;
+    const int hs = kRlSepTileRows + pr - 1, wsz = kRlTile + pc - 1;
     const int nch = rl_chunks(pc), wsp = rl_sep_stride(pc);
     const unsigned a_off = step == 0 ? B.off_u : B.off_t;
     const float *fx = ws + B.off_fx, *fy = ws + B.off_fy;
@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *
     float *fx_s = fy_s + nch * kRlChunk;
     float *t_s = fx_s + (pr + 3) / 4 * 4;
     const unsigned lt = blockIdx.x - B.tblk0;
-    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlTile, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlSepTileRows, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
     // first image row / column of the halo: x = i + (pr-1)/2 - m
     const int r0 = ti0 + (pr - 1) / 2 - (pr - 1), c0 = tj0 + (pc - 1) / 2 - (pc - 1);
     const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
