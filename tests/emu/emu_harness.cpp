@@ -175,6 +175,7 @@ extern "C" int emu_rl_iteration_sep(int h, int w, int pr, int pc, int mode, cons
     }
     const unsigned blocks = (unsigned)((img + 255) / 256);
     const int tile_rows = rl_tile_rows(tiled == 2 ? kRlSeparable : kRlNarrow);
+    B.tiles_w = (B.W + rl_tile_cols(tiled == 2 ? kRlSeparable : kRlNarrow) - 1) / rl_tile_cols(tiled == 2 ? kRlSeparable : kRlNarrow);
     B.n_tiles = B.tiles_w * ((B.H + tile_rows - 1) / tile_rows);
     const unsigned tiles_n = rl_tile_block_count(pr, pc, (unsigned)B.n_tiles);  // blocks of the tiled grid
     std::vector<RlTileRef> tiles(tiles_n, RlTileRef{B});

@@ -268,8 +268,9 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         if (B.n_iter > max_iter) max_iter = B.n_iter;
         B.blk0 = blk;
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
-        B.tiles_w = (B.W + 15) / 16;
-        const int tile_rows = rl_tile_rows(separable && B.mode != 0 ? kRlSeparable : kRlNarrow);
+        const int tile_kind = separable && B.mode != 0 ? kRlSeparable : kRlNarrow;
+        const int tile_rows = rl_tile_rows(tile_kind), tile_cols = rl_tile_cols(tile_kind);
+        B.tiles_w = (B.W + tile_cols - 1) / tile_cols;
         B.n_tiles = B.tiles_w * ((B.H + tile_rows - 1) / tile_rows);
         tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc, separable && B.mode != 0));
         const size_t img = (size_t)B.H * B.W;

@@ -1456,20 +1456,23 @@ __global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1)
 //     T[x][j]   = sum_n a[x][j + sc - n] fy[n]          (halo rows x, the tile's 16 columns)
 //     out[i][j] = sum_m T[i + sr - m][j] fx[m]
 // pr + pc multiply-adds per pixel and half-step instead of pr pc (104 against 2 679 for the 47 x 57 band), which
-// turns a tile from ALU/LDS-bound into what its halo costs to fetch — hence tiles of 32 x 16 pixels (kRlSepTileRows;
-// 512 threads, 31 KB of LDS for the largest band), which load 11 floats per pixel where 16 x 16 load 20.  The halo is stored as it lies in the image and the
+// turns a tile from ALU/LDS-bound into what its halo costs to fetch — hence tiles of kRlSepTileRows x kRlSepTileCols
+// pixels (32 x 32: 1 024 threads, 42 KB of LDS for the largest band), which load 6.7 floats per pixel where 16 x 16
+// load 20.  The halo is stored as it lies in the image and the
 // profiles stored reversed, so both passes walk upwards: out[ti][tj] = sum_m' sum_n' a_s[ti + m'][tj + n']
 // fx[pr-1-m'] fy[pc-1-n'].  The mirrored PSF of the second half-step has the profiles the other way round.
 // Pass A reuses the wide kernel's window arithmetic (four pixels side by side per thread, packed FMAs): a
 // quarter wave reads 16 consecutive halo rows at one column group, conflict-free for an odd row stride in 16-byte
 // units.
-constexpr int kRlSepThreads = kRlTile * kRlSepTileRows;  // a thread per pixel of the 32 x 16 tile
-constexpr int kRlSepRows = 10;  // halo rows a wave has in flight while staging (78 rows of the largest band / 8 waves)
+constexpr int kRlSepThreads = kRlSepTileCols * kRlSepTileRows;  // a thread per pixel of the tile
+constexpr int kRlSepQuads = kRlSepTileCols / kRlPix;              // column groups of four per halo row (pass A)
+constexpr int kRlSepRows = (kRlSepTileRows + 48 + kRlSepThreads / 64 - 1) / (kRlSepThreads / 64);  // halo rows a wave has in flight while staging: kernels of up to 49 rows in one batch
 
 __host__ __device__ inline int rl_sep_stride(int pc)
 {
-    // the last column group's window ends at column 12 + 16 chunks + 3; everything up to the stride is initialised
-    int w = kRlChunk * ((pc + kRlChunk - 1) / kRlChunk + 1);
+    // the last column group's window ends at column (tile width - 4) + 16 chunks + 3; everything up to the stride is
+    // initialised
+    int w = kRlChunk * ((pc + kRlChunk - 1) / kRlChunk) + kRlSepTileCols;
     if (w / 4 % 2 == 0) w += 4;
     return w;
 }
@@ -1478,10 +1481,10 @@ __host__ __device__ inline size_t rl_sep_floats(int pr, int pc)
 {
     const int hs = kRlSepTileRows + pr - 1;
     return (size_t)hs * rl_sep_stride(pc) + (size_t)((pc + kRlChunk - 1) / kRlChunk) * kRlChunk + (size_t)(pr + 3) / 4 * 4
-           + (size_t)hs * kRlTile;
+           + (size_t)hs * kRlSepTileCols;
 }
 
-__global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *__restrict__ tiles,
+__global__ __launch_bounds__(kRlSepThreads, 8) void k_rl_step_sep(const RlTileRef *__restrict__ tiles,
                                                                const int *__restrict__ it_base, int iteration, int step,
                                                                float *__restrict__ ws)
 {
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *
     const RlBand B = rl_block_band(tiles, it_base, iteration);
     if (iteration >= B.n_iter) return;  // block-uniform
     const int pr = B.pr, pc = B.pc;
-    const int hs = kRlSepTileRows + pr - 1, wsz = kRlTile + pc - 1;
+    const int hs = kRlSepTileRows + pr - 1, wsz = kRlSepTileCols + pc - 1;
     const int nch = rl_chunks(pc), wsp = rl_sep_stride(pc);
     const unsigned a_off = step == 0 ? B.off_u : B.off_t;
     const float *fx = ws + B.off_fx, *fy = ws + B.off_fy;
@@ -1498,12 +1501,12 @@ __global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *
     float *fx_s = fy_s + nch * kRlChunk;
     float *t_s = fx_s + (pr + 3) / 4 * 4;
     const unsigned lt = blockIdx.x - B.tblk0;
-    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlSepTileRows, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlTile;
+    const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlSepTileRows, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlSepTileCols;
     // first image row / column of the halo: x = i + (pr-1)/2 - m
     const int r0 = ti0 + (pr - 1) / 2 - (pr - 1), c0 = tj0 + (pc - 1) / 2 - (pc - 1);
     const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
     const int px = (int)threadIdx.x;
-    const int ti = px / kRlTile, tj = px % kRlTile;
+    const int ti = px / kRlSepTileCols, tj = px % kRlSepTileCols;
     const int i = ti0 + ti, j = tj0 + tj;
     const bool writer = i < B.H && j < B.W;
     const int idx = i * B.W + j;
@@ -1565,26 +1568,26 @@ __global__ __launch_bounds__(kRlSepThreads) void k_rl_step_sep(const RlTileRef *
     }
     __syncthreads();
     // pass A: (halo row, column group of four) per thread
-    for (int task = px; task < (hs + 15) / 16 * 64; task += kRlSepThreads) {
-        const int r = task / 64 * 16 + (task & 15), q = (task >> 4) & 3;
+    for (int task = px; task < (hs + 15) / 16 * (16 * kRlSepQuads); task += kRlSepThreads) {
+        const int r = task / (16 * kRlSepQuads) * 16 + (task & 15), q = (task >> 4) % kRlSepQuads;  // a quarter wave: 16 rows, one column group
         if (r >= hs) continue;
         float acc[kRlPix];
         rl_tile_taps_split(a_s + r * wsp + 4 * q, wsp, fy_s, pc, 0, 1, acc);  // acc[p] = sum_n w[3 - p + n] fy_s[n]
-        *reinterpret_cast<float4 *>(t_s + r * kRlTile + 4 * q) = float4{acc[3], acc[2], acc[1], acc[0]};
+        *reinterpret_cast<float4 *>(t_s + r * kRlSepTileCols + 4 * q) = float4{acc[3], acc[2], acc[1], acc[0]};
     }
     __syncthreads();
     if (!writer) return;
     // pass B: a pixel per thread, four partial sums
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    const float *col = t_s + ti * kRlTile + tj;
+    const float *col = t_s + ti * kRlSepTileCols + tj;
     int m = 0;
     for (; m + 4 <= pr; m += 4) {
-        s0 = fmaf(col[(m + 0) * kRlTile], fx_s[m + 0], s0);
-        s1 = fmaf(col[(m + 1) * kRlTile], fx_s[m + 1], s1);
-        s2 = fmaf(col[(m + 2) * kRlTile], fx_s[m + 2], s2);
-        s3 = fmaf(col[(m + 3) * kRlTile], fx_s[m + 3], s3);
+        s0 = fmaf(col[(m + 0) * kRlSepTileCols], fx_s[m + 0], s0);
+        s1 = fmaf(col[(m + 1) * kRlSepTileCols], fx_s[m + 1], s1);
+        s2 = fmaf(col[(m + 2) * kRlSepTileCols], fx_s[m + 2], s2);
+        s3 = fmaf(col[(m + 3) * kRlSepTileCols], fx_s[m + 3], s3);
     }
-    for (; m < pr; ++m) s0 = fmaf(col[m * kRlTile], fx_s[m], s0);
+    for (; m < pr; ++m) s0 = fmaf(col[m * kRlSepTileCols], fx_s[m], s0);
     const float sum = (s0 + s1) + (s2 + s3);
     if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
     else ws[B.off_u + idx] = other * sum;

@@ -60,9 +60,11 @@ struct RlBand {
     unsigned off_zero;  // a float that is 0.0f: what a halo position outside the image loads (no select, no mask to keep)
 };
 enum : int { kRlNarrow = 0, kRlWide = 1, kRlSeparable = 2 };  // kinds of tile lists (one kernel each)
-// rows of a tile: 16 x 16 pixels, but 32 x 16 for the separable kernels — their cost is the halo they fetch (a 47 x 57
-// kernel: 20 floats loaded per pixel of a 16 x 16 tile, 11 per pixel of a 32 x 16 one), not their arithmetic
-constexpr int kRlTileRows = 16, kRlSepTileRows = 32;
+// a tile: 16 x 16 pixels, but kRlSepTileRows x kRlSepTileCols for the separable kernels — their cost is the halo they
+// fetch (a 47 x 57 kernel: 20 floats loaded per pixel of a 16 x 16 tile, 11 for 32 x 16, 6.7 for 32 x 32), not their
+// arithmetic
+constexpr int kRlTileRows = 16, kRlTileCols = 16, kRlSepTileRows = 32, kRlSepTileCols = 32;
+inline int rl_tile_cols(int kind) { return kind == kRlSeparable ? kRlSepTileCols : kRlTileCols; }
 inline int rl_tile_rows(int kind) { return kind == kRlSeparable ? kRlSepTileRows : kRlTileRows; }
 
 void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands, int n_taps, const double *cs,
