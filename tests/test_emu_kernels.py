@@ -293,7 +293,8 @@ def test_rl_step_kernels(emu, case):
 
 
 @pytest.mark.parametrize("case", [dict(h=11, w=13, pr=19, pc=21), dict(h=20, w=37, pr=47, pc=57),
-                                  dict(h=9, w=40, pr=17, pc=33), dict(h=40, w=9, pr=53, pc=5)])
+                                  dict(h=9, w=40, pr=17, pc=33), dict(h=40, w=9, pr=53, pc=5),
+                                  dict(h=6, w=70, pr=3, pc=121)])   # halo wider than two column passes of a wave
 def test_rl_step_separable_kernel(emu, case):
     """k_rl_step_sep: a wide kernel that is an outer product fx x fy (every band PSF of the reference is one)
     as a pass along the rows and a pass down the columns — against the reference's loops over the 2-D array and
