@@ -71,6 +71,11 @@ typedef struct thz_window_cfg {
  * GPU is present — there is no CPU fallback. */
 int thz_create(int device, thz_ctx **out);
 void thz_destroy(thz_ctx *ctx);
+/* Frees the device scratch the context keeps between calls (the pixel-sum workspace, the blocks of the last
+ * thz_deconvolve — see there); the next call that needs them allocates again.  Waits for the context's stream.
+ * Not in the reference (its buffers die with each filter call): a host under memory pressure calls this after a
+ * Deconvolution, the way it would drop a cache. */
+int thz_release_scratch(thz_ctx *ctx);
 const char *thz_last_error(const thz_ctx *ctx);
 int thz_abi_version(void);
 /* hipStream_t of the context as an opaque pointer (for callers that want to

@@ -272,7 +272,9 @@ def test_repeated_calls_reuse_and_release_device_blocks():
         fresh.append(run(eng, c))
         eng.close()
     eng = pkg.Engine(0)
-    for i in (0, 0, 1, 0, 2, 1, 1, 0):
+    for n, i in enumerate((0, 0, 1, 0, 2, 1, 1, 0)):
         st, out = run(eng, cases[i])
         assert st == fresh[i][0] and np.array_equal(out, fresh[i][1]), i
+        if n == 5:
+            eng.release_scratch()   # thz_release_scratch: the next call allocates again
     eng.close()

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("thz_abi_version", C.c_int, []),
     ("thz_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("thz_destroy", None, [_P]),
+    ("thz_release_scratch", C.c_int, [_P]),
     ("thz_last_error", C.c_char_p, [_P]),
     ("thz_stream", _P, [_P]),
     ("thz_sync", C.c_int, [_P]),
@@ -688,6 +689,10 @@ class Engine:
     def _check(self, rc: int):
         if rc != THZ_OK:
             raise ThzError(rc, self.lib.thz_last_error(self.ctx).decode())
+
+    def release_scratch(self):
+        """frees the device scratch the context keeps between calls (thz_release_scratch)"""
+        self._check(self.lib.thz_release_scratch(self.ctx))
 
     def close(self):
         if self.ctx:

@@ -61,6 +61,21 @@ void thz_destroy(thz_ctx *ctx)
     delete ctx;
 }
 
+int thz_release_scratch(thz_ctx *ctx)
+{
+    if (!ctx) return THZ_ERR_INVALID;
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->aux_streams)
+        if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (auto &b : ctx->dc_pool) (void)hipFree(b.p);
+    ctx->dc_pool.clear();
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    return THZ_OK;
+}
+
 const char *thz_last_error(const thz_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 void *thz_stream(thz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
