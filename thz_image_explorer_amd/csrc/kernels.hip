@@ -1356,22 +1356,22 @@ __global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1)
             constexpr int kRows = 8;
             const int wvu = THZ_UNIFORM(px >> 6), ln = px & 63;
             auto stage = [&](int rb, int c) {
-                    float v[kRows];
-                    const int y = c0 + c;
-                    const bool yin = y >= 0 && y < B.W;
+                float v[kRows];
+                const int y = c0 + c;
+                const bool yin = y >= 0 && y < B.W;
 #pragma unroll
-                    for (int q = 0; q < kRows; ++q) {
-                        // rows are wave-uniform (scalar tests); a position outside the image loads a stored zero, so
-                        // the loads are unconditional, issue back to back and leave no masks to keep
-                        const int r = rb + 4 * q, x = r0 + r;
-                        const bool row_ok = r < hs && x >= 0 && x < B.H;
-                        v[q] = ws[row_ok && yin ? a_off + (unsigned)(x * B.W) + (unsigned)y : B.off_zero];
-                    }
+                for (int q = 0; q < kRows; ++q) {
+                    // rows are wave-uniform (scalar tests); a position outside the image loads a stored zero, so
+                    // the loads are unconditional, issue back to back and leave no masks to keep
+                    const int r = rb + 4 * q, x = r0 + r;
+                    const bool row_ok = r < hs && x >= 0 && x < B.H;
+                    v[q] = ws[row_ok && yin ? a_off + (unsigned)(x * B.W) + (unsigned)y : B.off_zero];
+                }
 #pragma unroll
-                    for (int q = 0; q < kRows; ++q) {
-                        const int r = rb + 4 * q;
-                        if (r < hs) a_s[r * wsz + c] = v[q];
-                    }
+                for (int q = 0; q < kRows; ++q) {
+                    const int r = rb + 4 * q;
+                    if (r < hs) a_s[r * wsz + c] = v[q];
+                }
             };
             // the first batch (the whole halo for kernels of up to 17 x 49 taps) stands in front of the loops: at a
             // loop head the compiler waits for every load in flight, the tap's and the operand's included
@@ -1525,34 +1525,34 @@ __global__ __launch_bounds__(kRlSepThreads, 8) void k_rl_step_sep(const RlTileRe
         // loads a stored zero, so the loads are unconditional, issue back to back and leave no masks to keep.
         const int wvu = THZ_UNIFORM(wv);
         auto stage = [&](int rb, int cb) {
-                float v[kRlSepRows][2];
-                bool cok[2];
-                unsigned yv[2];
+            float v[kRlSepRows][2];
+            bool cok[2];
+            unsigned yv[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int c = cb + p * kWave, y = c0 + c;
+                cok[p] = c < wsz && y >= 0 && y < B.W;
+                yv[p] = (unsigned)y;
+            }
+#pragma unroll
+            for (int k = 0; k < kRlSepRows; ++k) {
+                const int r = rb + k * (kRlSepThreads / kWave), x = r0 + r;
+                const bool row_ok = r < hs && x >= 0 && x < B.H;
+                const unsigned row_at = a_off + (unsigned)(x * B.W);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) v[k][p] = ws[row_ok && cok[p] ? row_at + yv[p] : B.off_zero];
+            }
+#pragma unroll
+            for (int k = 0; k < kRlSepRows; ++k) {
+                const int r = rb + k * (kRlSepThreads / kWave);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int c = cb + p * kWave, y = c0 + c;
-                    cok[p] = c < wsz && y >= 0 && y < B.W;
-                    yv[p] = (unsigned)y;
+                    const int c = cb + p * kWave;
+                    if (r < hs && c < wsp) a_s[r * wsp + c] = v[k][p];
                 }
-#pragma unroll
-                for (int k = 0; k < kRlSepRows; ++k) {
-                    const int r = rb + k * (kRlSepThreads / kWave), x = r0 + r;
-                    const bool row_ok = r < hs && x >= 0 && x < B.H;
-                    const unsigned row_at = a_off + (unsigned)(x * B.W);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) v[k][p] = ws[row_ok && cok[p] ? row_at + yv[p] : B.off_zero];
-                }
-#pragma unroll
-                for (int k = 0; k < kRlSepRows; ++k) {
-                    const int r = rb + k * (kRlSepThreads / kWave);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int c = cb + p * kWave;
-                        if (r < hs && c < wsp) a_s[r * wsp + c] = v[k][p];
-                    }
-                }
+            }
         };
-        // the first batch — the whole halo for kernels of up to 49 x 113 taps — stands in front of the loops: at a
+        // the first batch — the whole halo for kernels of up to 49 x 80 taps — stands in front of the loops: at a
         // loop head the compiler waits for every load in flight, which would put the profiles' round trip in
         // front of the halo's
         constexpr int kRowsPerBatch = kRlSepRows * (kRlSepThreads / kWave);
