@@ -375,8 +375,8 @@ int thz_host_band_psf(const thz_psf *psf, float center_freq, float dx, float dy,
  * Returns THZ_SKIPPED with out = in when one of the reference's guards applies
  * (empty PSF, image < 16x16, PSF wider than the image), THZ_ERR_ABORTED (out =
  * in) when aborted.  Blocking.  The call's device scratch (one padded spectrum
- * per pixel, the bands' images: ~0.6 KB x nt/1000 per pixel and band) stays with the
- * context for the next call of the same geometry and is released by a call of
+ * per pixel, the bands' images: ~0.6 KB x nt/1000 per pixel and band) and the
+ * iteration graphs stay with the context for the next call of the same geometry and is released by a call of
  * another geometry or by thz_destroy. */
 int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
                    float dx, float dy, const float *d_in, float *d_out, float *d_img,

@@ -426,16 +426,10 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     int *d_it = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_it, kRlChains * sizeof(int)));
     struct ChainGraphs {
-        hipGraph_t graph[kRlChains] = {nullptr, nullptr, nullptr, nullptr};
-        hipGraphExec_t exec[kRlChains] = {nullptr, nullptr, nullptr, nullptr};
         bool tried[kRlChains] = {false, false, false, false};
         hipEvent_t start = nullptr;
         ~ChainGraphs()
         {
-            for (int c = 0; c < kRlChains; ++c) {
-                if (exec[c]) (void)hipGraphExecDestroy(exec[c]);
-                if (graph[c]) (void)hipGraphDestroy(graph[c]);
-            }
             if (start) (void)hipEventDestroy(start);
         }
     } cg;
@@ -445,18 +439,29 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
             for (int step = 0; step < 2; ++step)
                 launch_rl_step_tiled(st, L.kind, d_tiles + L.first, grid, L.lds, it_base, o, step, d_ws);
     };
+    // The graph of a chain's batch lives in the context (ctx.hpp: dc_graph) and is reused by the next call when
+    // everything its nodes hold is the same: kernel kind, grid, LDS size and the three pointers.
     auto graph_of = [&](size_t c) -> hipGraphExec_t {
-        if (cg.tried[c]) return cg.exec[c];
+        thz_ctx::ChainGraph &G = ctx->dc_graph[c];
+        if (cg.tried[c]) return G.exec;
         cg.tried[c] = true;
+        const TileList &L = lists[c];
+        if (G.exec && G.kind == L.kind && G.blocks == L.blocks && G.lds == L.lds && G.tiles == d_tiles + L.first
+            && G.it == d_it + c && G.ws == d_ws)
+            return G.exec;
+        G.drop();
         if (hipStreamBeginCapture(chain_stream[c], hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            chain_launches(c, chain_stream[c], d_it + c, 0, kRlBatch, lists[c].blocks);
-            if (hipStreamEndCapture(chain_stream[c], &cg.graph[c]) != hipSuccess || !cg.graph[c]
-                || hipGraphInstantiate(&cg.exec[c], cg.graph[c], nullptr, nullptr, 0) != hipSuccess) {
-                cg.exec[c] = nullptr;
+            chain_launches(c, chain_stream[c], d_it + c, 0, kRlBatch, L.blocks);
+            if (hipStreamEndCapture(chain_stream[c], &G.graph) != hipSuccess || !G.graph
+                || hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0) != hipSuccess) {
+                G.drop();
                 (void)hipGetLastError();
+            } else {
+                G.kind = L.kind; G.blocks = L.blocks; G.lds = L.lds;
+                G.tiles = d_tiles + L.first; G.it = d_it + c; G.ws = d_ws;
             }
         }
-        return cg.exec[c];
+        return G.exec;
     };
     if (parallel) {  // the chains start behind the padded images
         HIP_TRY(ctx, hipEventCreateWithFlags(&cg.start, hipEventDisableTiming));
