@@ -248,14 +248,18 @@ def test_separable_wide_kernels_match_the_2d_sums(engine, monkeypatch):
 
 
 def test_repeated_calls_reuse_and_release_device_blocks():
-    """the call's device blocks stay in the context for the next call (ctx.hpp: dc_pool): a second call of the same
-    geometry, a call of another geometry in between and a guarded call (which uses none) must all give what a
+    """the call's device blocks, iteration graphs, FIR bank, transform tables and filter spectra stay in the context for
+    the next call (ctx.hpp: dc_pool, dc_graph, dc_bank, dc_plan, dc_spectra): a second call of the same geometry, a
+    call of another geometry or another bank in between and a guarded call (which uses none) must all give what a
     fresh context gives, bit for bit"""
     z = np.load(os.path.join(GOLD, "psf_sample.npz"))
     psf = pkg.psf_from_npz(z)
     cases = [dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 4, 0.8, 3.0, 0.5)),
              dict(nx=48, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5)),
-             dict(nx=12, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5))]   # guarded: nx < 16
+             dict(nx=12, ny=40, nt=128, d=1.0, cfg=pkg.DeconvCfg(8, 4, 0.25, 2.0, 0.5)),   # guarded: nx < 16
+             # the first case's cube and time axis under another bank: the cached FIR bank and filter spectra must go
+             dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 4, 0.6, 2.5, 0.5)),
+             dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 5, 0.8, 3.0, 0.5))]
 
     def run(eng, c):
         time, cube = _bar_target_cube(c["nx"], c["ny"], c["nt"])
@@ -272,7 +276,7 @@ def test_repeated_calls_reuse_and_release_device_blocks():
         fresh.append(run(eng, c))
         eng.close()
     eng = pkg.Engine(0)
-    for n, i in enumerate((0, 0, 1, 0, 2, 1, 1, 0)):
+    for n, i in enumerate((0, 0, 1, 0, 2, 1, 1, 0, 3, 0, 4, 3, 3)):
         st, out = run(eng, cases[i])
         assert st == fresh[i][0] and np.array_equal(out, fresh[i][1]), i
         if n == 5:

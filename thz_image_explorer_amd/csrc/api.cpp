@@ -51,6 +51,7 @@ void thz_destroy(thz_ctx *ctx)
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (auto &g : ctx->dc_graph) g.drop();
+    ctx->drop_dc_tables();
     for (auto &b : ctx->dc_pool) (void)hipFree(b.p);
     for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
@@ -70,6 +71,7 @@ int thz_release_scratch(thz_ctx *ctx)
     for (hipStream_t st : ctx->aux_streams)
         if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
     for (auto &g : ctx->dc_graph) g.drop();
+    ctx->drop_dc_tables();
     for (auto &b : ctx->dc_pool) (void)hipFree(b.p);
     ctx->dc_pool.clear();
     if (ctx->ws) (void)hipFree(ctx->ws);

@@ -56,6 +56,35 @@ struct thz_ctx {
         }
     };
     ChainGraph dc_graph[4];
+    // ... and what the call derives from the time axis and the configuration alone: the FIR bank (host, 0.24 ms),
+    // the transform tables of the padded length (0.08 ms) and the bands' filter spectra (0.15 ms), each recomputed
+    // only when what it depends on has changed
+    struct DcBank {
+        std::vector<float> time, filters, centers;
+        int n_filters = -1;
+        float start_freq = 0.0f, end_freq = 0.0f, win_width = 0.0f;
+        unsigned gen = 0;  // counts recomputations: the spectra remember which bank they belong to
+    } dc_bank;
+    struct DcPlan {
+        size_t M = 0;
+        PlanHost H;
+        c32 *d_tw = nullptr;
+        size_t o1 = 0, o2 = 0, o3 = 0;
+        bool f = false;
+    } dc_plan;
+    struct DcSpectra {
+        c32 *d_H = nullptr;
+        size_t M = 0;
+        unsigned bank_gen = 0;
+        int b0 = -1, b1 = -1;
+    } dc_spectra;
+    void drop_dc_tables()
+    {
+        if (dc_plan.d_tw) (void)hipFree(dc_plan.d_tw);
+        if (dc_spectra.d_H) (void)hipFree(dc_spectra.d_H);
+        dc_plan = DcPlan{};
+        dc_spectra = DcSpectra{};
+    }
     int timing = 0;  // 0 off, 1 immediate (host waits per call), 2 deferred (no host wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t stage_ns[THZ_STAGE_COUNT] = {0};

@@ -133,8 +133,18 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     std::vector<float> filters, centers;
     float w_min = 0.0f, w_max = 0.0f;
     if (!skip) {
-        filter_bank(nb, (double)cfg->start_freq, (double)cfg->end_freq, (double)cfg->win_width,
-                    ctx->time.data(), filters, centers);
+        // the bank depends on the time axis and four numbers of the configuration: kept in the context
+        thz_ctx::DcBank &K = ctx->dc_bank;
+        if (K.n_filters != nb || K.start_freq != cfg->start_freq || K.end_freq != cfg->end_freq
+            || K.win_width != cfg->win_width || K.time != ctx->time) {
+            filter_bank(nb, (double)cfg->start_freq, (double)cfg->end_freq, (double)cfg->win_width,
+                        ctx->time.data(), K.filters, K.centers);
+            K.time = ctx->time;
+            K.n_filters = nb; K.start_freq = cfg->start_freq; K.end_freq = cfg->end_freq; K.win_width = cfg->win_width;
+            ++K.gen;
+        }
+        filters = K.filters;
+        centers = K.centers;
         float wx_min = INFINITY, wx_max = -INFINITY, wy_min = INFINITY, wy_max = -INFINITY;
         for (int i = 0; i < nb; ++i) {
             const float wx = hybrid_eval(psf->wx_fit, centers[(size_t)i]);
@@ -183,45 +193,50 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // ---- transform plan for the padded length M
     size_t M = 1;
     while (M < nt + kDeconvTaps - 1) M <<= 1;
-    PlanHost H;
-    const c32 *d_f[3] = {nullptr, nullptr, nullptr};
-    if (M > 16384 || !build_plan(M, H, true))  // with the F core's tables where M has them (band energies)
-        return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
-    const size_t N = M / 2, nk = N + 1;
-    DevFree mem(ctx);
-    c32 *d_tw = nullptr, *d_spec = nullptr, *d_H = nullptr;
-    float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
-    RlBand *d_bands = nullptr;
-    {
+    // the tables of the padded length live in the context until M changes
+    thz_ctx::DcPlan &PL = ctx->dc_plan;
+    if (PL.M != M) {
+        if (PL.d_tw) (void)hipFree(PL.d_tw);
+        PL = thz_ctx::DcPlan{};
+        if (M > 16384 || !build_plan(M, PL.H, true))  // with the F core's tables where M has them (band energies)
+            return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
+        PlanHost &H = PL.H;
         std::vector<c32> pack(H.tw);
         pack.insert(pack.end(), H.tw_split.begin(), H.tw_split.end());
-        const bool f = H.family == kFamilyF && !H.f_t1.empty();
-        const size_t o1 = pack.size();
-        if (f) pack.insert(pack.end(), H.f_t1.begin(), H.f_t1.end());
-        const size_t o2 = pack.size();
-        if (f) pack.insert(pack.end(), H.f_t2.begin(), H.f_t2.end());
-        const size_t o3 = pack.size();
-        if (f) pack.insert(pack.end(), H.f_w2n.begin(), H.f_w2n.end());
-        HIP_TRY(ctx, mem.alloc(&d_tw, pack.size() * sizeof(c32)));
-        HIP_TRY(ctx, hipMemcpyAsync(d_tw, pack.data(), pack.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
+        PL.f = H.family == kFamilyF && !H.f_t1.empty();
+        PL.o1 = pack.size();
+        if (PL.f) pack.insert(pack.end(), H.f_t1.begin(), H.f_t1.end());
+        PL.o2 = pack.size();
+        if (PL.f) pack.insert(pack.end(), H.f_t2.begin(), H.f_t2.end());
+        PL.o3 = pack.size();
+        if (PL.f) pack.insert(pack.end(), H.f_w2n.begin(), H.f_w2n.end());
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&PL.d_tw), pack.size() * sizeof(c32)));
+        HIP_TRY(ctx, hipMemcpyAsync(PL.d_tw, pack.data(), pack.size() * sizeof(c32), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack goes out of scope
         H.f_t1.clear();  // offsets only from here on
         H.f_t2.clear();
         H.f_w2n.clear();
-        // the transform kernels of this call are the generic (LDS) ones; only the tables ride along
-        d_f[0] = f ? d_tw + o1 : nullptr;
-        d_f[1] = f ? d_tw + o2 : nullptr;
-        d_f[2] = f ? d_tw + o3 : nullptr;
+        PL.M = M;
     }
+    const PlanHost &H = PL.H;
+    const size_t N = M / 2, nk = N + 1;
+    DevFree mem(ctx);
+    c32 *d_tw = PL.d_tw, *d_spec = nullptr, *d_H = nullptr;
+    float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
+    RlBand *d_bands = nullptr;
+    // the transform kernels of this call are the generic (LDS) ones; only the F core's tables ride along
     PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
-    P.f_t1 = d_f[0];
-    P.f_t2 = d_f[1];
-    P.f_w2n = d_f[2];
+    P.f_t1 = PL.f ? d_tw + PL.o1 : nullptr;
+    P.f_t2 = PL.f ? d_tw + PL.o2 : nullptr;
+    P.f_w2n = PL.f ? d_tw + PL.o3 : nullptr;
     tick("plan, twiddles");
     // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double, for the bands of
     // this call (band-parallel multi-GPU: cfg->band_begin/band_end select a subset of the bank)
     const int nbs = b1 - b0;
-    {
+    thz_ctx::DcSpectra &SP = ctx->dc_spectra;
+    if (!SP.d_H || SP.M != M || SP.bank_gen != ctx->dc_bank.gen || SP.b0 != b0 || SP.b1 != b1) {
+        if (SP.d_H) (void)hipFree(SP.d_H);
+        SP = thz_ctx::DcSpectra{};
         std::vector<double> trig(2 * M);  // cos | sin of -2 pi m / M
         for (size_t m = 0; m < M; ++m) {
             const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)M;
@@ -232,14 +247,16 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         float *d_filters = nullptr;
         HIP_TRY(ctx, mem.alloc(&d_trig, trig.size() * sizeof(double)));
         HIP_TRY(ctx, mem.alloc(&d_filters, (size_t)nbs * kDeconvTaps * sizeof(float)));
-        HIP_TRY(ctx, mem.alloc(&d_H, (size_t)nbs * nk * sizeof(c32)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&SP.d_H), (size_t)nbs * nk * sizeof(c32)));
         HIP_TRY(ctx, hipMemcpyAsync(d_trig, trig.data(), trig.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_filters, filters.data() + (size_t)b0 * kDeconvTaps,
                                     (size_t)nbs * kDeconvTaps * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         launch_dc_filter_spectra(ctx->stream, d_filters, nbs, kDeconvTaps, d_trig, d_trig + M, (unsigned)M,
-                                 (unsigned)nk, d_H);
+                                 (unsigned)nk, SP.d_H);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // trig goes out of scope
+        SP.M = M; SP.bank_gen = ctx->dc_bank.gen; SP.b0 = b0; SP.b1 = b1;
     }
+    d_H = SP.d_H;
     centers = std::vector<float>(centers.begin() + b0, centers.begin() + b1);
     tick("filter spectra");
     // ---- per-band PSFs, iteration counts, workspace layout
