@@ -372,3 +372,46 @@ def test_session_recompute_from_each_chain_position(engine, shape):
         check(sess, oracle_chain(cube, time, cfg), nx, ny)
     finally:
         sess.close()
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 1001), (3, 5, 300), (3, 3, 512)])
+def test_session_and_pipeline_ex_on_the_generic_kernels(engine, shape):
+    """thz_set_kernel_family(1): every length on the G kernels.  A length that is not a power of two is then a
+    generic chirp-z plan, for which the fused entry point has no single kernel: thz_pipeline_ex (what every session
+    recompute goes through) must run it as forward + inverse launches, as thz_pipeline does — it used to fall
+    through to the power-of-two chain and read out of bounds."""
+    nx, ny, nt = shape
+    time, cube = synth.make_cube(nx, ny, nt)
+    npix, nf = nx * ny, nt // 2 + 1
+    chain_p, chain = synth.default_chain(time), synth.oracle_chain(time)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    e = engine
+    e.set_kernel_family(1)
+    try:
+        e.set_time_axis(time)
+        assert e.kernel_variant().startswith("g-")
+        bufs = [e.to_device(cube), e.to_device(chain_p["w_pre"]), e.to_device(chain_p["fd_mask"]), e.to_device(chain_p["w_post"]),
+                e.empty((npix, nf, 2)), e.empty((npix, nf)), e.empty((npix, nf)), e.empty((npix, nt)), e.empty((npix,)),
+                e.empty((2 * nf,))]
+        d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums = bufs
+        e.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums)
+        amp = d_amp.download((npix, nf), np.float32)
+        assert rel(d_fft.download((npix, nf, 2), np.float32), ref["fft"].reshape(npix, nf, 2), scale) < TOL
+        assert rel(amp, ref["amplitudes"].reshape(npix, nf), scale) < TOL
+        assert rel(d_out.download((npix, nt), np.float32), ref["data"].reshape(npix, nt)) < TOL
+        assert rel(d_img.download((npix,), np.float32), ref["img"].ravel()) < TOL
+        sa = amp.astype(np.float64).sum(0)
+        assert np.abs(d_sums.download((2 * nf,), np.float32)[:nf] - sa).max() <= 2e-6 * np.abs(sa).max()
+        for b in bufs:
+            b.free()
+        sess = pkg.Session(e, nx, ny, time)
+        try:
+            sess.upload(cube, subtract_bias=False)
+            cfg = pkg.chain_cfg_default(time)
+            sess.recompute(cfg)
+            check(sess, oracle_chain(cube, time, cfg), nx, ny)
+        finally:
+            sess.close()
+    finally:
+        e.set_kernel_family(0)

@@ -180,11 +180,22 @@ struct FPlan {
     static constexpr int WIN_SLOTS = (N >= 2048) ? 4 : 6;  // 160 KB LDS leaves room for 4 at nt = 4096
     static constexpr int EXTRA_ENTRIES = W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
     static_assert(R1 <= WG_ENTRIES && W2N_HEAD <= N && 256 % M1 == 0, "staged twiddle tables");
+    // k_f at nt = 4096 keeps the pass-1 twiddles in COMPACT form (round 3): only the rows k1 = 1, 2, 4, 8 of the
+    // lane's even column, T1c[r][lane] = W_N^(C1 lane 2^r) — 2 KiB instead of 16 — and builds the other rows as
+    // products (f_core_pass1<P, true>); row 0 of that table is also w2n[4 lane], so the staged head of the split
+    // twiddles goes too.  The 16 KiB this frees are the block accumulators of the pixel sums (FSums): the kernel
+    // with the sums keeps its eighth wave, the complex-multiplier builds get theirs back.
+    static constexpr bool T1_COMPACT = (N == 2048);
+    static constexpr int T1C_ROWS = (R1 == 16) ? 4 : 3;
+    static constexpr int KF_T1_ENTRIES = T1_COMPACT ? T1C_ROWS * kWave : T1_ENTRIES;
+    static constexpr int KF_W2N_HEAD = T1_COMPACT ? 0 : W2N_HEAD;
+    static constexpr int KF_EXTRA_ENTRIES = KF_W2N_HEAD + WG_ENTRIES + WIN_SLOTS * WIN_BLK / 2;
+    static_assert(!T1_COMPACT || (C1 == 2 && N == 2048), "compact pass-1 twiddles: row 0 must be w2n[4 lane]");
     // kCfgSums: + the block's accumulators, tickets and scratch of FSums behind the wave buffers
     static constexpr int SUM_ENTRIES = (2 * N + 16 + 32) / 2;  // in cx; = FSums::kAreaFloats / 2
     static constexpr size_t lds_bytes(int waves, int cfg = 0)
     {
-        return (size_t)(T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + EXTRA_ENTRIES + waves * WAVE_ENTRIES
+        return (size_t)(KF_T1_ENTRIES + T2_ENTRIES + mask_entries(cfg) + KF_EXTRA_ENTRIES + waves * WAVE_ENTRIES
                         + ((cfg & kCfgSums) ? SUM_ENTRIES : 0)) * sizeof(cx);
     }
 
@@ -256,7 +267,27 @@ struct FAddr {
 // In:  r[c][j1] = z[(N/R1) j1 + C1*lane + c]   (forward data, or swapped data for
 //      the inverse).  Out: natural-order spectrum Z[0..N] in `buf` (Z[N] = Z[0]).
 // t1/t2 point to the block's LDS copies of the tables.  Ends with wave_sync().
-template <class P>
+// exp(-2 pi i e / d) for the small angles of the compact twiddle form (|angle| < 0.1): Taylor series in double
+constexpr double f_small_cos(double x)
+{
+    const double z = x * x;
+    return 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0))));
+}
+constexpr double f_small_sin(double x)
+{
+    const double z = x * x;
+    return x * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0)))));
+}
+constexpr double kFTwoPi = 6.28318530717958647692528676655900577;
+constexpr float f_unit_re(int e, int d) { return (float)f_small_cos(kFTwoPi * e / d); }
+constexpr float f_unit_im(int e, int d) { return (float)-f_small_sin(kFTwoPi * e / d); }
+
+// COMPACT (k_f at nt = 4096, FPlan::T1_COMPACT): t1 points to T1c[r][lane] = W_N^(2 lane 2^r), r = 0..3, and the
+// twiddle of (m, k1) = (2 lane + b, k1) is built as
+//     W_N^(2 lane k1) = product of the rows of k1's bits  (at most three multiplies deep: 7 = (1 2) 4, 15 = 7 8)
+//     W_N^((2 lane + 1) k1) = that  x  W_N^k1              (a compile-time constant)
+// — 26 complex multiplies per pass where the full table costs 15 16-byte LDS reads, and 14 KiB of LDS less.
+template <class P, bool COMPACT = false>
 __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, const cx *t1,
                                              const FAddr<P> &ad, int lane)
 {
@@ -266,6 +297,31 @@ __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, con
     for (int c = 0; c < C1; ++c) {
         dftR<R1>(r[c]);
         THZ_SCHED_FENCE();
+    }
+    if constexpr (COMPACT) {
+        static_assert(C1 == 2 && R1 == 16, "compact pass-1 twiddles are written for the 16 x 16 x 8 plan");
+        const cx *tc = t1 + launder_v(lane);
+        cx tw[R1];
+        tw[1] = tc[0];
+        tw[2] = tc[kWave];
+        tw[4] = tc[2 * kWave];
+        tw[8] = tc[3 * kWave];
+        st2(buf + ad.w1[0], r[0][0], r[1][0]);
+#pragma unroll
+        for (int k1 = 1; k1 < R1; ++k1) {
+            if (k1 == 3) tw[3] = cx_mul(tw[1], tw[2]);
+            if (k1 == 5) tw[5] = cx_mul(tw[1], tw[4]);
+            if (k1 == 6) tw[6] = cx_mul(tw[2], tw[4]);
+            if (k1 == 7) tw[7] = cx_mul(tw[3], tw[4]);
+            if (k1 > 8) tw[k1] = cx_mul(tw[k1 - 8], tw[8]);
+            const cx odd = cx{f_unit_re(k1, P::N), f_unit_im(k1, P::N)};  // W_N^k1
+            const cx v0 = cx_mul(r[0][k1], tw[k1]);
+            const cx v1 = cx_mul(r[1][k1], cx_mul(odd, tw[k1]));
+            st2(buf + ad.w1[k1 & 3] + k1 * M1, v0, v1);  // = e1(k1, 2*lane + {0,1})
+            if ((k1 & 3) == 3) THZ_SCHED_FENCE();
+        }
+        wave_sync();
+        return;
     }
     const cx *t1l = t1 + launder_v(C1 * lane);
 #pragma unroll
@@ -361,6 +417,20 @@ __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr
 // consumer's op_sel/neg modifiers).  The products are the same real products; only which of the two
 // is rounded before the fused add changes.
 __device__ __forceinline__ cx f_stage_w2n(cx w) { return cx{0.5f * w.y, -0.5f * w.x}; }
+
+// Compact form (FPlan::T1_COMPACT): no staged head of the split twiddles; w2n[4 l] = W_N^(2 l) is row 0 of the
+// compact pass-1 table, and the staged value of w2n[4 l + e], e = 0..3, is that times the constant
+// -(i/2) exp(-i pi e / N).
+template <int N, int E>
+__device__ __forceinline__ cx f_w2n_from_row0(cx t)
+{
+    if constexpr (E == 0) return f_stage_w2n(t);
+    else {
+        // -(i/2) (x + i y) = y/2 - i x/2 with (x, y) = exp(-2 pi i E / (2 N))
+        constexpr float kx = 0.5f * f_unit_im(E, 2 * N), ky = -0.5f * f_unit_re(E, 2 * N);
+        return cx_mul(cx{kx, ky}, t);
+    }
+}
 
 // Written on p = a + b, m = a - b (s = {p.x, m.y}, d = {m.x, p.y}): the conjugate never exists as a
 // value, the multiply takes its splats straight from p and m, and X[N-k] comes out unconjugated —
@@ -617,7 +687,8 @@ struct FSums {
     }
 };
 
-template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false>
+// WC: w2n_s is row 0 of the compact pass-1 table instead of the staged head of the split twiddles
+template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false, bool WC = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane, FSums<P> *sums = nullptr)
@@ -629,8 +700,16 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
     const float kPi = 3.14159274101257324219f, kTwoPi = 2.0f * kPi;
     constexpr bool want_phase = AMP_PHASE;
     cx wl[4];
+    if constexpr (WC) {
+        const cx t = w2n_s[lane];
+        wl[0] = f_w2n_from_row0<N, 0>(t);
+        wl[1] = f_w2n_from_row0<N, 1>(t);
+        wl[2] = f_w2n_from_row0<N, 2>(t);
+        wl[3] = f_w2n_from_row0<N, 3>(t);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) wl[c] = w2n_s[4 * lane + c];
+        for (int c = 0; c < 4; ++c) wl[c] = w2n_s[4 * lane + c];
+    }
     float carry = 0.0f;       // sum of adjusted differences of all previous groups
     float prev_tail = 0.0f;   // raw phase of the last bin of the previous group
     float first = 0.0f;       // raw phase of bin 0
@@ -780,15 +859,27 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 // that the phases of the whole spectrum could be taken).
 // CMASK (with MASKED): the multiplier is complex, mask points to nf cx; X[0] H[0] and X[N] H[N] lose their
 // imaginary parts after the multiply.
-template <class P, bool MASKED, bool CMASK = false>
+template <class P, bool MASKED, bool CMASK = false, bool WC = false>
 __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, const cx *wg_s,
                                                 const float *__restrict__ mask, int lane,
                                                 cx (&r)[P::C1][P::R1])
 {
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
     cx wlc[C1];  // conj of the lane's staged twiddles: the product below is conj(w2) directly
+    if constexpr (WC) {
+        // w2n[2 lane + c] = w2n[4 (lane >> 1)] x exp(-i pi (2 (lane & 1) + c) / N): row 0 of the compact table at
+        // lane >> 1, times one of two constants
+        static_assert(C1 == 2, "compact twiddles: 16 x 16 x 8 plan");
+        const cx t = w2n_s[lane >> 1];
+        const bool odd = (lane & 1) != 0;
+        const cx e0 = f_w2n_from_row0<N, 0>(t), e1 = f_w2n_from_row0<N, 1>(t);
+        const cx e2 = f_w2n_from_row0<N, 2>(t), e3 = f_w2n_from_row0<N, 3>(t);
+        wlc[0] = cx_conj(odd ? e2 : e0);
+        wlc[1] = cx_conj(odd ? e3 : e1);
+    } else {
 #pragma unroll
-    for (int c = 0; c < C1; ++c) wlc[c] = cx_conj(w2n_s[C1 * lane + c]);
+        for (int c = 0; c < C1; ++c) wlc[c] = cx_conj(w2n_s[C1 * lane + c]);
+    }
     // n = M1 j1 + C1 lane + c and its mirror N - n; M1 is a multiple of 32*4 only for
     // C1 = 2 (M1 = 128), so (n >> 5) & 3 is lane-constant there; for C1 = 1 (M1 = 64)
     // it alternates with j1 & 1 -> two base variants cover both plans.
@@ -955,16 +1046,24 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     const int lane = lane_id();
     const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
+    constexpr bool TC = P::T1_COMPACT;  // compact pass-1 twiddles (FPlan): t1 = T1c[r][lane], no staged w2n head
     cx *t1 = reinterpret_cast<cx *>(lds);
-    cx *t2 = t1 + P::T1_ENTRIES;
+    cx *t2 = t1 + P::KF_T1_ENTRIES;
     float *mask_s = reinterpret_cast<float *>(t2 + P::T2_ENTRIES);
-    cx *w2n_s = t2 + P::T2_ENTRIES + ME;
-    cx *wg_s = w2n_s + P::W2N_HEAD;
+    cx *w2n_s = TC ? t1 : t2 + P::T2_ENTRIES + ME;  // TC: row 0 of T1c is w2n[4 lane]
+    cx *wg_s = t2 + P::T2_ENTRIES + ME + P::KF_W2N_HEAD;
     float *win_s = reinterpret_cast<float *>(wg_s + P::WG_ENTRIES);
-    cx *buf = t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
-    for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
+    cx *buf = t2 + P::T2_ENTRIES + ME + P::KF_EXTRA_ENTRIES + (size_t)wib * P::WAVE_ENTRIES;
+    if constexpr (!TC) {
+        for (int i = (int)threadIdx.x; i < P::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
+    }
     if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[P::M1 * (int)threadIdx.x];
-    for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    if constexpr (TC) {
+        for (int i = (int)threadIdx.x; i < P::KF_T1_ENTRIES; i += (int)blockDim.x)
+            t1[i] = T.t1[(1 << (i / kWave)) * P::M1 + C1 * (i % kWave)];  // row 2^r, column C1 lane
+    } else {
+        for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    }
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
     if constexpr (CMASK) {
         cx *cm = reinterpret_cast<cx *>(mask_s);
@@ -976,7 +1075,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     } else if (MODE != kInv) {
         for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) mask_s[i] = A.mask[i];
     }
-    float *sum_area = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::EXTRA_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES);
+    float *sum_area = reinterpret_cast<float *>(t2 + P::T2_ENTRIES + ME + P::KF_EXTRA_ENTRIES + (size_t)wpb * P::WAVE_ENTRIES);
     if constexpr (SUMS) {
         static_assert(FSums<P>::kAreaFloats == 2 * P::SUM_ENTRIES, "LDS size of the sums area");
         FSums<P>::clear(sum_area, (int)threadIdx.x, (int)blockDim.x);
@@ -1098,7 +1197,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
             // The next trace of this wave is prefetched into registers right
             // after pass 1 (of the inverse transform in the fused chain): `r` is dead
             // by then, so the 16 KiB of prefetch registers never coexist with it.
-            f_core_pass1<P>(r, buf, t1, ad, lane);
+            f_core_pass1<P, TC>(r, buf, t1, ad, lane);
             if (MODE == kFwd && p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
             f_core_pass23<P>(buf, t2, ad, lane);
             if (MODE == kFwd) f_land_prefetch<P>(raw);
@@ -1121,10 +1220,10 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
                 if (lane == 0) buf[N] = cx{x_nyq_next, 0.0f};
             }
             wave_sync();
-            f_inverse_input<P, false>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), nullptr,
-                                      lane, r);
+            f_inverse_input<P, false, false, TC>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
+                                                 nullptr, lane, r);
             wave_sync();
-            f_core_pass1<P>(r, buf, t1, ad, lane);
+            f_core_pass1<P, TC>(r, buf, t1, ad, lane);
             if (p + stride < A.npix) {
                 f_load_spec<P>(A.fft_in + (p + stride) * nf, lane, raw);
                 x_nyq_next = A.fft_in[(p + stride) * nf + N].x;
@@ -1135,14 +1234,14 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // spectrum stores (+ the inverse transform of the fused chain)
     auto part_b = [&]() {
         if constexpr (MODE != kInv) {
-            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS>(buf, launder_uniform((const cx *)w2n_s),
-                                                           launder_uniform((const cx *)wg_s), mask_l, p, A, lane, &sums);
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS, TC>(buf, launder_uniform((const cx *)w2n_s),
+                                                               launder_uniform((const cx *)wg_s), mask_l, p, A, lane, &sums);
             if constexpr (MODE == kPipe) {
                 cx r[C1][R1];
-                f_inverse_input<P, true, CMASK>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s), mask_l,
-                                                lane, r);
+                f_inverse_input<P, true, CMASK, TC>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
+                                                    mask_l, lane, r);
                 wave_sync();  // every lane has read Z before the core overwrites buf
-                f_core_pass1<P>(r, buf, t1, ad, lane);
+                f_core_pass1<P, TC>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);
                 f_core_pass23<P>(buf, t2, ad, lane);
             }

@@ -2201,6 +2201,13 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         dispatch_fb<kPipe>(st, P, A);
         return;
     }
+    if (P.mode != kModePow2 && fft_out) {
+        // generic chirp-z plan (thz_set_kernel_family(1) with a length that is not a power of two): k_pipeline below
+        // is the power-of-two chain only, so the chain is a forward and an inverse launch around the stored spectrum
+        launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
