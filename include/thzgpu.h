@@ -437,6 +437,11 @@ typedef struct thz_chain_cfg {
      * lives on the (nx / s, ny / s) grid with dx * s, dy * s (thz_session_grid);
      * s <= 1, or a side shorter than s, leaves the grid alone. */
     int32_t scale_factor;
+    /* ConfigContainer.avg_in_fourier_space (config.rs:171-213; default false): the ifft stage then also
+     * rebuilds a time trace from the pixel-mean amplitudes and phases — avg_data = C2R(from_polar(avg_signal_fft,
+     * avg_phase_fft)) / nt (math_tools.rs:442-470), needs want_means — and every region of interest's roi_data
+     * from its own mean amplitudes and phases (:496-529) instead of from the traces (:477-483). */
+    int32_t avg_in_fourier_space;
 } thz_chain_cfg;
 
 /* Defaults of the reference after OpenFile + reset(): every filter active, bounds
@@ -486,6 +491,34 @@ int thz_session_recompute_from(thz_session *s, const thz_chain_cfg *cfg, int sta
  * filter K13, thz_host_wiener_filter.  Both ride in the fused launch.  A later recompute whose spectra
  * have another length (tilted cube) returns THZ_ERR_INVALID. */
 int thz_session_set_fd_filters(thz_session *s, const float *real_mask, const float *cmask, size_t nf);
+/* Regions of interest — ScannedImageFilterData::rois (data_container.rs:109-162), edited by ConfigCommand::AddROI /
+ * UpdateROI / DeleteROI (data_thread.rs:922-1000).  Replaces the session's whole set (n_rois = 0 removes it).
+ * poly_xy: the polygons' vertices one after the other, (x, y) u64 pairs exactly as the reference keeps them
+ * (f64 -> usize by truncation, :936-939: pixels of the RAW grid — average_polygon_roi divides them by the
+ * scale factor itself, math_tools.rs:606-609); n_vertices[i] of them belong to region i.  From the next
+ * recompute on, the ifft stage's per-region means (math_tools.rs:473-543) and the plot copy-out's
+ * (data_thread.rs:1442-1482) are taken with every recompute and read with thz_session_roi. */
+int thz_session_set_rois(thz_session *s, size_t n_rois, const size_t *n_vertices, const uint64_t *poly_xy);
+size_t thz_session_roi_count(const thz_session *s);
+/* One region's vectors after a recompute; host pointers, any may be NULL.  The masks follow the reference's
+ * integer rule bit for bit (thz_roi_mask); the sampled pixel of mask position (x, y) is [shape0 - y - 1, x]
+ * (math_tools.rs:647).  With want_means == 2 the pixels are added in the reference's order — y outer, x inner,
+ * sequential f32 — and divided by the count: the means are those of the resident arrays bit for bit; otherwise
+ * (0, 1) the sums are taken in parallel (<= 2e-6 of the largest value away). */
+typedef struct thz_roi_out {
+    float *signal_fft; /* nf_out  roi_signal_fft: mean amplitudes (:485, data_thread.rs:1453-1461) */
+    float *phase_fft;  /* nf_out  roi_phase_fft: mean unwrapped phases (:486, :1464-1472) */
+    float *signal;     /* nt_out  data.roi_signal of the plot copy-out: mean of the chain's FINAL traces
+                                   (data_thread.rs:1445-1451) or, with avg_in_fourier_space, roi_data (:1476-1482) */
+    float *roi_data;   /* nt_out  the ifft stage's roi_data: mean of the stage's input traces — the fft stage's
+                                   windowed `data` — (math_tools.rs:477-483) or, with avg_in_fourier_space,
+                                   C2R(from_polar(signal_fft, phase_fft), Im X[0] := 0) / nt (:496-529; where realfft
+                                   would refuse the spectrum — Im of the last bin of an even length != 0 — the
+                                   reference's fallback: the mean of the traces, :530-538) */
+    uint32_t *count;   /* pixels inside the polygon */
+} thz_roi_out;
+int thz_session_roi(thz_session *s, size_t roi, const thz_roi_out *out);
+
 /* Grid of the last recompute's outputs (the raw grid until then): every buffer
  * except THZ_BUF_RAW has nx * ny pixels of this grid.  Any pointer may be NULL. */
 int thz_session_grid(const thz_session *s, size_t *nx, size_t *ny, float *dx, float *dy);
@@ -589,6 +622,13 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
  * iterations on whichever GPU owns it, so two GPUs shorten the call by little — the split is correct, not fast. */
 int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, const thz_deconv_cfg *cfg,
                                  volatile const int *abort_flag, float *progress);
+/* Regions of interest over the whole (nx, ny) grid (thz_session_set_rois): every slab sums its rows of the
+ * whole grid's mask — the sampled row index shape0 - y - 1 (math_tools.rs:647) runs along the sharded axis —,
+ * the recompute's C2 all-reduces the regions' sums with the pixel sums, and every member divides by the grid's
+ * pixel count.  thz_group_session_roi reads local member 0's copy (identical on all).  Collective like the
+ * recompute itself: every rank sets the same regions. */
+int thz_group_session_set_rois(thz_group_session *gs, size_t n_rois, const size_t *n_vertices, const uint64_t *poly_xy);
+int thz_group_session_roi(thz_group_session *gs, size_t roi, const thz_roi_out *out);
 /* gathered results on rank 0's device after a recompute: THZ_BUF_IMG (nx, ny) always; THZ_BUF_DATA with
  * THZ_GATHER_TIME / ALL; THZ_BUF_FFT / AMPLITUDES / PHASES with ALL; THZ_BUF_AVG_* (on every member these
  * are also in its slab session).  NULL when absent or when this process does not drive rank 0. */
@@ -605,7 +645,8 @@ typedef struct thz_plot_out {
     float *filtered_signal;     /* nt_out  final trace, filter_data.last()              :1384-1396 */
     float *filtered_signal_fft; /* nf_out  band-passed amplitudes                       :1398-1408 */
     float *filtered_phase_fft;  /* nf_out                                               :1409-1419 */
-    float *avg_signal;          /* nt_out  pixel mean of the final cube                 :1422-1430 */
+    float *avg_signal;          /* nt_out  pixel mean of the final cube, or — avg_in_fourier_space of the last
+                                            recompute — the ifft stage's avg_data            :1422-1432 */
     float *avg_signal_fft;      /* nf_out  pixel mean of the amplitudes (needs want_means) :1434   */
     float *avg_phase_fft;       /* nf_out                                                  :1435   */
 } thz_plot_out;

@@ -89,12 +89,17 @@ class ChainCfg(C.Structure):
                 ("td_before_width", C.c_double), ("fft_window", WindowCfg),
                 ("fd_active", C.c_int32), ("fd_low", C.c_double), ("fd_high", C.c_double), ("fd_width", C.c_double),
                 ("td_after_active", C.c_int32), ("td_after_low", C.c_double), ("td_after_high", C.c_double),
-                ("td_after_width", C.c_double), ("want_means", C.c_int32), ("scale_factor", C.c_int32)]
+                ("td_after_width", C.c_double), ("want_means", C.c_int32), ("scale_factor", C.c_int32),
+                ("avg_in_fourier_space", C.c_int32)]
 
 
 class PipelineIo(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("d_raw", "d_pre_win", "d_fd_mask", "d_fd_cmask", "d_post_win", "d_fft", "d_amp",
                                           "d_phase", "d_data_out", "d_img", "d_sums")]
+
+
+class RoiOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("signal_fft", "phase_fft", "signal", "roi_data", "count")]
 
 
 class PlotOut(C.Structure):
@@ -174,6 +179,9 @@ SYMBOLS = [
     ("thz_session_recompute", C.c_int, [_P, C.POINTER(ChainCfg)]),
     ("thz_session_recompute_from", C.c_int, [_P, C.POINTER(ChainCfg), C.c_int]),
     ("thz_session_set_fd_filters", C.c_int, [_P, _P, _P, _SZ]),
+    ("thz_session_set_rois", C.c_int, [_P, _SZ, _P, _P]),
+    ("thz_session_roi_count", _SZ, [_P]),
+    ("thz_session_roi", C.c_int, [_P, _SZ, C.POINTER(RoiOut)]),
     ("thz_session_grid", C.c_int, [_P, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("thz_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_session_nt_out", _SZ, [_P]),
@@ -202,6 +210,8 @@ SYMBOLS = [
     ("thz_group_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_group_session_result", _P, [_P, C.c_int]),
     ("thz_group_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
+    ("thz_group_session_set_rois", C.c_int, [_P, _SZ, _P, _P]),
+    ("thz_group_session_roi", C.c_int, [_P, _SZ, C.POINTER(RoiOut)]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
     ("thz_session_voxels", C.c_int, [_P, C.POINTER(VoxelCfg), C.c_uint64, C.c_int, _SZ, _SZ, _SZ, _P, C.c_uint64,
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_float), _P]),
@@ -402,6 +412,24 @@ def chain_cfg_default(time) -> ChainCfg:
     return cfg
 
 
+def _pack_rois(polys):
+    """list of (n, 2) vertex arrays -> (n_rois, size_t counts, u64 vertices) for thz_*_set_rois"""
+    polys = [np.ascontiguousarray(p, np.uint64).reshape(-1, 2) for p in polys]
+    counts = (_SZ * max(len(polys), 1))(*[p.shape[0] for p in polys])
+    flat = np.concatenate(polys).ravel() if polys else np.zeros(0, np.uint64)
+    return len(polys), counts, np.ascontiguousarray(flat, np.uint64)
+
+
+def _roi_out(nt_out, want):
+    nf = nt_out // 2 + 1
+    sizes = dict(signal_fft=nf, phase_fft=nf, signal=nt_out, roi_data=nt_out)
+    want = list(sizes) if want is None else want
+    res = {k: np.empty(sizes[k], np.float32) for k in want}
+    cnt = C.c_uint32()
+    ro = RoiOut(count=C.addressof(cnt), **{k: v.ctypes.data for k, v in res.items()})
+    return res, cnt, ro
+
+
 class Session:
     """thz_session: resident cube + whole-chain recompute"""
 
@@ -435,6 +463,18 @@ class Session:
         nf = r.size if r is not None else (c.size // 2 if c is not None else 0)
         self.eng._check(self.eng.lib.thz_session_set_fd_filters(self.h, r.ctypes.data if r is not None else None,
                                                                 c.ctypes.data if c is not None else None, nf))
+
+    def set_rois(self, polys):
+        """regions of interest: list of (n, 2) integer vertex arrays (x, y) in raw-grid pixels; [] removes them"""
+        n, counts, flat = _pack_rois(polys)
+        self.eng._check(self.eng.lib.thz_session_set_rois(self.h, n, counts, flat.ctypes.data if flat.size else None))
+
+    def roi(self, index, want=None):
+        """per-region vectors of the last recompute -> dict (+ 'count')"""
+        res, cnt, ro = _roi_out(self.nt_out, want)
+        self.eng._check(self.eng.lib.thz_session_roi(self.h, index, C.byref(ro)))
+        res["count"] = cnt.value
+        return res
 
     def deconvolve(self, psf, cfg, abort=None, progress=None):
         """the chain's Deconvolution stage on the last recompute's output -> status (0 applied, 1 skipped)"""
@@ -604,6 +644,17 @@ class GroupSession:
 
     def recompute(self, cfg: ChainCfg, start_stage=1, gather=GATHER_SMALL):
         self.g._check(self.g.lib.thz_group_session_recompute(self.h, C.byref(cfg), int(start_stage), int(gather)))
+
+    def set_rois(self, polys):
+        """regions of interest over the whole grid (every rank sets the same ones)"""
+        n, counts, flat = _pack_rois(polys)
+        self.g._check(self.g.lib.thz_group_session_set_rois(self.h, n, counts, flat.ctypes.data if flat.size else None))
+
+    def roi(self, index, want=None, nt_out=None):
+        res, cnt, ro = _roi_out(self.nt if nt_out is None else nt_out, want)
+        self.g._check(self.g.lib.thz_group_session_roi(self.h, index, C.byref(ro)))
+        res["count"] = cnt.value
+        return res
 
     def deconvolve(self, psf, cfg, abort=None, progress=None):
         """band-parallel Deconvolution stage over the group -> status (0 applied, 1 skipped)"""

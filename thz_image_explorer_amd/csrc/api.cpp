@@ -534,10 +534,19 @@ int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float 
     if (int rc = use_device(ctx)) return rc;
     if (!d_arr || !d_out || npix == 0 || len == 0 || (ncomp != 1 && ncomp != 2))
         return fail(ctx, THZ_ERR_INVALID, "thz_pixel_sum: bad argument");
-    const size_t L = len * (size_t)ncomp;
-    StageTimer t(ctx, THZ_STAGE_MEAN);
+    return pixel_sum_rows(ctx, d_arr, nullptr, npix, len * (size_t)ncomp, d_out);
+}
+
+}  // extern "C"
+
+// Σ over the rows list[0 .. npix) of d_arr (list null: rows 0 .. npix - 1), rows of L floats; order-free (parallel)
+// sums — the pixel sums behind the fast means and, with a list, a region of interest's (session_roi.cpp)
+int pixel_sum_rows(thz_ctx *ctx, const float *d_arr, const uint32_t *d_list, size_t npix, size_t L, float *d_out)
+{
+    StageTimer t(ctx, d_list ? THZ_STAGE_ROI : THZ_STAGE_MEAN);
     if (npix < 64) {
-        launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
+        if (d_list) launch_gather_sum(ctx->stream, d_arr, L, d_list, (uint32_t)npix, 0.0f, d_out);
+        else launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
         return check_launch(ctx);
     }
     // two-level: row groups x column tiles with 4 rows of loads in flight per
@@ -546,9 +555,10 @@ int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float 
     if (int rc = ensure_ws(ctx, (max_groups + mid_groups) * L * sizeof(float))) return rc;
     float *part = reinterpret_cast<float *>(ctx->ws);
     float *part2 = part + max_groups * L;
-    size_t groups = launch_colsum_partial(ctx->stream, d_arr, npix, L, part, max_groups);
+    size_t groups = launch_colsum_partial(ctx->stream, d_arr, npix, L, part, max_groups, d_list);
     if (groups == 0) {  // very long rows: plain strided sum
-        launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
+        if (d_list) launch_gather_sum(ctx->stream, d_arr, L, d_list, (uint32_t)npix, 0.0f, d_out);
+        else launch_sum_axis0(ctx->stream, d_arr, npix, L, 0.0f, d_out);
         return check_launch(ctx);
     }
     // the last level is one thread per column walking the partial rows one by one:
@@ -561,6 +571,8 @@ int thz_pixel_sum(thz_ctx *ctx, size_t npix, size_t len, int ncomp, const float 
     launch_sum_axis0(ctx->stream, src, groups, L, 0.0f, d_out);
     return check_launch(ctx);
 }
+
+extern "C" {
 
 int thz_roi_mask(thz_ctx *ctx, const uint64_t *poly_xy, size_t n_vertices, uint64_t scaling,
                  size_t shape0, size_t shape1, uint8_t *d_mask)

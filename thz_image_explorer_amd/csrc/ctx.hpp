@@ -189,3 +189,6 @@ inline int need_plan(thz_ctx *ctx)
 }  // namespace thz_api
 using namespace thz_api;
 
+// api.cpp: order-free column sums over all rows (d_list null) or over the listed rows of d_arr
+int pixel_sum_rows(thz_ctx *ctx, const float *d_arr, const uint32_t *d_list, size_t npix, size_t L, float *d_out);
+

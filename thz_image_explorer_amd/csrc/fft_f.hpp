@@ -647,6 +647,8 @@ struct FSums {
         unsigned *tick = reinterpret_cast<unsigned *>(area + 2 * N) + g;
         const unsigned mine = round * (unsigned)wpb + (unsigned)wib;
         unsigned spins = 0u;
+        float *sa = area + 256 * g + 4 * lane, *sp = sa + N;
+#ifdef THZ_EMU
         while (lds_flag_load(tick) != mine) {
             spin_pause();
             if (++spins > (1u << 24)) {  // ~ seconds: something else is badly wrong; do not hang the GPU over it
@@ -654,12 +656,41 @@ struct FSums {
                 break;
             }
         }
-        float *sa = area + 256 * g + 4 * lane, *sp = sa + N;
         const float4 va = *reinterpret_cast<const float4 *>(sa), vp = *reinterpret_cast<const float4 *>(sp);
         *reinterpret_cast<float4 *>(sa) = make_float4(va.x + a[0], va.y + a[1], va.z + a[2], va.w + a[3]);
         *reinterpret_cast<float4 *>(sp) = make_float4(vp.x + y[0], vp.y + y[1], vp.z + y[2], vp.w + y[3]);
         wave_sync();  // every lane's update is issued before lane 0 hands the ticket on
         if (lane == 0) lds_flag_store(tick, mine + 1u);
+#else
+        // One LDS round trip per visit instead of three (round 3).  The CU's LDS executes a wave's DS instructions
+        // in issue order (what wave_sync() relies on everywhere in this file), so (a) the accumulators can be read
+        // right behind the ticket, in the same wait: if the ticket read shows this wave's number, the previous
+        // owner's updates — issued before its ticket write — were executed before it, and the reads behind it see
+        // them; otherwise the values are dropped and read again; (b) the hand-over needs no wait for the updates to
+        // land: the ticket write is issued behind them and executes behind them.  Only the compiler has to keep the
+        // order, hence the barriers.
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v va, vp;
+        for (;;) {
+            const unsigned t = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            va = *reinterpret_cast<const f4v *>(sa);  // (plain loads: a volatile access through the generic pointer
+            vp = *reinterpret_cast<const f4v *>(sp);  //  loses the LDS address space and becomes a flat load)
+            asm volatile("" ::: "memory");
+            if (THZ_UNIFORM((int)t) == (int)mine) break;
+            spin_pause();
+            if (++spins > (1u << 24)) {  // ~ seconds: something else is badly wrong; do not hang the GPU over it
+                give_up = 1u;
+                break;
+            }
+        }
+        *reinterpret_cast<float4 *>(sa) = make_float4(va.x + a[0], va.y + a[1], va.z + a[2], va.w + a[3]);
+        *reinterpret_cast<float4 *>(sp) = make_float4(vp.x + y[0], vp.y + y[1], vp.z + y[2], vp.w + y[3]);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(tick, mine + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+#endif
     }
     // after the trace loop (and a block barrier): bin N across the waves, then the block's row of sum_partial
     __device__ __forceinline__ void finish(float *row, int nf, int lane)
@@ -688,7 +719,10 @@ struct FSums {
 };
 
 // WC: w2n_s is row 0 of the compact pass-1 table instead of the staged head of the split twiddles
-template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false, bool WC = false>
+// STORE_FFT = false (fused chain): the masked spectrum is stored by f_inverse_input, which forms the same products
+// X m (X H) anyway and holds them two adjacent bins per lane — sixteen 1 KiB stores in one short burst instead of two
+// per group spread over the whole epilogue; only the Nyquist bin is still stored here.
+template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false, bool WC = false, bool STORE_FFT = true>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane, FSums<P> *sums = nullptr)
@@ -765,10 +799,12 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(Y[c].x, Y[c].x, Y[c].y * Y[c].y));
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
             }
-            if (g == 0 && lane == 0) Y[0].y = 0.0f;  // bin 0
-            float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
-            store_f4(f, Y[0].x, Y[0].y, Y[1].x, Y[1].y);
-            store_f4(f + 4, Y[2].x, Y[2].y, Y[3].x, Y[3].y);
+            if constexpr (STORE_FFT) {
+                if (g == 0 && lane == 0) Y[0].y = 0.0f;  // bin 0
+                float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
+                store_f4(f, Y[0].x, Y[0].y, Y[1].x, Y[1].y);
+                store_f4(f + 4, Y[2].x, Y[2].y, Y[3].x, Y[3].y);
+            }
         } else {
             float m[4];
             {
@@ -780,9 +816,11 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
                 for (int c = 0; c < 4; ++c) a[c] = fast_sqrt(fmaf(X[c].x, X[c].x, X[c].y * X[c].y)) * m[c];
                 store_f4(A.amp_out + p * nf + k0, a[0], a[1], a[2], a[3]);
             }
-            float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
-            store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
-            store_f4(f + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+            if constexpr (STORE_FFT) {
+                float *f = reinterpret_cast<float *>(A.fft_out + p * nf + k0);
+                store_f4(f, X[0].x * m[0], X[0].y * m[0], X[1].x * m[1], X[1].y * m[1]);
+                store_f4(f + 4, X[2].x * m[2], X[2].y * m[2], X[3].x * m[3], X[3].y * m[3]);
+            }
         }
         if constexpr (want_phase) {
             float ph[4];
@@ -859,11 +897,17 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 // that the phases of the whole spectrum could be taken).
 // CMASK (with MASKED): the multiplier is complex, mask points to nf cx; X[0] H[0] and X[N] H[N] lose their
 // imaginary parts after the multiply.
-template <class P, bool MASKED, bool CMASK = false, bool WC = false>
+// STORE (fused chain, with MASKED): fft_row = the trace's row of the spectrum output; the masked bins n < N — the
+// values the inverse transform is built from, to the bit — are stored from here (bin N: the spectrum epilogue).
+template <class P, bool MASKED, bool CMASK = false, bool WC = false, bool STORE = false>
 __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, const cx *wg_s,
                                                 const float *__restrict__ mask, int lane,
-                                                cx (&r)[P::C1][P::R1])
+                                                cx (&r)[P::C1][P::R1], cx *fft_row = nullptr)
 {
+    // the masked values are stored AND consumed: no product of this function may be fused into the split's adds
+    // (the stand-alone inverse must land on the same samples from the stored spectrum, bit for bit)
+#pragma clang fp contract(off)
+    static_assert(!STORE || MASKED, "the stored spectrum is the masked one");
     constexpr int N = P::N, R1 = P::R1, C1 = P::C1, M1 = P::M1;
     cx wlc[C1];  // conj of the lane's staged twiddles: the product below is conj(w2) directly
     if constexpr (WC) {
@@ -894,9 +938,11 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
     constexpr int TOP = M1 * (R1 - 1) + C1 - 1;
     const int mk_f = launder_v(C1 * lane);                 // mask[n]     = mask[mk_f + M1 j1 + c]
     const int mk_r = launder_v(N - TOP - C1 * lane);       // mask[N - n] = mask[mk_r + TOP - (M1 j1 + c)]
+    float *frow = reinterpret_cast<float *>(fft_row) + 2 * mk_f;
 #pragma unroll
     for (int j1 = 0; j1 < R1; ++j1) {
         const cx wgc = cx_conj(wg_s[j1]);  // conj(w2n[M1 j1]), wave-uniform
+        cx kept[C1];
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
             const int off = M1 * j1 + c;
@@ -924,7 +970,12 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
                 xk = cx{xk.x * mk, xk.y * mk};
                 xn = cx{xn.x * mn, xn.y * mn};
             }
+            kept[c] = xk;
             r[c][j1] = c2r_swapped(xk, xn, wc);
+        }
+        if constexpr (STORE) {
+            if constexpr (C1 == 2) store_f4(frow + 2 * M1 * j1, kept[0].x, kept[0].y, kept[1].x, kept[1].y);
+            else *reinterpret_cast<float2 *>(frow + 2 * M1 * j1) = make_float2(kept[0].x, kept[0].y);
         }
         if ((j1 & 1) == 1) THZ_SCHED_FENCE();
     }
@@ -1234,12 +1285,13 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // spectrum stores (+ the inverse transform of the fused chain)
     auto part_b = [&]() {
         if constexpr (MODE != kInv) {
-            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS, TC>(buf, launder_uniform((const cx *)w2n_s),
-                                                               launder_uniform((const cx *)wg_s), mask_l, p, A, lane, &sums);
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS, TC, MODE != kPipe>(buf, launder_uniform((const cx *)w2n_s),
+                                                                              launder_uniform((const cx *)wg_s), mask_l, p, A, lane,
+                                                                              &sums);
             if constexpr (MODE == kPipe) {
                 cx r[C1][R1];
-                f_inverse_input<P, true, CMASK, TC>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
-                                                    mask_l, lane, r);
+                f_inverse_input<P, true, CMASK, TC, true>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
+                                                          mask_l, lane, r, A.fft_out + p * nf);
                 wave_sync();  // every lane has read Z before the core overwrites buf
                 f_core_pass1<P, TC>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);

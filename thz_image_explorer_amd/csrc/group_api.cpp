@@ -393,6 +393,8 @@ int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, cons
             thz_group_session_destroy(gs);
             return rc;
         }
+        s->grid_x0 = gs->x0[(size_t)g->m[i].rank];  // where the slab sits in the whole grid (regions of interest)
+        s->grid_rows = nx;
         gs->sess.push_back(s);
         if (g->m[i].rank == 0) gs->root_local = (int)i;
     }
@@ -430,6 +432,36 @@ int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtr
     return thz_group_sync(g);
 }
 
+// all-reduce of the members' region sums (session_roi.cpp's block layout: the final traces' block is the last
+// R x nt floats — the only one a tail-only recompute or the Deconvolution stage renews)
+static int group_roi_reduce(thz_group_session *gs, std::vector<float *> &bufs, bool data_only)
+{
+    thz_session *s0 = gs->sess[0];
+    const size_t total = session_roi_floats(s0), fin = s0->rois.size() * s0->nt_out;
+    if (data_only)
+        for (float *&b : bufs) b += total - fin;
+    return thz_group_all_reduce_sum(gs->g, bufs.data(), data_only ? fin : total);
+}
+
+int thz_group_session_set_rois(thz_group_session *gs, size_t n_rois, const size_t *n_vertices, const uint64_t *poly_xy)
+{
+    if (!gs) return THZ_ERR_INVALID;
+    thz_group *g = gs->g;
+    for (size_t i = 0; i < gs->sess.size(); ++i) {
+        const int rc = thz_session_set_rois(gs->sess[i], n_rois, n_vertices, poly_xy);
+        if (rc) return gfail(g, rc, std::string("slab regions of interest: ") + thz_last_error(g->m[i].ctx));
+    }
+    return THZ_OK;
+}
+
+int thz_group_session_roi(thz_group_session *gs, size_t roi, const thz_roi_out *out)
+{
+    if (!gs || gs->sess.empty()) return THZ_ERR_INVALID;
+    const int rc = thz_session_roi(gs->sess[0], roi, out);
+    if (rc) return gfail(gs->g, rc, std::string("thz_group_session_roi: ") + thz_last_error(gs->g->m[0].ctx));
+    return rc;
+}
+
 int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg, int start_stage, int gather)
 {
     if (!gs || !cfg) return THZ_ERR_INVALID;
@@ -462,8 +494,24 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
         if (int rc = thz_group_all_reduce_sum(g, bufs.data(), 2 * nf)) return rc;
         for (size_t i = 0; i < gs->sess.size(); ++i) {
             // Σ of the raw traces was all-reduced at upload; the copy in d_msum[0, nt) is already the cube's
-            const int rc = session_means(gs->sess[i], cfg, gs->nx * gs->ny);
+            int rc = session_means(gs->sess[i], cfg, gs->nx * gs->ny);
+            if (!rc) rc = session_avg_data(gs->sess[i], cfg);
             if (rc) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[i].ctx));
+        }
+    }
+    // C2, second part: the regions of interest's masked sums (every slab's rows of the whole grid's mask)
+    if (!gs->sess.empty() && !gs->sess[0]->rois.empty()) {
+        bool data_only = tail.size() && tail[0];  // (the members agree: same regions, same history)
+        std::vector<float *> bufs;
+        for (size_t i = 0; i < gs->sess.size(); ++i) {
+            const int rc = session_roi_sums(gs->sess[i], cfg, &data_only);
+            if (rc) return gfail(g, rc, std::string("slab regions of interest: ") + thz_last_error(g->m[i].ctx));
+            bufs.push_back(gs->sess[i]->d_roi_sum);
+        }
+        if (int rc = group_roi_reduce(gs, bufs, data_only)) return rc;
+        for (size_t i = 0; i < gs->sess.size(); ++i) {
+            const int rc = session_roi_finish(gs->sess[i], cfg, data_only);
+            if (rc) return gfail(g, rc, std::string("slab regions of interest: ") + thz_last_error(g->m[i].ctx));
         }
     }
     // C1: per-pixel results to rank 0
@@ -646,6 +694,22 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
         }
     }
     cleanup();
+    // the regions of interest's means of the FINAL traces follow the stage's output (data_thread.rs:1445-1451)
+    if (!gs->sess[0]->rois.empty() && gs->sess[0]->have_last_cfg) {
+        std::vector<float *> bufs;
+        bool data_only = true;
+        for (size_t i = 0; i < nl; ++i) {
+            const int rc = session_roi_sums(gs->sess[i], &gs->sess[i]->last_cfg, &data_only);
+            if (rc) return gfail(g, rc, std::string("slab regions of interest: ") + thz_last_error(g->m[i].ctx));
+            bufs.push_back(gs->sess[i]->d_roi_sum);
+        }
+        if (int rc = group_roi_reduce(gs, bufs, data_only)) return rc;
+        for (size_t i = 0; i < nl; ++i) {
+            const int rc = session_roi_finish(gs->sess[i], &gs->sess[i]->last_cfg, data_only);
+            if (rc) return gfail(g, rc, std::string("slab regions of interest: ") + thz_last_error(g->m[i].ctx));
+        }
+        if (int rc = thz_group_sync(g)) return rc;
+    }
     if (status < 0) return gfail(g, status, "thz_group_session_deconvolve: aborted or failed on a rank; the stage passes its input through");
     return status;
 }

@@ -608,13 +608,17 @@ __global__ __launch_bounds__(256) void k_sum_rows_f64(const float *__restrict__ 
 // of every row (a full row is read by consecutive chunk-iterations, 4 KiB each)
 // and keeps U rows x KC chunks of loads in flight.  Rows are only 4-byte aligned
 // (L = 2*nf or nf); the ragged last chunk (L % 4 floats) is summed by thread 0.
+// `list` (or null): the rows to add are arr's rows list[0 .. nrows) — a region of interest's pixels (session ROI
+// sums); the sums of a list are order-free like the pixel sums.
 template <int KC>
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ arr,
                                                         size_t nrows, size_t L,
                                                         size_t rows_per_group,
-                                                        float *__restrict__ partial)
+                                                        float *__restrict__ partial,
+                                                        const uint32_t *__restrict__ list)
 {
     constexpr int U = 2;
+    auto row_of = [&](size_t r) -> size_t { return list ? (size_t)list[r] : r; };
     // rows are dealt round-robin to the blocks (row = rg + G*i): at any moment the
     // chip streams one contiguous band of the array, like a linear copy does
     const size_t rg = blockIdx.x, G = gridDim.x;
@@ -630,13 +634,15 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     for (; r + (U - 1) * G < nrows; r += U * G) {
         float v[U][KC][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const size_t row = row_of(r + u * G);
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const size_t ch = t + 256 * (size_t)k;
-                if (ch < nfull) load_f4(arr + (r + u * G) * L + 4 * ch, v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3]);
+                if (ch < nfull) load_f4(arr + row * L + 4 * ch, v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3]);
                 else v[u][k][0] = v[u][k][1] = v[u][k][2] = v[u][k][3] = 0.0f;
             }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
             const size_t ch = t + 256 * (size_t)k;
             if (ch < nfull) {
                 float a, b, c, d;
-                load_f4(arr + r * L + 4 * ch, a, b, c, d);
+                load_f4(arr + row_of(r) * L + 4 * ch, a, b, c, d);
                 acc[k][0] += a; acc[k][1] += b; acc[k][2] += c; acc[k][3] += d;
             }
         }
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     if (tail0 < L && t < kWave) {
         for (size_t c = tail0; c < L; ++c) {
             float s = 0.0f;
-            for (size_t rr = rg + G * t; rr < nrows; rr += G * kWave) s += arr[rr * L + c];
+            for (size_t rr = rg + G * t; rr < nrows; rr += G * kWave) s += arr[row_of(rr) * L + c];
             s = wave_reduce_add(s);
             if (t == 0) partial[rg * L + c] = s;
         }
@@ -727,6 +733,48 @@ __global__ __launch_bounds__(64) void k_gather_sum(const float *__restrict__ arr
     }
     for (; c < count; ++c) s += col[(size_t)list[c] * len];
     out[z] = (div > 0.0f) ? s / div : s;
+}
+
+// k_gather_sum over arr * w1 * w2 * w3 (each factor optional, applied in this order with its own rounding): the ROI
+// mean of the fft stage's `data` output — the input traces after the Tilt taper, "Time Band Pass" and the fft
+// window, three successive f32 multiplies in the reference (tilt_compensation.rs:171-201, band_pass_td_*.rs:155-175,
+// math_tools.rs:356-371) — summed in the reference's order (math_tools.rs:477-483 -> :640-659) without the windowed
+// cube ever being stored.
+__global__ __launch_bounds__(64) void k_gather_sum_w(const float *__restrict__ arr, size_t len,
+                                                     const uint32_t *__restrict__ list, uint32_t count, float div,
+                                                     const float *__restrict__ w1, const float *__restrict__ w2,
+                                                     const float *__restrict__ w3, float *__restrict__ out)
+{
+    const size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= len) return;
+    const float *col = arr + z;
+    const float a = w1 ? w1[z] : 1.0f, b = w2 ? w2[z] : 1.0f, c3 = w3 ? w3[z] : 1.0f;
+    auto weigh = [&](float v) {
+        if (w1) v = v * a;
+        if (w2) v = v * b;
+        if (w3) v = v * c3;
+        return v;
+    };
+    float s = 0.0f;
+    uint32_t c = 0;
+    for (; c + kGatherBatch <= count; c += kGatherBatch) {
+        float v[kGatherBatch];
+#pragma unroll
+        for (int i = 0; i < kGatherBatch; ++i) v[i] = col[(size_t)list[c + i] * len];
+#pragma unroll
+        for (int i = 0; i < kGatherBatch; ++i) s += weigh(v[i]);
+    }
+    for (; c < count; ++c) s += weigh(col[(size_t)list[c] * len]);
+    out[z] = (div > 0.0f) ? s / div : s;
+}
+
+// out = in / d (IEEE division, what `result[z] /= pixel_counts[z] as f32` does, math_tools.rs:655-659), or
+// (in * w) / d when w is given
+__global__ __launch_bounds__(256) void k_div_vec(const float *__restrict__ in, const float *__restrict__ w, float d, size_t n,
+                                                 float *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (w ? in[i] * w[i] : in[i]) / d;
 }
 
 // One wave per pixel: the trace is copied to its insert position on the extended axis, the front
@@ -2285,7 +2333,7 @@ void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inn
 // returns the number of partial rows written to `partial` (each L floats); 0 if L is
 // too wide for the kernel (caller falls back)
 size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,
-                             float *partial, size_t max_groups)
+                             float *partial, size_t max_groups, const uint32_t *list)
 {
     const size_t chunks = (L / 4 + 255) / 256;  // 16-byte chunks per thread
     if (chunks > 8) return 0;
@@ -2295,11 +2343,11 @@ size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, siz
     if (groups < 1) groups = 1;
     const size_t rows_per_group = (nrows + groups - 1) / groups;
     groups = (nrows + rows_per_group - 1) / rows_per_group;
-    if (chunks <= 1) THZ_LAUNCH((k_colsum_partial<1>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
-    else if (chunks <= 2) THZ_LAUNCH((k_colsum_partial<2>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
-    else if (chunks <= 3) THZ_LAUNCH((k_colsum_partial<3>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
-    else if (chunks <= 5) THZ_LAUNCH((k_colsum_partial<5>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
-    else THZ_LAUNCH((k_colsum_partial<8>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial);
+    if (chunks <= 1) THZ_LAUNCH((k_colsum_partial<1>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial, list);
+    else if (chunks <= 2) THZ_LAUNCH((k_colsum_partial<2>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial, list);
+    else if (chunks <= 3) THZ_LAUNCH((k_colsum_partial<3>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial, list);
+    else if (chunks <= 5) THZ_LAUNCH((k_colsum_partial<5>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial, list);
+    else THZ_LAUNCH((k_colsum_partial<8>), (unsigned)groups, 256, 0, st, arr, nrows, L, rows_per_group, partial, list);
     return groups;
 }
 
@@ -2315,6 +2363,17 @@ void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint3
                        uint32_t count, float div, float *out)
 {
     THZ_LAUNCH(k_gather_sum, (unsigned)((len + 63) / 64), 64, 0, st, arr, len, d_list, count, div, out);
+}
+
+void launch_gather_sum_w(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list, uint32_t count, float div,
+                         const float *w1, const float *w2, const float *w3, float *out)
+{
+    THZ_LAUNCH(k_gather_sum_w, (unsigned)((len + 63) / 64), 64, 0, st, arr, len, d_list, count, div, w1, w2, w3, out);
+}
+
+void launch_div_vec(hipStream_t st, const float *in, const float *w, float d, size_t n, float *out)
+{
+    THZ_LAUNCH(k_div_vec, grid_1d(n, 256, kNumCU), 256, 0, st, in, w, d, n, out);
 }
 
 void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,

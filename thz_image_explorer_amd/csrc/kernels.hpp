@@ -121,13 +121,18 @@ void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *i
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
                       float *out);
 void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inner, float *out);  // column sums of a few rows, adds in double
+// list (or null): add arr's rows list[0 .. nrows) instead of rows 0 .. nrows - 1 (a region of interest's pixels)
 size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,
-                             float *partial, size_t max_groups);
+                             float *partial, size_t max_groups, const uint32_t *list = nullptr);
 void launch_roi_mask(hipStream_t st, const uint64_t *d_poly, int n, uint64_t x_min, uint64_t x_max,
                      uint64_t y_min, uint64_t y_max, uint64_t x_size, uint64_t y_size,
                      uint8_t *d_mask);
 void launch_gather_sum(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list,
                        uint32_t count, float div, float *out);
+// launch_gather_sum over arr * w1 * w2 * w3 (each factor optional, one f32 multiply each, in this order)
+void launch_gather_sum_w(hipStream_t st, const float *arr, size_t len, const uint32_t *d_list, uint32_t count, float div,
+                         const float *w1, const float *w2, const float *w3, float *out);
+void launch_div_vec(hipStream_t st, const float *in, const float *w, float d, size_t n, float *out);  // out = (in [* w]) / d, IEEE division
 void launch_scale3d(hipStream_t st, const float *arr, size_t nx, size_t ny, size_t L, size_t s,
                     float *out);
 

@@ -5,6 +5,16 @@
 
 #include <vector>
 
+// One region of interest of a session (thz_session_set_rois) and its pixel list for the grid of the last recompute
+struct SessionRoi {
+    std::vector<uint64_t> poly;   // (x, y) pairs as the reference keeps them: pixels of the raw grid
+    uint32_t *d_list = nullptr;   // THIS slab's pixels inside, in the reference's visiting order (y outer, x inner;
+    size_t list_cap = 0;          //   mask position (x, y) samples pixel [shape0 - y - 1, x], math_tools.rs:640-651)
+    uint32_t count = 0;           // ... how many
+    uint32_t total = 0;           // pixels of the WHOLE grid inside (= count unless the session is a group's slab)
+    size_t for_rows = 0, for_cols = 0, for_scale = 0, for_x0 = 0, for_grid_rows = 0;  // what the list was built for
+};
+
 struct thz_session {
     thz_ctx *ctx = nullptr;
     size_t nx = 0, ny = 0, nt = 0, nf = 0;
@@ -39,6 +49,21 @@ struct thz_session {
     bool have_means = false;
     bool have_outputs = false;   // a recompute has run
     const float *d_src = nullptr;  // what the fft stage read: d_raw, d_scaled or d_tilt (extended axis)
+    // ---- regions of interest (session_roi.cpp)
+    std::vector<SessionRoi> rois;
+    float *d_roi_sum = nullptr;    // [amplitudes R x nf | phases R x nf | stage-input traces R x nt | final traces R x nt]:
+    float *d_roi = nullptr;        //   this session's (after a group's all-reduce: the grid's) sums, and the means
+    size_t roi_floats = 0;
+    float *d_wsep = nullptr;       // the three time multipliers in front of the transform, one by one (reference-order
+    size_t wsep_floats = 0;        //   roi_data): [tilt taper | Time Band Pass | fft window], nt_out each
+    bool wsep_on[3] = {false, false, false};
+    std::vector<float> roi_polar;  // avg_in_fourier_space: per region the polar inverse transform (nt_out each), host
+    std::vector<char> roi_polar_ok;  //   0: realfft would have refused the spectrum (the reference falls back to the traces)
+    std::vector<float> avg_data;   // avg_in_fourier_space: the ifft stage's avg_data (nt_out), host
+    bool have_rois = false;        // d_roi holds the means of the last recompute
+    // placement in a group's grid (group_api.cpp): this session holds rows grid_x0 .. of grid_rows rows of the
+    // CURRENT (scaled) grid; grid_rows == 0: the session is the whole grid
+    size_t grid_x0 = 0, grid_rows = 0;
 };
 
 
@@ -48,3 +73,14 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
 // second half: pixel means from the sums in d_msum, which cover total_pix pixels (the slab's own, or all
 // slabs' after the group's all-reduce)
 int session_means(thz_session *s, const thz_chain_cfg *cfg, size_t total_pix);
+// Regions of interest, in two halves like the means: session_roi_sums enqueues the masked sums of this session's
+// pixels into d_roi_sum (*data_only: the chain's tail or the Deconvolution stage changed the final traces only —
+// cleared when the buffers are new and everything is summed after all);
+// a group all-reduces d_roi (thz_session_roi_floats floats) in between; session_roi_finish divides by the
+// regions' pixel counts over the whole grid and, with avg_in_fourier_space, takes the polar inverse transforms.
+int session_roi_sums(thz_session *s, const thz_chain_cfg *cfg, bool *data_only);
+int session_roi_finish(thz_session *s, const thz_chain_cfg *cfg, bool data_only);
+size_t session_roi_floats(const thz_session *s);
+void session_roi_free(thz_session *s);
+// the ifft stage's avg_data (avg_in_fourier_space; needs the means): host-side, after session_means
+int session_avg_data(thz_session *s, const thz_chain_cfg *cfg);

@@ -101,6 +101,7 @@ void thz_session_destroy(thz_session *s)
                     (void *)s->d_rawsum, (void *)s->d_msum})
         if (p) (void)hipFree(p);
     if (s->h_vec) (void)hipHostFree(s->h_vec);
+    session_roi_free(s);
     delete s;
 }
 
@@ -147,7 +148,7 @@ bool same_front(const thz_chain_cfg &a, const thz_chain_cfg &b)
            && a.fft_window.type == b.fft_window.type && a.fft_window.lower == b.fft_window.lower
            && a.fft_window.upper == b.fft_window.upper && a.fd_active == b.fd_active && a.fd_low == b.fd_low
            && a.fd_high == b.fd_high && a.fd_width == b.fd_width && a.scale_factor == b.scale_factor
-           && a.want_means == b.want_means;
+           && a.want_means == b.want_means && a.avg_in_fourier_space == b.avg_in_fourier_space;
 }
 
 void post_multiplier(const thz_chain_cfg *cfg, const std::vector<float> &time, std::vector<float> &post)
@@ -276,14 +277,33 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
 
     // ---- multipliers in the reference's f32 order: ((tilt * td_before) * fft_window)
     std::vector<float> pre(nt_cur, 1.0f), w(nt_cur), post, mask(nf, 1.0f);
-    if (tilt_as_multiplier) pre = tilt_taper;
+    // ... and one by one for the regions of interest's reference-order roi_data (session_roi.cpp): the mean of the
+    // fft stage's `data`, on which the reference performs the three multiplies in turn
+    const bool want_sep = cfg->want_means == 2 && !s->rois.empty();
+    std::vector<float> sep(want_sep ? 3 * nt_cur : 0);
+    s->wsep_on[0] = s->wsep_on[1] = s->wsep_on[2] = false;
+    if (tilt_as_multiplier) {
+        pre = tilt_taper;
+        if (want_sep) { std::memcpy(sep.data(), tilt_taper.data(), nt_cur * sizeof(float)); s->wsep_on[0] = true; }
+    }
     if (cfg->td_before_active) {
         double lo = cfg->td_before_low, hi = cfg->td_before_high;
         td_bandpass(time.data(), nt_cur, &lo, &hi, cfg->td_before_width, w.data(), nullptr, nullptr);
         for (size_t i = 0; i < nt_cur; ++i) pre[i] = pre[i] * w[i];
+        if (want_sep) { std::memcpy(sep.data() + nt_cur, w.data(), nt_cur * sizeof(float)); s->wsep_on[1] = true; }
     }
     fft_window(cfg->fft_window.type, time.data(), nt_cur, cfg->fft_window.lower, cfg->fft_window.upper, w.data());
     for (size_t i = 0; i < nt_cur; ++i) pre[i] = pre[i] * w[i];
+    if (want_sep) {
+        std::memcpy(sep.data() + 2 * nt_cur, w.data(), nt_cur * sizeof(float));
+        s->wsep_on[2] = true;
+        if (s->wsep_floats != 3 * nt_cur) {
+            s->wsep_floats = 0;
+            if (int rc = dev_alloc(ctx, &s->d_wsep, 3 * nt_cur)) return rc;
+            s->wsep_floats = 3 * nt_cur;
+        }
+        if (int rc = thz_memcpy_h2d(ctx, s->d_wsep, sep.data(), sep.size() * sizeof(float))) return rc;
+    }
     if (cfg->fd_active)
         fd_bandpass(ctx->freq.data(), nf, cfg->fd_low, cfg->fd_high, cfg->fd_width, mask.data(), nullptr, nullptr);
     // further Frequency-domain plugins behind the band pass (K14: a real multiplier, one f32 multiply per
@@ -381,8 +401,14 @@ int thz_session_recompute_from(thz_session *s, const thz_chain_cfg *cfg, int sta
     if (start_stage == 8) return THZ_OK;  // only the Deconvolution stage is re-run: thz_session_deconvolve
     bool tail_only = false;
     if (int rc = session_enqueue(s, cfg, start_stage, &tail_only)) return rc;
-    if (!tail_only)
+    if (!tail_only) {
         if (int rc = session_means(s, cfg, s->nx_cur * s->ny_cur)) return rc;
+        if (int rc = session_avg_data(s, cfg)) return rc;
+    }
+    // regions of interest: the ifft stage's per-region means + the plot copy-out's (session_roi.cpp)
+    bool roi_data_only = tail_only;
+    if (int rc = session_roi_sums(s, cfg, &roi_data_only)) return rc;
+    if (int rc = session_roi_finish(s, cfg, roi_data_only)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return THZ_OK;
 }
@@ -429,6 +455,12 @@ int thz_session_deconvolve(thz_session *s, const thz_psf *psf, const thz_deconv_
         return rc;
     }
     s->deconv_current = true;  // THZ_SKIPPED too: the guards copied the input through
+    if (s->have_last_cfg && !s->rois.empty()) {  // the regions' means of the FINAL traces follow the stage's output
+        bool roi_data_only = true;
+        if (int rc2 = session_roi_sums(s, &s->last_cfg, &roi_data_only)) return rc2;
+        if (int rc2 = session_roi_finish(s, &s->last_cfg, roi_data_only)) return rc2;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return rc;
 }
 
@@ -577,8 +609,12 @@ int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *o
             if (!rc && out->phase_fft) rc = thz_memcpy_d2h(ctx, out->phase_fft, d_tmp + nf, nf * sizeof(float));
         }
         if (!rc && out->avg_signal) {
-            rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nt, 1, final_data(s), d_tmp + 2 * nf);
-            if (!rc) rc = thz_memcpy_d2h(ctx, out->avg_signal, d_tmp + 2 * nf, nt * sizeof(float));
+            if (s->have_last_cfg && s->last_cfg.avg_in_fourier_space && s->avg_data.size() == nt) {
+                std::memcpy(out->avg_signal, s->avg_data.data(), nt * sizeof(float));  // filtered.avg_data, data_thread.rs:1431
+            } else {
+                rc = thz_pixel_mean(ctx, s->nx_cur, s->ny_cur, nt, 1, final_data(s), d_tmp + 2 * nf);
+                if (!rc) rc = thz_memcpy_d2h(ctx, out->avg_signal, d_tmp + 2 * nf, nt * sizeof(float));
+            }
         }
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_tmp);
