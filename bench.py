@@ -14,6 +14,9 @@ for the launch plumbing only: shipping the RCCL unique id, the barrier and the m
 contract.  The cube is fixed as N grows (strong scaling: BASELINE.json asks for the same cube at 1, 2, 4 and
 8 GPUs); --scaling weak keeps a fixed slab per GPU.
 
+One fixed pentagon is set as a region of interest, so every timed step also takes the region's
+masked means, as the reference's ifft stage does for every region with every recompute (math_tools.rs:473-543).
+
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the fused launch) from hipEvents
 recorded on the engine's own stream around every timed launch; `cpu_baseline` times the CPU oracle (port of
 the reference algorithm, OpenMP over x rows like the reference's rayon split) on a bounded sample on rank 0
@@ -112,6 +115,53 @@ def cpu_baseline(nt, ny, budget_s):
     return out
 
 
+# "ROI: one fixed pentagon" — vertices (x, y) as the reference keeps them, on the 1024 x 1024 grid
+# (scaled with the grid otherwise); 23 359 pixels inside by the reference's integer rule, 2.2 % of the image
+PENTAGON_1024 = ((300, 200), (520, 260), (600, 480), (420, 620), (240, 460))
+
+
+def pentagon(nx, ny):
+    return np.array([[x * ny // 1024, y * nx // 1024] for x, y in PENTAGON_1024], np.uint64)
+
+
+def spot_check(sess, tm, first_trace, npix, H=None, n=48):
+    """The headline run proves itself: n seeded traces of the step's resident outputs against a numpy fp64
+    model of the chain built on the ORACLE's multiplier vectors (synth.oracle_chain; the traces are regenerated
+    on the host from the counter-based generator).  Relative max-norm errors per output; outside the timed region."""
+    import synth
+    import thz_image_explorer_amd as pkg
+    nt = tm.size
+    rng = np.random.default_rng(0x7A3D2026)
+    pix = np.sort(rng.choice(npix, size=min(n, npix), replace=False))
+    raw = synth.make_traces(np.uint64(first_trace) + pix.astype(np.uint64), nt).astype(np.float64)
+    c = synth.oracle_chain(tm)
+    pre = c["w_tilt"].astype(np.float64) * c["w_td_before"] * c["w_fft"]
+    X = np.fft.rfft(raw * pre, axis=1)
+    m = c["fd_mask"].astype(np.float64) * (1.0 if H is None else (H[:, 0].astype(np.float64) + 1j * H[:, 1]))
+    Y = X * m
+    amp = np.abs(Y)
+    Y[:, 0] = Y[:, 0].real
+    if nt % 2 == 0:
+        Y[:, -1] = Y[:, -1].real
+    data = np.fft.irfft(Y, n=nt, axis=1) * c["w_post"]
+    img = (data ** 2).sum(1)
+    got = {k: np.stack([sess.download(b, int(p), 1)[0] for p in pix])
+           for k, b in (("fft", pkg.BUF_FFT), ("amp", pkg.BUF_AMPLITUDES), ("ph", pkg.BUF_PHASES), ("data", pkg.BUF_DATA), ("img", pkg.BUF_IMG))}
+    g_fft = got["fft"][..., 0] + 1j * got["fft"][..., 1]
+    err = {"fft": float(np.abs(g_fft - Y).max() / np.abs(Y).max()),
+           "amplitudes": float(np.abs(got["amp"] - amp).max() / amp.max()),
+           "data": float(np.abs(got["data"] - data).max() / np.abs(data).max()),
+           "img": float(np.abs(got["img"].ravel() - img).max() / img.max())}
+    # unwrapped phases (of X, as with the band pass): equal up to whole turns where the amplitude carries a phase
+    ax = np.abs(X)
+    strong = ax > 0.05 * ax.max(1, keepdims=True)
+    d = got["ph"].astype(np.float64) - np.unwrap(np.angle(X), axis=1)
+    d -= 2 * np.pi * np.round(d / (2 * np.pi))
+    err["phases_mod_2pi_where_strong"] = float(np.abs(d)[strong].max())
+    err["traces"] = int(pix.size)
+    return err
+
+
 def wiener_multiplier(eng, tm):
     """K13 of BASELINE config 5 from the synthetic reference pulse (the noise-free template of the cube's traces,
     SURVEY §8d): R through the engine's own window + transform, H by thz_host_wiener_filter"""
@@ -145,6 +195,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-means", action="store_true", help="no pixel means: the fused launch alone")
+    ap.add_argument("--no-roi", action="store_true", help="without the region of interest (the fixed pentagon of SURVEY 8d)")
+    ap.add_argument("--no-spot-check", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +206,6 @@ def main():
         local_rank = int(os.environ["THZ_BENCH_DEVICE"])
     if args.gpus != world and args.gpus > 1:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got WORLD_SIZE={world})")
-    import torch
 
     import thz_image_explorer_amd as pkg
     from thz_image_explorer_amd import binding
@@ -163,15 +214,14 @@ def main():
     # launch plumbing: the id of the library's RCCL communicator travels over a gloo broadcast
     dist = None
     uid = None
-    if world > 1:
+    if world > 1:   # torch only as the launch plumbing of a process-per-GPU run (gloo: rendezvous, barrier, max over ranks)
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         box = [pkg.group_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     nx, ny, nt = args.nx, args.ny, args.nt
     nf = nt // 2 + 1
@@ -191,19 +241,23 @@ def main():
     gs.upload(None, subtract_bias=False)   # image of the raw cube, raw pixel sums (+ their all-reduce): once per file
     cfg = pkg.chain_cfg_default(tm)
     cfg.want_means = 0 if args.no_means else 1
+    H_wiener = None
     if args.wiener:
-        sess.set_fd_filters(None, wiener_multiplier(eng, tm))
+        H_wiener = wiener_multiplier(eng, tm)
+        sess.set_fd_filters(None, H_wiener)
+    roi_poly = None if args.no_roi else pentagon(nx_tot, ny)
+    if roi_poly is not None:
+        gs.set_rois([roi_poly])
     gather = {"small": pkg.GATHER_SMALL, "time": pkg.GATHER_TIME, "all": pkg.GATHER_ALL}[args.gather]
 
     def step():
         gs.recompute(cfg, 1, gather)
 
     def fence():
-        group.sync()
-        torch.cuda.synchronize(dev)
+        group.sync()   # hipStreamSynchronize on every stream the engine uses on this rank's device
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            group.sync()
 
     for _ in range(args.warmup):
         step()
@@ -216,10 +270,19 @@ def main():
     dt = time.perf_counter() - t0
     pipe_ns, pipe_calls = eng.timing_collect(binding.STAGE_PIPELINE)
     mean_ns, mean_calls = eng.timing_collect(binding.STAGE_MEAN)
+    roi_ns, roi_calls = eng.timing_collect(binding.STAGE_ROI)
     eng.timing_collect(binding.STAGE_FFT)
     eng.enable_timing(0)
+    # the run's own correctness witness, before the extra kernel legs below reuse the output buffers
+    spot = roi_out = None
+    if rank == 0 and not args.no_spot_check:
+        spot = spot_check(sess, tm, x0 * ny, npix, H_wiener)
+    if rank == 0 and roi_poly is not None:
+        r = gs.roi(0, want=["signal_fft", "signal"])
+        roi_out = {"pixels": int(r["count"]), "finite": bool(np.isfinite(r["signal_fft"]).all() and np.isfinite(r["signal"]).all()),
+                   "mean_amplitude_max": float(r["signal_fft"].max())}
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)   # a CPU tensor over gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -259,18 +322,21 @@ def main():
                          "avg_launch_ms": n_s * 1e3, "achieved": n_gbs, "frac": n_gbs / HBM_PEAK_GBPS, "launches_timed": n_calls,
                          "traffic": measured_traffic(nt, npix, wiener=False, sums=False)}
         if not args.wiener:
+            # BASELINE config 5's chain AS A SESSION RUNS IT: complex multiplier AND the in-launch pixel sums
             d_H = eng.to_device(wiener_multiplier(eng, tm))
+            d_sums = eng.empty((2 * nf,)) if fused_sums else None
             for _ in range(6):
-                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, None, None)
+                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, None, d_sums)
             eng.sync()
             w_ns, w_calls = eng.timing_collect(binding.STAGE_PIPELINE)
             if w_calls:
                 w_s = w_ns / w_calls * 1e-9
                 w_gbs = npix * algorithmic_bytes_per_trace(nt) / w_s / 1e9
-                wleg = {"kernel": "k_f<pipe, complex multiplier> (BASELINE config 5: reference-pulse Wiener filter in the fused launch)",
+                wleg = {"kernel": "k_f<pipe, complex multiplier" + (", sums" if fused_sums else "") + "> (BASELINE config 5: reference-pulse "
+                                  "Wiener filter in the fused launch" + (", with the in-launch pixel sums a session recompute carries" if fused_sums else "") + ")",
                         "bytes_per_trace": algorithmic_bytes_per_trace(nt), "avg_launch_ms": w_s * 1e3, "achieved": w_gbs,
                         "frac": w_gbs / HBM_PEAK_GBPS, "launches_timed": w_calls,
-                        "traffic": measured_traffic(nt, npix, wiener=True)}
+                        "traffic": measured_traffic(nt, npix, wiener=True, sums=fused_sums)}
         eng.enable_timing(0)
 
     # sanity: the run produced finite, non-trivial output (checked outside the timed region)
@@ -299,6 +365,11 @@ def main():
                                       + (f"; in-library RCCL: all-reduce of pixel sums + gather '{args.gather}' to rank 0"
                                          if world > 1 else ""),
                        "gather": args.gather, "step": "thz_group_session_recompute (UpdateType::Filter(1))",
+                       "rccl_ranks": group.world,   # thz_group_world: the communicator size the library saw
+                       "roi": (None if roi_poly is None else
+                               {"polygon": roi_poly.tolist(), **(roi_out or {}),
+                                "ms_per_step": (roi_ns / max(args.steps, 1)) * 1e-6 if roi_calls else None}),
+                       "spot_check_rel_err": spot,
                        "kernel_variant": eng.kernel_variant(),
                        "achieved_hbm_pct_whole_step": 100.0 * value / world * m_full / 1e9 / HBM_PEAK_GBPS},
             "roofline": {"bound": "hbm",
