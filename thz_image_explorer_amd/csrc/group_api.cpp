@@ -437,10 +437,14 @@ int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtr
 static int group_roi_reduce(thz_group_session *gs, std::vector<float *> &bufs, bool data_only)
 {
     thz_session *s0 = gs->sess[0];
-    const size_t total = session_roi_floats(s0), fin = s0->rois.size() * s0->nt_out;
-    if (data_only)
-        for (float *&b : bufs) b += total - fin;
-    return thz_group_all_reduce_sum(gs->g, bufs.data(), data_only ? fin : total);
+    const size_t total = session_roi_floats(s0), fin = s0->rois.size() * s0->nt_out, spec = 2 * s0->rois.size() * s0->nf_out;
+    std::vector<float *> tail(bufs);
+    for (float *&b : tail) b += total - fin;
+    if (data_only) return thz_group_all_reduce_sum(gs->g, tail.data(), fin);
+    if (s0->roi_src_fresh) return thz_group_all_reduce_sum(gs->g, bufs.data(), total);
+    // the source traces' block in the middle holds the grid's sums of an earlier recompute: left alone
+    if (int rc = thz_group_all_reduce_sum(gs->g, bufs.data(), spec)) return rc;
+    return thz_group_all_reduce_sum(gs->g, tail.data(), fin);
 }
 
 int thz_group_session_set_rois(thz_group_session *gs, size_t n_rois, const size_t *n_vertices, const uint64_t *poly_xy)

@@ -61,6 +61,13 @@ struct thz_session {
     std::vector<char> roi_polar_ok;  //   0: realfft would have refused the spectrum (the reference falls back to the traces)
     std::vector<float> avg_data;   // avg_in_fourier_space: the ifft stage's avg_data (nt_out), host
     bool have_rois = false;        // d_roi holds the means of the last recompute
+    // The regions' sums of the SOURCE traces (parallel sums) do not depend on the sliders: they are kept for as long as
+    // the source cube, the grid and the regions stay what they were (src_gen counts uploads, scale / tilt changes and
+    // list rebuilds; roi_src_gen is the generation the kept sums belong to, 0 = none)
+    unsigned long src_gen = 1, roi_src_gen = 0;
+    bool roi_src_fresh = false;    // the last session_roi_sums renewed the source block (a group all-reduces it then)
+    int last_sf = -1, last_tilt_active = -1;
+    double last_tilt_x = 0.0, last_tilt_y = 0.0;
     // placement in a group's grid (group_api.cpp): this session holds rows grid_x0 .. of grid_rows rows of the
     // CURRENT (scaled) grid; grid_rows == 0: the session is the whole grid
     size_t grid_x0 = 0, grid_rows = 0;

@@ -115,6 +115,7 @@ int thz_session_upload(thz_session *s, const float *cube, int subtract_bias)
     // the image below is the raw grid's: outputs of an earlier (possibly scaled) recompute are void
     s->have_outputs = false; s->have_means = false; s->deconv_current = false;
     s->scale = 1; s->nx_cur = s->nx; s->ny_cur = s->ny; s->dx_cur = s->dx; s->dy_cur = s->dy;
+    ++s->src_gen;  // new source traces: the regions' kept sums of them are void
     if (cube) HIP_TRY(ctx, hipMemcpyAsync(s->d_raw, cube, npix * s->nt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     launch_intensity(ctx->stream, npix, (int)s->nt, s->d_raw, s->d_img, subtract_bias ? 1 : 0);
     if (int rc = check_launch(ctx)) return rc;
@@ -214,6 +215,12 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
             return fail(ctx, THZ_ERR_UNSUPPORTED,
                         "tilt compensation extends the traces to " + std::to_string(nt_cur + 2 * steps)
                             + " samples: no transform of that length (powers of two up to 16384, other lengths up to 8191)");
+    }
+    // what the fft stage reads changes with the scale factor and the tilt only
+    if ((int)sf != s->last_sf || cfg->tilt_active != s->last_tilt_active
+        || (cfg->tilt_active && (cfg->tilt_x_deg != s->last_tilt_x || cfg->tilt_y_deg != s->last_tilt_y))) {
+        ++s->src_gen;
+        s->last_sf = (int)sf; s->last_tilt_active = cfg->tilt_active; s->last_tilt_x = cfg->tilt_x_deg; s->last_tilt_y = cfg->tilt_y_deg;
     }
     s->have_outputs = false;  // the grid may change under the buffers below
     s->have_last_cfg = false;

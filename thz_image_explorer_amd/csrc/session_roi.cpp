@@ -83,6 +83,7 @@ int build_lists(thz_session *s)
         }
         r.count = (uint32_t)list.size();
         r.total = total;
+        ++s->src_gen;  // other pixels: the kept sums of the source traces are void
         r.for_rows = rows; r.for_cols = cols; r.for_scale = s->scale; r.for_x0 = x0; r.for_grid_rows = grid_rows;
     }
     if (d_mask) {
@@ -130,11 +131,17 @@ int session_roi_sums(thz_session *s, const thz_chain_cfg *cfg, bool *data_only_i
         if (int rc = dev_realloc(ctx, &s->d_roi, L.total())) return rc;
         if (int rc = dev_realloc(ctx, &s->d_roi_sum, L.total())) return rc;
         s->roi_floats = L.total();
+        s->roi_src_gen = 0;
         data_only = false;  // nothing to keep
     }
     *data_only_io = data_only;
     const bool ordered = cfg->want_means == 2;
     const float *fin = final_data(s);
+    // the source block: always with the ordered sums (the multipliers are inside them), else only when the source
+    // traces, the grid or the regions changed since it was last taken
+    const bool src_now = !data_only && (ordered || s->roi_src_gen != s->src_gen);
+    s->roi_src_fresh = src_now;
+    if (src_now) s->roi_src_gen = ordered ? 0 : s->src_gen;
     for (size_t r = 0; r < L.R; ++r) {
         const SessionRoi &roi = s->rois[r];
         float *o = s->d_roi_sum;
@@ -142,7 +149,7 @@ int session_roi_sums(thz_session *s, const thz_chain_cfg *cfg, bool *data_only_i
             if (!data_only) {
                 HIP_TRY(ctx, hipMemsetAsync(o + L.amp(r), 0, L.nf * sizeof(float), ctx->stream));
                 HIP_TRY(ctx, hipMemsetAsync(o + L.ph(r), 0, L.nf * sizeof(float), ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(o + L.src(r), 0, L.nt * sizeof(float), ctx->stream));
+                if (src_now) HIP_TRY(ctx, hipMemsetAsync(o + L.src(r), 0, L.nt * sizeof(float), ctx->stream));
             }
             HIP_TRY(ctx, hipMemsetAsync(o + L.fin(r), 0, L.nt * sizeof(float), ctx->stream));
             continue;
@@ -164,7 +171,8 @@ int session_roi_sums(thz_session *s, const thz_chain_cfg *cfg, bool *data_only_i
             if (!data_only) {
                 if (int rc = pixel_sum_rows(ctx, s->d_amp, roi.d_list, roi.count, L.nf, o + L.amp(r))) return rc;
                 if (int rc = pixel_sum_rows(ctx, s->d_ph, roi.d_list, roi.count, L.nf, o + L.ph(r))) return rc;
-                if (int rc = pixel_sum_rows(ctx, s->d_src, roi.d_list, roi.count, L.nt, o + L.src(r))) return rc;
+                if (src_now)
+                    if (int rc = pixel_sum_rows(ctx, s->d_src, roi.d_list, roi.count, L.nt, o + L.src(r))) return rc;
             }
             if (int rc = pixel_sum_rows(ctx, fin, roi.d_list, roi.count, L.nt, o + L.fin(r))) return rc;
         }
