@@ -112,6 +112,12 @@ extern "C" void emu_fast_atan2(const float *y, const float *x, int n, float *out
     for (int i = 0; i < n; ++i) out[i] = thz::fast_atan2f(y[i], x[i]);
 }
 
+extern "C" void emu_div_const(const float *x, int n, float d, float *out)
+{
+    const thz::DivConst div(d);
+    for (int i = 0; i < n; ++i) out[i] = div(x[i]);
+}
+
 // ---- K15 voxel envelope (voxel.hip)
 extern "C" {
 

@@ -235,6 +235,28 @@ def test_fast_atan2_accuracy(emu):
     assert out[6] == 0.0 and abs(out[1] - np.pi) < 3e-7 and abs(out[3] + np.pi / 2) < 3e-7
 
 
+def test_div_const_edge_cases(emu):
+    """DivConst (thz_device.hpp: x / d in three instructions for a loop-invariant d): the correctly rounded
+    quotient for every finite operand with a normal quotient — and, documented there as outside its contract,
+    NaN for an infinite operand (IEEE: the infinity) and at most one ulp off in the denormal range"""
+    rng = np.random.default_rng(5)
+    for d in (1001.0, 777.0, 2000.0, 8191.0, 3.0):
+        x = (rng.standard_normal(200000) * 10 ** rng.uniform(-20, 20, 200000)).astype(np.float32)
+        out = np.empty_like(x)
+        emu.emu_div_const(_p(x), x.size, C.c_float(d), _p(out))
+        assert np.array_equal(out, x / np.float32(d))
+        edge = np.array([np.inf, -np.inf, 0.0, -0.0, np.nan], np.float32)
+        oe = np.empty_like(edge)
+        emu.emu_div_const(_p(edge), edge.size, C.c_float(d), _p(oe))
+        assert np.isnan(oe[0]) and np.isnan(oe[1]) and np.isnan(oe[4])          # the documented non-IEEE cases
+        assert oe[2] == 0.0 and oe[3] == 0.0                                      # (-0 comes back as +0: same value)
+        tiny = (rng.standard_normal(20000) * 1e-38).astype(np.float32)               # quotients in the denormal range
+        ot = np.empty_like(tiny)
+        emu.emu_div_const(_p(tiny), tiny.size, C.c_float(d), _p(ot))
+        ulp = np.float32(1.4e-45)
+        assert np.abs(ot.astype(np.float64) - (tiny / np.float32(d)).astype(np.float64)).max() <= float(ulp) * 1.01
+
+
 def _rl_reference(d, u, psf, mode):
     """one Richardson-Lucy iteration with the reference's loops (deconvolution.rs:432-458 for kernels of at
     most 256 elements: correlation-indexed, m outer / n inner, f32, no FMA; the 'same' true convolution the

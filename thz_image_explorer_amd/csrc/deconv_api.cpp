@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 
 using namespace thz;
 
@@ -43,7 +44,23 @@ struct DevFree {
             if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (!best || b.bytes < best->bytes)) best = &b;
         if (!best) {
             void *p = nullptr;
-            const hipError_t e = hipMalloc(&p, bytes);
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) {
+                // out of memory with blocks of another geometry still parked in the pool (a call that freed everything at
+                // its end would have succeeded here): give back every block nobody uses — and the chains' graphs, whose
+                // nodes point into them — and try once more
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(ctx->stream);
+                for (auto &g : ctx->dc_graph) g.drop();
+                auto &pool = ctx->dc_pool;
+                for (size_t i = 0; i < pool.size();) {
+                    if (!pool[i].in_use) {
+                        (void)hipFree(pool[i].p);
+                        pool.erase(pool.begin() + (long)i);
+                    } else ++i;
+                }
+                e = hipMalloc(&p, bytes);
+            }
             if (e != hipSuccess) {
                 *out = nullptr;
                 return e;
@@ -440,6 +457,12 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         }
         return first;
     };
+    // every way out of this function — error returns included — waits for the chains first: `mem` (declared above,
+    // destroyed after this guard) hands the blocks they work on back to the pool
+    struct ChainsDrained {
+        std::function<hipError_t()> wait;
+        ~ChainsDrained() { (void)wait(); }
+    } chains_drained{sync_chains};
     int *d_it = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_it, kRlChains * sizeof(int)));
     struct ChainGraphs {

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -47,8 +48,11 @@ bool rccl_load()
     Rccl &r = rccl();
     if (r.h) return true;
     // THZ_RCCL_LIB: developer knob — the library to open in RCCL's place (tests/mock_rccl: several ranks on ONE GPU)
-    if (const char *override_path = getenv("THZ_RCCL_LIB")) r.h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
-    else
+    if (const char *override_path = getenv("THZ_RCCL_LIB")) {
+        // never silent: a release process whose collectives go through something else than librccl says so
+        fprintf(stderr, "[thzgpu] THZ_RCCL_LIB is set: opening %s in place of librccl (test infrastructure)\n", override_path);
+        r.h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+    } else
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
@@ -103,6 +107,15 @@ struct thz_group_session {
     int root_local = -1;               // index of rank 0 among the local members, -1: another process has it
     // gathered copies on rank 0's device, allocated when first asked for
     float *d_img = nullptr, *d_data = nullptr, *d_fft = nullptr, *d_amp = nullptr, *d_ph = nullptr;
+    size_t cap_img = 0, cap_data = 0, cap_fft = 0, cap_amp = 0, cap_ph = 0;  // floats allocated
+    std::vector<size_t> cur_rows;      // rows of the outputs' grid per rank (the block grid behind a scaling stage)
+    size_t cur_ny = 0;
+    size_t cur_pix() const
+    {
+        size_t r = 0;
+        for (size_t v : cur_rows) r += v;
+        return r * cur_ny;
+    }
     size_t nt_out = 0;
     int gathered = -1;  // thz_gather level of the last recompute
 };
@@ -203,7 +216,8 @@ int thz_host_slab(size_t nx, int world, int rank, size_t *x0, size_t *n)
     return THZ_OK;
 }
 
-const char *thz_group_last_error(const thz_group *g) { return g ? g->err.c_str() : "null group"; }
+// g == NULL: why the last thz_group_create* / thz_group_unique_id could not load RCCL (there is no group to ask then)
+const char *thz_group_last_error(const thz_group *g) { return g ? g->err.c_str() : (rccl().err.empty() ? "null group" : rccl().err.c_str()); }
 int thz_group_world(const thz_group *g) { return g ? g->world : 0; }
 int thz_group_local_count(const thz_group *g) { return g ? (int)g->m.size() : 0; }
 int thz_group_rank(const thz_group *g, int i) { return (g && i >= 0 && i < (int)g->m.size()) ? g->m[i].rank : -1; }
@@ -398,6 +412,8 @@ int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, cons
         gs->sess.push_back(s);
         if (g->m[i].rank == 0) gs->root_local = (int)i;
     }
+    gs->cur_rows = gs->rows;
+    gs->cur_ny = ny;
     if (gs->root_local >= 0) {
         if (hipSetDevice(g->m[(size_t)gs->root_local].ctx->device) != hipSuccess
             || hipMalloc((void **)&gs->d_img, nx * ny * sizeof(float)) != hipSuccess) {
@@ -405,6 +421,7 @@ int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, cons
             thz_group_session_destroy(gs);
             return THZ_ERR_HIP;
         }
+        gs->cap_img = nx * ny;
     }
     *out = gs;
     return THZ_OK;
@@ -472,9 +489,10 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     thz_group *g = gs->g;
     if (gather < THZ_GATHER_SMALL || gather > THZ_GATHER_ALL || start_stage < 0 || start_stage > 8)
         return gfail(g, THZ_ERR_INVALID, "thz_group_session_recompute: bad gather level or chain position");
-    if (cfg->scale_factor > 1 || (cfg->tilt_active && (cfg->tilt_x_deg != 0.0 || cfg->tilt_y_deg != 0.0)) || cfg->want_means > 1)
+    const bool single = g->world == 1;  // one slab = the whole grid: everything a session does
+    if (!single && (cfg->scale_factor > 1 || (cfg->tilt_active && (cfg->tilt_x_deg != 0.0 || cfg->tilt_y_deg != 0.0)) || cfg->want_means > 1))
         return gfail(g, THZ_ERR_UNSUPPORTED,
-                     "a group session shards without a halo only: scale_factor 1, zero tilt, want_means 0 or 1 "
+                     "a group session of several slabs shards without a halo only: scale_factor 1, zero tilt, want_means 0 or 1 "
                      "(block means and the tilt's per-pixel shift depend on the position in the whole grid; "
                      "the reference-order means are sequential over all x rows)");
     if (start_stage == 8) return THZ_OK;
@@ -489,7 +507,12 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     const size_t nt_out = gs->sess.empty() ? gs->nt : gs->sess[0]->nt_out, nf = nt_out / 2 + 1;
     gs->nt_out = nt_out;
     // C2: the slabs' undivided amplitude / phase sums -> the cube's, on every member
-    if (cfg->want_means && !(tail.size() && tail[0])) {
+    if (cfg->want_means && !(tail.size() && tail[0]) && single && !gs->sess[0]->msum_fast) {
+        // the whole grid in one slab, means in the reference's order (want_means 2, or a tilted cube): nothing to exchange
+        int rc = session_means(gs->sess[0], cfg, gs->sess[0]->nx_cur * gs->sess[0]->ny_cur);
+        if (!rc) rc = session_avg_data(gs->sess[0], cfg);
+        if (rc) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[0].ctx));
+    } else if (cfg->want_means && !(tail.size() && tail[0])) {
         std::vector<float *> bufs;
         for (thz_session *s : gs->sess) {
             if (!s->msum_fast) return gfail(g, THZ_ERR_UNSUPPORTED, "slab means are not additive for this configuration");
@@ -498,7 +521,7 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
         if (int rc = thz_group_all_reduce_sum(g, bufs.data(), 2 * nf)) return rc;
         for (size_t i = 0; i < gs->sess.size(); ++i) {
             // Σ of the raw traces was all-reduced at upload; the copy in d_msum[0, nt) is already the cube's
-            int rc = session_means(gs->sess[i], cfg, gs->nx * gs->ny);
+            int rc = session_means(gs->sess[i], cfg, gs->cur_pix());
             if (!rc) rc = session_avg_data(gs->sess[i], cfg);
             if (rc) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[i].ctx));
         }
@@ -519,24 +542,39 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
         }
     }
     // C1: per-pixel results to rank 0
-    auto gather_buf = [&](int which, size_t per_pix, float **d_dst) -> int {
+    // the outputs' grid: the raw one, or — one slab, scaled — the session's block grid
+    gs->cur_rows = gs->rows;
+    gs->cur_ny = gs->ny;
+    if (single) {
+        gs->cur_rows[0] = gs->sess[0]->nx_cur;
+        gs->cur_ny = gs->sess[0]->ny_cur;
+    }
+    auto gather_buf = [&](int which, size_t per_pix, float **d_dst, size_t *cap) -> int {
         std::vector<const float *> send;
         std::vector<size_t> counts((size_t)g->world);
-        for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->rows[(size_t)q] * gs->ny * per_pix;
+        for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->cur_rows[(size_t)q] * gs->cur_ny * per_pix;
         for (thz_session *s : gs->sess) send.push_back(static_cast<const float *>(thz_session_buffer(s, which)));
-        if (gs->root_local >= 0 && !*d_dst) {
+        const size_t need = gs->cur_pix() * per_pix;
+        if (gs->root_local >= 0 && (!*d_dst || *cap < need)) {  // (a tilted cube's outputs are longer than the raw traces)
             GHIP_TRY(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
-            GHIP_TRY(g, hipMalloc((void **)d_dst, gs->nx * gs->ny * per_pix * sizeof(float)));
+            if (*d_dst) {
+                GHIP_TRY(g, hipStreamSynchronize(g->m[(size_t)gs->root_local].ctx->stream));
+                GHIP_TRY(g, hipFree(*d_dst));
+                *d_dst = nullptr;
+                *cap = 0;
+            }
+            GHIP_TRY(g, hipMalloc((void **)d_dst, need * sizeof(float)));
+            *cap = need;
         }
         return thz_group_gather(g, send.data(), counts.data(), *d_dst);
     };
-    if (int rc = gather_buf(THZ_BUF_IMG, 1, &gs->d_img)) return rc;
+    if (int rc = gather_buf(THZ_BUF_IMG, 1, &gs->d_img, &gs->cap_img)) return rc;
     if (gather >= THZ_GATHER_TIME)
-        if (int rc = gather_buf(THZ_BUF_DATA, nt_out, &gs->d_data)) return rc;
+        if (int rc = gather_buf(THZ_BUF_DATA, nt_out, &gs->d_data, &gs->cap_data)) return rc;
     if (gather >= THZ_GATHER_ALL) {
-        if (int rc = gather_buf(THZ_BUF_FFT, 2 * nf, &gs->d_fft)) return rc;
-        if (int rc = gather_buf(THZ_BUF_AMPLITUDES, nf, &gs->d_amp)) return rc;
-        if (int rc = gather_buf(THZ_BUF_PHASES, nf, &gs->d_ph)) return rc;
+        if (int rc = gather_buf(THZ_BUF_FFT, 2 * nf, &gs->d_fft, &gs->cap_fft)) return rc;
+        if (int rc = gather_buf(THZ_BUF_AMPLITUDES, nf, &gs->d_amp, &gs->cap_amp)) return rc;
+        if (int rc = gather_buf(THZ_BUF_PHASES, nf, &gs->d_ph, &gs->cap_ph)) return rc;
     }
     gs->gathered = gather;
     return thz_group_sync(g);
@@ -584,12 +622,36 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
     const size_t nl = gs->sess.size();
     for (thz_session *s : gs->sess)
         if (!s->have_outputs) return gfail(g, THZ_ERR_NOT_READY, "thz_group_session_deconvolve: no recompute has run");
-    const size_t nt = gs->nt_out, cube = gs->nx * gs->ny * nt;
+    if (g->world == 1 && !g->m[0].comm) {
+        // one slab = the whole grid: the session's own stage (no gather of the cube, no second copy of it), then C1
+        const int rc = thz_session_deconvolve(gs->sess[0], psf, cfg, abort_flag, progress);
+        if (rc < 0) return gfail(g, rc, std::string("thz_group_session_deconvolve: ") + thz_last_error(g->m[0].ctx));
+        thz_session *s = gs->sess[0];
+        const size_t npix = s->nx_cur * s->ny_cur;
+        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
+        GHIP_TRY(g, hipMemcpyAsync(gs->d_img, thz_session_buffer(s, THZ_BUF_IMG), npix * sizeof(float), hipMemcpyDeviceToDevice, g->m[0].ctx->stream));
+        if (gs->gathered >= THZ_GATHER_TIME && gs->d_data)
+            GHIP_TRY(g, hipMemcpyAsync(gs->d_data, thz_session_buffer(s, THZ_BUF_DATA), npix * gs->nt_out * sizeof(float), hipMemcpyDeviceToDevice,
+                                       g->m[0].ctx->stream));
+        if (int rc2 = thz_group_sync(g)) return rc2;
+        return rc;
+    }
+    // the outputs' grid (rows per rank in gs->cur_rows) and where each rank's rows start in it
+    std::vector<size_t> cur_x0((size_t)g->world, 0);
+    for (int q = 1; q < g->world; ++q) cur_x0[(size_t)q] = cur_x0[(size_t)q - 1] + gs->cur_rows[(size_t)q - 1];
+    const size_t grid_nx = gs->cur_pix() / (gs->cur_ny ? gs->cur_ny : 1), grid_ny = gs->cur_ny;
+    const size_t nt = gs->nt_out, cube = grid_nx * grid_ny * nt;
+    if (cfg->n_filters == 0 || cfg->n_iterations == 0) {
+        // rank-independent guards, checked before the bands are dealt out (an empty band range would read as "all bands"
+        // on every rank and the all-reduce below would return world x input): the stage passes its input through
+        for (thz_session *s : gs->sess) s->deconv_current = false;
+        return THZ_SKIPPED;
+    }
     // Richardson-Lucy is spatially global per band: every member needs the whole "Time Band Pass" output
     std::vector<float *> full(nl, nullptr), out(nl, nullptr), flag(nl, nullptr);
     std::vector<const float *> send(nl);
     std::vector<size_t> counts((size_t)g->world);
-    for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->rows[(size_t)q] * gs->ny * nt;
+    for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->cur_rows[(size_t)q] * grid_ny * nt;
     auto cleanup = [&]() {
         for (size_t i = 0; i < nl; ++i) {
             (void)hipSetDevice(g->m[i].ctx->device);
@@ -599,8 +661,17 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
             if (flag[i]) (void)hipFree(flag[i]);
         }
     };
+    // a HIP error past this point frees the whole-cube buffers before it returns
+#define GHIP_TRY_C(g, expr)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            cleanup();                                                                               \
+            return gfail(g, THZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+        }                                                                                            \
+    } while (0)
     for (size_t i = 0; i < nl; ++i) {
-        GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+        GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
         if (hipMalloc((void **)&full[i], cube * sizeof(float)) != hipSuccess || hipMalloc((void **)&out[i], cube * sizeof(float)) != hipSuccess
             || hipMalloc((void **)&flag[i], sizeof(float)) != hipSuccess) {
             cleanup();
@@ -626,7 +697,7 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
                 thz_session *s = gs->sess[i];
                 if (ctx->time.size() != nt || std::memcmp(ctx->time.data(), s->time_out.data(), nt * sizeof(float)) != 0)
                     if (int rc = thz_set_time_axis(ctx, s->time_out.data(), nt)) { rcs[i] = rc; return; }
-                rcs[i] = thz_deconvolve(ctx, psf, &c, gs->nx, gs->ny, s->dx, s->dy, full[i], out[i], nullptr, nullptr, abort_flag,
+                rcs[i] = thz_deconvolve(ctx, psf, &c, grid_nx, grid_ny, s->dx_cur, s->dy_cur, full[i], out[i], nullptr, nullptr, abort_flag,
                                         i == 0 ? progress : nullptr);
             });
         for (auto &t : th) t.join();
@@ -639,24 +710,24 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
     bool any_bad = false;
     {
         for (size_t i = 0; i < nl; ++i) {   // one float per member: 1 where the call failed or was aborted; summed over the group
-            GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+            GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
             const float v = rcs[i] < 0 ? 1.0f : 0.0f;
-            GHIP_TRY(g, hipMemcpyAsync(flag[i], &v, sizeof v, hipMemcpyHostToDevice, g->m[i].ctx->stream));
-            GHIP_TRY(g, hipStreamSynchronize(g->m[i].ctx->stream));
+            GHIP_TRY_C(g, hipMemcpyAsync(flag[i], &v, sizeof v, hipMemcpyHostToDevice, g->m[i].ctx->stream));
+            GHIP_TRY_C(g, hipStreamSynchronize(g->m[i].ctx->stream));
         }
         if (int rc = thz_group_all_reduce_sum(g, flag.data(), 1)) { cleanup(); return rc; }
         float v = 0.0f;
-        GHIP_TRY(g, hipSetDevice(g->m[0].ctx->device));
-        GHIP_TRY(g, hipMemcpyAsync(&v, flag[0], sizeof v, hipMemcpyDeviceToHost, g->m[0].ctx->stream));
-        GHIP_TRY(g, hipStreamSynchronize(g->m[0].ctx->stream));
+        GHIP_TRY_C(g, hipSetDevice(g->m[0].ctx->device));
+        GHIP_TRY_C(g, hipMemcpyAsync(&v, flag[0], sizeof v, hipMemcpyDeviceToHost, g->m[0].ctx->stream));
+        GHIP_TRY_C(g, hipStreamSynchronize(g->m[0].ctx->stream));
         any_bad = v != 0.0f;
     }
     int status = all_skipped ? THZ_SKIPPED : THZ_OK;
     if (any_bad) {
         for (size_t i = 0; i < nl; ++i) {
-            GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
-            if (g->m[i].rank == 0) GHIP_TRY(g, hipMemcpyAsync(out[i], full[i], cube * sizeof(float), hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
-            else GHIP_TRY(g, hipMemsetAsync(out[i], 0, cube * sizeof(float), g->m[i].ctx->stream));
+            GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
+            if (g->m[i].rank == 0) GHIP_TRY_C(g, hipMemcpyAsync(out[i], full[i], cube * sizeof(float), hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
+            else GHIP_TRY_C(g, hipMemsetAsync(out[i], 0, cube * sizeof(float), g->m[i].ctx->stream));
         }
         status = THZ_ERR_ABORTED;
         for (size_t i = 0; i < nl; ++i)
@@ -667,8 +738,8 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
     for (size_t i = 0; i < nl; ++i) {
         thz_session *s = gs->sess[i];
         thz_ctx *ctx = g->m[i].ctx;
-        GHIP_TRY(g, hipSetDevice(ctx->device));
-        const size_t q = (size_t)g->m[i].rank, n = counts[q], npix = gs->rows[q] * gs->ny;
+        GHIP_TRY_C(g, hipSetDevice(ctx->device));
+        const size_t q = (size_t)g->m[i].rank, n = counts[q], npix = gs->cur_rows[q] * grid_ny;
         if (s->deconv_floats != n) {
             if (s->d_deconv) { (void)hipFree(s->d_deconv); s->d_deconv = nullptr; }
             if (s->d_deconv_img) { (void)hipFree(s->d_deconv_img); s->d_deconv_img = nullptr; }
@@ -680,7 +751,7 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
             }
             s->deconv_floats = n;
         }
-        GHIP_TRY(g, hipMemcpyAsync(s->d_deconv, out[i] + gs->x0[q] * gs->ny * nt, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        GHIP_TRY_C(g, hipMemcpyAsync(s->d_deconv, out[i] + cur_x0[q] * grid_ny * nt, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         if (int rc = thz_intensity(ctx, npix, s->d_deconv, s->d_deconv_img)) { cleanup(); return gfail(g, rc, thz_last_error(ctx)); }
         s->deconv_current = status >= 0;
     }
@@ -688,16 +759,17 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
     {
         std::vector<const float *> im;
         std::vector<size_t> ic((size_t)g->world);
-        for (int q = 0; q < g->world; ++q) ic[(size_t)q] = gs->rows[(size_t)q] * gs->ny;
+        for (int q = 0; q < g->world; ++q) ic[(size_t)q] = gs->cur_rows[(size_t)q] * grid_ny;
         for (thz_session *s : gs->sess) im.push_back(s->deconv_current ? s->d_deconv_img : s->d_img);
         if (int rc = thz_group_gather(g, im.data(), ic.data(), gs->d_img)) { cleanup(); return rc; }
         if (gs->gathered >= THZ_GATHER_TIME && gs->root_local >= 0) {
-            GHIP_TRY(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
-            GHIP_TRY(g, hipMemcpyAsync(gs->d_data, out[(size_t)gs->root_local], cube * sizeof(float), hipMemcpyDeviceToDevice,
+            GHIP_TRY_C(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
+            GHIP_TRY_C(g, hipMemcpyAsync(gs->d_data, out[(size_t)gs->root_local], cube * sizeof(float), hipMemcpyDeviceToDevice,
                                        g->m[(size_t)gs->root_local].ctx->stream));
         }
     }
     cleanup();
+#undef GHIP_TRY_C
     // the regions of interest's means of the FINAL traces follow the stage's output (data_thread.rs:1445-1451)
     if (!gs->sess[0]->rois.empty() && gs->sess[0]->have_last_cfg) {
         std::vector<float *> bufs;
@@ -752,7 +824,7 @@ int thz_group_session_download(thz_group_session *gs, int which, size_t pix0, si
     case THZ_BUF_AMPLITUDES: case THZ_BUF_PHASES: per = nf; break;
     default: return THZ_ERR_INVALID;
     }
-    if (pix0 > gs->nx * gs->ny || npix > gs->nx * gs->ny - pix0) return gfail(g, THZ_ERR_INVALID, "pixel range out of bounds");
+    if (pix0 > gs->cur_pix() || npix > gs->cur_pix() - pix0) return gfail(g, THZ_ERR_INVALID, "pixel range out of bounds");
     return thz_memcpy_d2h(g->m[(size_t)gs->root_local].ctx, dst, base + pix0 * per, npix * per * sizeof(float));
 }
 

@@ -195,6 +195,9 @@ __device__ __forceinline__ float launder_f(float x)
 // q' is the correctly rounded quotient (Markstein 1990; no mismatch against `x / d` in 1.4e9 random operands
 // for d = 777 ... 8191) in three instructions instead of the eleven of the generic IEEE sequence (v_div_scale x2,
 // v_rcp, four FMAs, v_div_fmas, v_div_fixup) — which was 14 % of the nt = 1001 chain's instruction issue.
+// PRECONDITION: finite x whose quotient is a normal number (what samples of a scan divided by a trace length are).
+// x = +-Inf gives NaN where IEEE division gives +-Inf (r = Inf - Inf), -0 comes back as +0, and a quotient in the
+// denormal / flushed range can be one ulp off; the emulation test pins both cases (test_emu_kernels.py::test_div_const_edge_cases).
 struct DivConst {
     float d, rcp;
     __device__ __forceinline__ explicit DivConst(float divisor) : d(divisor), rcp(1.0f / divisor) {}
