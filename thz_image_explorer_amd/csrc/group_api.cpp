@@ -506,6 +506,13 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     }
     const size_t nt_out = gs->sess.empty() ? gs->nt : gs->sess[0]->nt_out, nf = nt_out / 2 + 1;
     gs->nt_out = nt_out;
+    // the outputs' grid: the raw one, or — one slab, scaled — the session's block grid
+    gs->cur_rows = gs->rows;
+    gs->cur_ny = gs->ny;
+    if (single) {
+        gs->cur_rows[0] = gs->sess[0]->nx_cur;
+        gs->cur_ny = gs->sess[0]->ny_cur;
+    }
     // C2: the slabs' undivided amplitude / phase sums -> the cube's, on every member
     if (cfg->want_means && !(tail.size() && tail[0]) && single && !gs->sess[0]->msum_fast) {
         // the whole grid in one slab, means in the reference's order (want_means 2, or a tilted cube): nothing to exchange
@@ -542,13 +549,6 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
         }
     }
     // C1: per-pixel results to rank 0
-    // the outputs' grid: the raw one, or — one slab, scaled — the session's block grid
-    gs->cur_rows = gs->rows;
-    gs->cur_ny = gs->ny;
-    if (single) {
-        gs->cur_rows[0] = gs->sess[0]->nx_cur;
-        gs->cur_ny = gs->sess[0]->ny_cur;
-    }
     auto gather_buf = [&](int which, size_t per_pix, float **d_dst, size_t *cap) -> int {
         std::vector<const float *> send;
         std::vector<size_t> counts((size_t)g->world);
