@@ -1,76 +1,36 @@
-//! "Time Band Pass (after)" (`src/filters/band_pass_td_after_fft.rs`): same struct, UI and config; `filter()` records low / high / width
-//! (clamped like `:137-138`) and the engine multiplies by the vector of `thz_host_td_bandpass` (zero outside
-//! [lower, upper), adapted-Blackman taper inside, `:124-182`) — inside the fused launch.  UNVERIFIED BY A COMPILER.
-use crate::config::ThreadCommunication;
-use crate::data_container::ScannedImageFilterData;
-use crate::filters::filter::{CopyStaticFieldsTrait, Filter, FilterConfig, FilterDomain};
-use crate::gpu::engine::ENGINE;
-use crate::gui::application::GuiSettingsContainer;
-use crate::math_tools_gpu::shallow_clone;
-use bevy_egui::egui::{self, Ui};
-use filter_macros::{register_filter, CopyStaticFields};
-use ndarray::Array1;
-use std::sync::atomic::AtomicBool;
-use std::sync::{Arc, RwLock};
+//! "Time Band Pass" (after the inverse FFT) on the engine — REPLACES ONLY the bodies of `filter()` and `show_data()`
+//! in `src/filters/band_pass_td_after_fft.rs`.  The struct, `new`, `reset`, `config`, `ui` and the unit tests stay
+//! VERBATIM.  Transliteration of `GpuTimeDomainBandPassAfterFFT` (`thz_image_explorer_amd/host/thz_engine.cpp`, tested
+//! by `tests/test_gpu_engine.py`); UNVERIFIED BY A COMPILER.
+//!
+//! Add to the file's imports:
+//!     use crate::gpu::engine::ENGINE;
+//!     use crate::gpu::ffi::thz_host_td_bandpass;
+//!     use crate::math_tools_gpu::{empty_plot_out, shallow_clone};
 
-#[register_filter]
-#[derive(Clone, Debug, CopyStaticFields)]
-pub struct TimeDomainBandPassAfterFFT {
-    pub low: f64,
-    pub high: f64,
-    pub window_width: f64,
-    #[static_field]
-    time_axis: Vec<f32>,
-    #[static_field]
-    signal_axis: Vec<f32>,
-    #[static_field]
-    input_signal_axis: Vec<f32>,
-}
-
-impl Filter for TimeDomainBandPassAfterFFT {
-    fn new() -> Self where Self: Sized {
-        TimeDomainBandPassAfterFFT { low: 0.0, high: 0.0, window_width: 0.1, time_axis: vec![], signal_axis: vec![], input_signal_axis: vec![] }
-    }
-
-    /// full range of the new file's axis (band_pass_td_after_fft.rs:66-72)
-    fn reset(&mut self, time: &Array1<f32>, _shape: &[usize]) {
-        if let (Some(first), Some(last)) = (time.first(), time.last()) {
-            self.low = *first as f64;
-            self.high = *last as f64;
-        }
-        self.time_axis = time.to_vec();
-    }
-
+    /// Called AFTER the recompute (deferred): the selected pixel's trace of this stage's output = the chain's final
+    /// trace (this is the last stage in front of the Deconvolution)
     fn show_data(&mut self, data: &ScannedImageFilterData) {
+        if data.width == 0 || data.height == 0 || data.time.is_empty() { return; }
+        let eng = ENGINE.lock().unwrap();
+        if !eng.available() { drop(eng); return self.show_data_cpu(data); }
         self.time_axis = data.time.to_vec();
-        let mut trace = vec![0f32; data.time.len()];
-        let out = crate::gpu::ffi::ThzPlotOut {
-            signal: std::ptr::null_mut(), signal_fft: std::ptr::null_mut(), phase_fft: std::ptr::null_mut(),
-            filtered_signal: trace.as_mut_ptr(), filtered_signal_fft: std::ptr::null_mut(),
-            filtered_phase_fft: std::ptr::null_mut(), avg_signal: std::ptr::null_mut(),
-            avg_signal_fft: std::ptr::null_mut(), avg_phase_fft: std::ptr::null_mut(),
-        };
-        if ENGINE.lock().unwrap().plot(data.pixel_selected[0], data.pixel_selected[1], &out).is_ok() {
-            self.signal_axis = trace;
+        let mut v = vec![0f32; eng.nt_out()];
+        let mut po = empty_plot_out();
+        po.filtered_signal = v.as_mut_ptr();
+        if eng.plot(data.pixel_selected[0] * data.scaling, data.pixel_selected[1] * data.scaling, &po) {
+            self.signal_axis = v.clone();
+            self.input_signal_axis = v;
         }
     }
 
-    fn config(&self) -> FilterConfig {
-        FilterConfig { name: "Time Band Pass (after)".to_string(), description: "Band Pass Filter in Time Domain.".to_string(),
-                       hyperlink: None, domain: FilterDomain::TimeAfterFFT }
-    }
-
-    fn filter(&mut self, input_data: &ScannedImageFilterData, _gui_settings: &mut GuiSettingsContainer,
-              _progress_lock: &mut Arc<RwLock<Option<f32>>>, _abort_flag: &Arc<AtomicBool>) -> ScannedImageFilterData {
+    fn filter(&mut self, input_data: &ScannedImageFilterData, gui_settings: &mut GuiSettingsContainer,
+              progress_lock: &mut Arc<RwLock<Option<f32>>>, abort_flag: &Arc<AtomicBool>) -> ScannedImageFilterData {
         let mut eng = ENGINE.lock().unwrap();
-        if !eng.available() { return input_data.clone(); }
+        if !eng.available() { drop(eng); return self.filter_cpu(input_data, gui_settings, progress_lock, abort_flag); }
+        let t = input_data.time.as_slice().unwrap();
+        let mut w = vec![0f32; t.len()];
+        unsafe { thz_host_td_bandpass(t.as_ptr(), t.len(), &mut self.low, &mut self.high, self.window_width, w.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()); }
         eng.record_td_after(true, self.low, self.high, self.window_width);
         shallow_clone(input_data)
     }
-
-    fn ui(&mut self, ui: &mut Ui, _thread_communication: &mut ThreadCommunication, _panel_width: f32) -> egui::Response {
-        // unchanged from the reference: double slider over time_axis + trace plot
-        crate::filters::band_pass_td_ui::draw(&mut self.low, &mut self.high, &mut self.window_width, &self.time_axis,
-                                              &self.signal_axis, &self.input_signal_axis, ui)
-    }
-}

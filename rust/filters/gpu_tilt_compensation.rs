@@ -1,67 +1,34 @@
-//! "Tilt Compensation" (`src/filters/tilt_compensation.rs`): same struct, UI and config; `filter()` records the
-//! two angles.  Zero tilt is just the tail taper (`:186-188`), which the engine folds into the fused launch's
-//! pre-transform multiplier; a non-zero tilt re-lays the cube out on the extended axis on the device
-//! (`thz_host_tilt_plan` + `thz_tilt_apply`, geometry `:104-175`, hard-coded dt = 0.05 ps `:122`) and the chain
-//! continues at the new length — the container's `time` / `frequency` then come from `thz_session_time_out`.
-//! UNVERIFIED BY A COMPILER.
-use crate::config::ThreadCommunication;
-use crate::data_container::ScannedImageFilterData;
-use crate::filters::filter::{CopyStaticFieldsTrait, Filter, FilterConfig, FilterDomain};
-use crate::gpu::engine::ENGINE;
-use crate::gpu::ffi::thz_host_tilt_plan;
-use crate::gui::application::GuiSettingsContainer;
-use crate::math_tools_gpu::shallow_clone;
-use bevy_egui::egui::{self, Ui};
-use filter_macros::{register_filter, CopyStaticFields};
-use ndarray::Array1;
-use std::sync::atomic::AtomicBool;
-use std::sync::{Arc, RwLock};
+//! "Tilt Compensation" on the engine — REPLACES ONLY the body of `filter()` in `src/filters/tilt_compensation.rs`
+//! (`:97-226`).  The struct, `new`, `reset`, `show_data`, `config`, `ui` and the unit tests of that file stay
+//! VERBATIM.  Transliteration of `GpuTiltCompensation::filter` (`thz_image_explorer_amd/host/thz_engine.cpp`, tested by
+//! `tests/test_gpu_engine.py`); UNVERIFIED BY A COMPILER.
+//!
+//! Add to the file's imports:
+//!     use crate::gpu::engine::ENGINE;
+//!     use crate::gpu::ffi::{thz_host_frequency_axis, thz_host_tilt_plan};
+//!     use crate::math_tools_gpu::shallow_clone;
 
-#[register_filter]
-#[derive(Clone, Debug, CopyStaticFields)]
-pub struct TiltCompensation {
-    pub tilt_x: f64,
-    pub tilt_y: f64,
-}
-
-impl Filter for TiltCompensation {
-    fn new() -> Self where Self: Sized { TiltCompensation { tilt_x: 0.0, tilt_y: 0.0 } }
-    fn reset(&mut self, _time: &Array1<f32>, _shape: &[usize]) {}
-    fn show_data(&mut self, _data: &ScannedImageFilterData) {}
-
-    fn config(&self) -> FilterConfig {
-        FilterConfig { name: "Tilt Compensation".to_string(),
-                       description: "Compensate any misalignment along x axis and y axis.".to_string(),
-                       hyperlink: None, domain: FilterDomain::TimeBeforeFFTPrioFirst }
-    }
-
-    fn filter(&mut self, input_data: &ScannedImageFilterData, _gui_settings: &mut GuiSettingsContainer,
-              _progress_lock: &mut Arc<RwLock<Option<f32>>>, _abort_flag: &Arc<AtomicBool>) -> ScannedImageFilterData {
+    fn filter(&mut self, input_data: &ScannedImageFilterData, gui_settings: &mut GuiSettingsContainer,
+              progress_lock: &mut Arc<RwLock<Option<f32>>>, abort_flag: &Arc<AtomicBool>) -> ScannedImageFilterData {
         let mut eng = ENGINE.lock().unwrap();
-        if !eng.available() { return input_data.clone(); }
+        if !eng.available() { drop(eng); return self.filter_cpu(input_data, gui_settings, progress_lock, abort_flag); } // the reference's body, kept as `filter_cpu`
+        let (dx, dy) = match (input_data.dx, input_data.dy) { (Some(dx), Some(dy)) => (dx, dy), _ => return input_data.clone() }; // :111
         eng.record_tilt(true, self.tilt_x, self.tilt_y);
         let mut output = shallow_clone(input_data);
-        // the extended axis, so that the stage loop's re-plan check (data_thread.rs:1194-1227) sees the new length
+        // the extended axis (:104-170, 206-217): the containers behind this stage carry it; the device lays the cube
+        // out on it with the same plan (thz_host_tilt_plan: extension, per-pixel insert index)
         let t = input_data.time.as_slice().unwrap();
-        let (dx, dy) = (input_data.dx.unwrap_or(1.0), input_data.dy.unwrap_or(1.0));
-        let steps = unsafe { thz_host_tilt_plan(t.as_ptr(), t.len(), input_data.width, input_data.height, self.tilt_x, self.tilt_y,
-                                                dx, dy, std::ptr::null_mut(), std::ptr::null_mut()) };
+        let steps = unsafe { thz_host_tilt_plan(t.as_ptr(), t.len(), input_data.width, input_data.height, self.tilt_x, self.tilt_y, dx, dy,
+                                                std::ptr::null_mut(), std::ptr::null_mut()) };
         if steps > 0 {
             let mut new_time = vec![0f32; t.len() + 2 * steps];
-            unsafe { thz_host_tilt_plan(t.as_ptr(), t.len(), input_data.width, input_data.height, self.tilt_x, self.tilt_y,
-                                        dx, dy, new_time.as_mut_ptr(), std::ptr::null_mut()); }
+            unsafe { thz_host_tilt_plan(t.as_ptr(), t.len(), input_data.width, input_data.height, self.tilt_x, self.tilt_y, dx, dy,
+                                        new_time.as_mut_ptr(), std::ptr::null_mut()); }
+            let mut freq = vec![0f32; new_time.len() / 2 + 1];
+            unsafe { thz_host_frequency_axis(new_time.as_ptr(), new_time.len(), freq.as_mut_ptr()); }
             output.time = Array1::from(new_time);
+            output.frequency = Array1::from(freq);
+            // (the data thread re-plans r2c / c2r for the new length itself, data_thread.rs:1194-1227)
         }
         output
     }
-
-    fn ui(&mut self, ui: &mut Ui, _thread_communication: &mut ThreadCommunication, _panel_width: f32) -> egui::Response {
-        let mut final_response = ui.allocate_response(egui::Vec2::ZERO, egui::Sense::hover());
-        let rx = ui.horizontal(|ui| { ui.label("Tilt X: "); ui.add(egui::Slider::new(&mut self.tilt_x, -15.0..=15.0).suffix(" deg")) }).inner;
-        let ry = ui.horizontal(|ui| { ui.label("Tilt Y: "); ui.add(egui::Slider::new(&mut self.tilt_y, -15.0..=15.0).suffix(" deg")) }).inner;
-        final_response |= rx.clone();
-        final_response |= ry.clone();
-        if rx.changed() || ry.changed() { final_response.mark_changed(); }
-        final_response
-    }
-}

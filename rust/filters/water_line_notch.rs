@@ -2,6 +2,9 @@
 //! BASELINE config 3 names a water-line filter).  `FilterDomain::Frequency`, behind "Frequency Band Pass":
 //!     m[k] = prod_i (1 - exp(-((f_k - line_i) / sigma)^2))   over the 135 lines of assets/water_lines.csv
 //! a real per-bin multiplier applied in the engine's fused launch like the band pass itself.
+//! Transliteration of `WaterLineNotch` (`thz_image_explorer_amd/host/thz_engine.cpp`, tested by `tests/test_gpu_engine.py`:
+//! switched on, the walk's output is the band pass times the notch; switched off — the data thread then calls
+//! `note_inactive` instead of `filter()` — it is gone again).  A complete new file: list it in `src/filters/mod.rs:23-47`.
 //! UNVERIFIED BY A COMPILER.
 use crate::config::ThreadCommunication;
 use crate::data_container::ScannedImageFilterData;
@@ -47,7 +50,7 @@ impl Filter for WaterLineNotch {
         let f = input_data.frequency.as_slice().unwrap();
         let mut m = vec![1f32; f.len()];
         unsafe { thz_host_water_line_mask(f.as_ptr(), f.len(), self.lines_thz.as_ptr(), self.lines_thz.len(), self.sigma_thz, m.as_mut_ptr()); }
-        eng.record_fd_plugins(Some(m), None);
+        eng.record_water_lines(true, m);
         shallow_clone(input_data)
     }
 

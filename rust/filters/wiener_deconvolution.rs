@@ -5,7 +5,10 @@
 //! axis, windowed with the reference file's own axis, transformed with the scan's plan: `data_thread.rs:405-533`
 //! = `thz_reference_spectrum`).  The complex per-bin multiplier rides inside the engine's fused launch
 //! (imaginary parts of bin 0 / Nyquist forced to 0: realfft's C2R precondition, `math_tools.rs:510-512`).
-//! UNVERIFIED BY A COMPILER.
+//! The plugin's NAME must not contain "Deconvolution": the data thread treats every filter whose name does as the
+//! Richardson-Lucy stage that only runs when it is the one being updated (`data_thread.rs:1139-1149`).
+//! Transliteration of `WienerDeconvolution` (`thz_image_explorer_amd/host/thz_engine.cpp`).  A complete new file: list it
+//! in `src/filters/mod.rs:23-47`.  UNVERIFIED BY A COMPILER.
 use crate::config::ThreadCommunication;
 use crate::data_container::ScannedImageFilterData;
 use crate::filters::filter::{CopyStaticFieldsTrait, Filter, FilterConfig, FilterDomain};
@@ -34,7 +37,7 @@ impl Filter for WienerDeconvolution {
     fn show_data(&mut self, _data: &ScannedImageFilterData) {}
 
     fn config(&self) -> FilterConfig {
-        FilterConfig { name: "Reference Wiener Deconvolution".to_string(),
+        FilterConfig { name: "Reference Wiener Filter".to_string(),
                        description: "Divides every spectrum by the reference pulse's (Wiener-regularised).".to_string(),
                        hyperlink: None, domain: FilterDomain::Frequency }
     }
@@ -47,7 +50,11 @@ impl Filter for WienerDeconvolution {
         // R[k] = amp[k] exp(i phase[k]) from OpenRef's vectors (length nt, the first nf filled: data_thread.rs:486-533)
         let (amp, ph) = match (input_data.roi_signal_fft.get(&self.reference_key), input_data.roi_phase_fft.get(&self.reference_key)) {
             (Some((_, a)), Some((_, p))) if a.len() >= nf && p.len() >= nf => (a, p),
-            _ => { log::warn!("Wiener deconvolution: no reference pulse loaded, stage passes its input through"); return shallow_clone(input_data); }
+            _ => {
+                log::warn!("Wiener filter: no reference pulse loaded, the stage passes its input through");
+                eng.record_wiener(false, vec![]);
+                return shallow_clone(input_data);
+            }
         };
         let mut r = vec![0f32; 2 * nf];
         for k in 0..nf {
@@ -56,7 +63,7 @@ impl Filter for WienerDeconvolution {
         }
         let mut h = vec![0f32; 2 * nf];
         unsafe { thz_host_wiener_filter(r.as_ptr(), nf, self.eps_rel, h.as_mut_ptr()); }
-        eng.record_fd_plugins(None, Some(h));
+        eng.record_wiener(true, h);
         shallow_clone(input_data)
     }
 

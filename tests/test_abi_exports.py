@@ -81,3 +81,58 @@ def test_rust_ffi_is_current_and_complete():
             if f.endswith(".rs") and f != "ffi.rs":
                 used = set(re.findall(r"\b(thz_[a-z0-9_]+)\s*\(", open(os.path.join(root, f)).read()))
                 assert used <= fns, f"{f}: {sorted(used - fns)}"
+
+
+RUST = os.path.join(ROOT, "rust")
+
+
+def _rust_sources():
+    out = {}
+    for root, _, files in os.walk(RUST):
+        for f in files:
+            if f.endswith((".rs", ".patch")):
+                out[os.path.relpath(os.path.join(root, f), RUST)] = open(os.path.join(root, f)).read()
+    return out
+
+
+def test_rust_binding_calls_only_what_exists():
+    """No Rust toolchain here, so what a compiler would catch first is checked by text: every engine method the
+    plugins / math_tools_gpu / the data-thread patch call exists in engine.rs, every math_tools_gpu function they
+    call exists there, and engine.rs is the transliteration of the C++ engine that IS built and tested
+    (thz_image_explorer_amd/host/thz_engine.hpp: same method names)"""
+    src = _rust_sources()
+    engine_fns = set(re.findall(r"pub fn (\w+)\s*[(<]", src["engine.rs"]))
+    mt_fns = set(re.findall(r"pub fn (\w+)\s*[(<]", src["math_tools_gpu.rs"]))
+    for name, text in src.items():
+        if name in ("ffi.rs", "engine.rs"):
+            continue
+        code = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith(("//", "+ //", "+//")))
+        used = set(re.findall(r"\beng\.(\w+)\(", code)) | set(re.findall(r"ENGINE\.lock\(\)\.unwrap\(\)\.(\w+)\(", code))
+        assert used <= engine_fns, f"{name}: engine methods that do not exist: {sorted(used - engine_fns)}"
+        used_mt = set(re.findall(r"math_tools_gpu::(\w+)\(", code))
+        assert used_mt <= mt_fns, f"{name}: math_tools_gpu functions that do not exist: {sorted(used_mt - mt_fns)}"
+        for imp in re.findall(r"use crate::math_tools_gpu::\{([^}]*)\}", text) + re.findall(r"use crate::math_tools_gpu::(\w+);", text):
+            for fn in [x.strip() for x in imp.split(",") if x.strip()]:
+                assert fn in mt_fns, f"{name} imports math_tools_gpu::{fn}"
+    hpp = open(os.path.join(ROOT, "thz_image_explorer_amd", "host", "thz_engine.hpp")).read()
+    cpp_methods = set(re.findall(r"\b(\w+)\s*\(", hpp))
+    twin = engine_fns - {"new", "chain_position_of_domain", "chain_position_of_id", "voxels"}
+    assert twin <= cpp_methods, f"engine.rs methods without a C++ twin: {sorted(twin - cpp_methods)}"
+    # no plugin file refers to UI modules that exist nowhere (VERDICT r2)
+    for name, text in src.items():
+        assert "band_pass_fd_ui" not in text and "band_pass_td_ui" not in text, name
+
+
+def test_data_thread_patch_applies_to_the_reference():
+    ref = "/root/reference/src/data_thread.rs"
+    if not os.path.exists(ref):
+        pytest.skip("the reference is not on this machine")
+    import shutil
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "src"))
+        shutil.copy(ref, os.path.join(d, "src", "data_thread.rs"))
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(RUST, "data_thread.patch")], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and "FAILED" not in r.stdout and "fuzz" not in r.stdout, r.stdout
