@@ -599,8 +599,12 @@ typedef enum thz_gather {
     THZ_GATHER_ALL = 2    /* + spectrum, amplitudes, phases: a complete ScannedImageFilterData on rank 0 */
 } thz_gather;
 
-/* A session over a group: member i keeps slab i of the raw cube and of every output resident.  Restricted to
- * what shards without a halo: scale_factor 1, zero tilt, want_means 0 or 1 (others: THZ_ERR_UNSUPPORTED). */
+/* A session over a group: member i keeps slab i of the raw cube and of every output resident.  Everything a session
+ * does shards (round 3): a non-zero tilt (the plan is made for the whole grid), scale_factor > 1 (a block of s x s
+ * pixels whose rows lie in two slabs belongs to the slab that holds its LAST row: the slab in front hands over the
+ * partial sums of its rows, the sum continues in the reference's order — THZ_ERR_UNSUPPORTED only when a slab has
+ * fewer rows than the scale factor), want_means 2 (the reference's sequential means, slab after slab on a carried
+ * running sum: bit for bit one session's, serial by construction). */
 typedef struct thz_group_session thz_group_session;
 int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, const float *time, float dx, float dy,
                              thz_group_session **out);
@@ -633,6 +637,9 @@ int thz_group_session_roi(thz_group_session *gs, size_t roi, const thz_roi_out *
  * THZ_GATHER_TIME / ALL; THZ_BUF_FFT / AMPLITUDES / PHASES with ALL; THZ_BUF_AVG_* (on every member these
  * are also in its slab session).  NULL when absent or when this process does not drive rank 0. */
 void *thz_group_session_result(thz_group_session *gs, int which);
+/* the whole grid of the last recompute's outputs (thz_session_grid over all slabs): (nx, ny) of the raw grid, or
+ * behind a scaling stage (nx / s, ny / s); what the gathered buffers and thz_group_session_download index */
+int thz_group_session_grid(const thz_group_session *gs, size_t *nx, size_t *ny);
 int thz_group_session_download(thz_group_session *gs, int which, size_t pix0, size_t npix, void *dst);
 
 /* Plot copy-out of UpdateType::Plot (data_thread.rs:1337-1432): everything the

@@ -318,9 +318,21 @@ impl GpuEngine {
     /// `UpdateType::Plot` copy-out for pixel (px, py) of the RAW grid (`data_thread.rs:1337-1432`)
     pub fn plot(&self, px: usize, py: usize, out: &ThzPlotOut) -> bool {
         if self.session.is_null() { return false; }
-        match self.owner_of(px) {
-            Some((s, lx)) => unsafe { thz_session_plot(s, lx, py, out) == THZ_OK },
-            None => false,
+        let (s, lx) = match self.owner_of(px) { Some(v) => v, None => return false };
+        let sf = if self.pending.scale_factor > 1 { self.pending.scale_factor as usize } else { 1 };
+        unsafe {
+            if sf == 1 || thz_group_world(self.group) == 1 { return thz_session_plot(s, lx, py, out) == THZ_OK; }
+            // Several slabs behind a scaling stage: the raw trace comes from the slab that holds row px, everything else
+            // from the slab that holds the pixel's BLOCK — the one with the block's last raw row
+            let mut raw = crate::math_tools_gpu::empty_plot_out();
+            raw.signal = out.signal;
+            if !out.signal.is_null() && thz_session_plot(s, lx, py, &raw) != THZ_OK { return false; }
+            let mut rest = ThzPlotOut { ..*out };
+            rest.signal = ptr::null_mut();
+            match self.owner_of((px / sf) * sf + sf - 1) {
+                Some((sb, lb)) => thz_session_plot(sb, lb, py, &rest) == THZ_OK,
+                None => false,
+            }
         }
     }
 

@@ -13,6 +13,7 @@
 
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -117,37 +118,36 @@ ncclResult_t flush()
     std::vector<std::pair<ncclComm *, Op>> q;
     q.swap(g_queue);
     bool ok = true;
-    ncclComm *pc = nullptr;
-    for (auto &e : q)
-        if (e.second.kind >= 2) pc = e.first;
-    // Every rank of a communicator reaches its group end, with or without messages of its own, when ANY rank has
-    // point-to-point traffic?  Not in general — so the point-to-point phase is entered only by ranks that posted a
-    // send or a receive, and the library's use (thz_group_gather: every rank != 0 sends, rank 0 receives from each)
-    // has all ranks of the communicator in it unless a count is zero.  Counts are never zero in the tests.
-    if (pc) {
-        for (auto &e : q) {
-            const Op &op = e.second;
-            if (op.kind != 2) continue;
-            ncclComm *c = e.first;
-            const size_t bytes = op.count * type_bytes(op.type);
-            size_t &used = c->sh->mail_used[c->rank][op.peer];
-            if (used + bytes > kSlotBytes) { std::fprintf(stderr, "mock rccl: mailbox overflow\n"); ok = false; continue; }
-            if (hipStreamSynchronize(op.stream) != hipSuccess || hipMemcpy(c->mail(c->rank, op.peer) + used, op.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-            used += bytes;
+    // Point-to-point traffic is pairwise, like RCCL's: only the two ranks of a message take part (round 3: the
+    // library's chained reference-order means and its block sums over slab edges talk rank q -> q + 1 while the other
+    // ranks do something else).  One mailbox per ordered pair with a "bytes waiting" word: the sender waits until it
+    // is empty, fills it and publishes the size; the receiver waits for a size, drains it and clears the word.  Ops
+    // run in posting order (the library posts at most one message per pair and direction in a group).
+    for (auto &e : q) {
+        const Op &op = e.second;
+        if (op.kind < 2) continue;
+        ncclComm *c = e.first;
+        const size_t bytes = op.count * type_bytes(op.type);
+        if (bytes > kSlotBytes) { std::fprintf(stderr, "mock rccl: mailbox overflow\n"); ok = false; continue; }
+        if (hipStreamSynchronize(op.stream) != hipSuccess) ok = false;
+        if (op.kind == 2) {
+            volatile size_t *used = &c->sh->mail_used[c->rank][op.peer];
+            long spins = 0;
+            while (*used != 0 && ++spins < 120000000L) sched_yield();
+            if (*used != 0) { std::fprintf(stderr, "mock rccl: send %d -> %d never drained\n", c->rank, op.peer); ok = false; continue; }
+            if (hipMemcpy(c->mail(c->rank, op.peer), op.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+            __sync_synchronize();
+            *used = bytes;
+        } else {
+            volatile size_t *used = &c->sh->mail_used[op.peer][c->rank];
+            long spins = 0;
+            while (*used == 0 && ++spins < 120000000L) sched_yield();
+            if (*used != bytes) { std::fprintf(stderr, "mock rccl: recv %d <- %d: %zu bytes waiting, %zu expected\n", c->rank, op.peer, (size_t)*used, bytes); ok = false; if (*used) *used = 0; continue; }
+            __sync_synchronize();
+            if (hipMemcpy(op.recv, c->mail(op.peer, c->rank), bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+            __sync_synchronize();
+            *used = 0;
         }
-        pthread_barrier_wait(&pc->sh->barrier);
-        size_t read_at[kMaxRanks] = {0};
-        for (auto &e : q) {
-            const Op &op = e.second;
-            if (op.kind != 3) continue;
-            ncclComm *c = e.first;
-            const size_t bytes = op.count * type_bytes(op.type);
-            if (hipStreamSynchronize(op.stream) != hipSuccess || hipMemcpy(op.recv, c->mail(op.peer, c->rank) + read_at[op.peer], bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
-            read_at[op.peer] += bytes;
-        }
-        pthread_barrier_wait(&pc->sh->barrier);
-        for (int d = 0; d < pc->nranks; ++d) pc->sh->mail_used[pc->rank][d] = 0;
-        pthread_barrier_wait(&pc->sh->barrier);
     }
     for (auto &e : q)
         if (e.second.kind < 2 && !run_collective(e.first, e.second)) ok = false;

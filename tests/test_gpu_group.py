@@ -162,18 +162,89 @@ def test_rank_api_through_real_rccl_single_rank(engine, monkeypatch):
             gs.close()
 
 
-def test_group_session_refuses_what_does_not_shard():
-    time, cube = synth.make_cube(4, 4, 256)
-    with pkg.Group(devices=[0, 0]) as g:
-        gs = pkg.GroupSession(g, 4, 4, time)
+def _variant_cfg(time, variant):
+    cfg = pkg.chain_cfg_default(time)
+    if variant == "scale2+tilt+means2":
+        cfg.scale_factor, cfg.tilt_x_deg, cfg.want_means = 2, 1.5, 2
+    elif variant.startswith("scale"):
+        cfg.scale_factor = int(variant[5:])
+    elif variant == "tilt":
+        cfg.tilt_x_deg, cfg.tilt_y_deg = 2.0, -1.0
+    elif variant == "means2":
+        cfg.want_means = 2
+    return cfg
+
+
+@pytest.mark.parametrize("variant", ["scale2", "scale3", "tilt", "means2", "scale2+tilt+means2"])
+@pytest.mark.parametrize("shape,members", [((13, 6, 256), 2), ((17, 8, 1024), 3), ((12, 6, 1001), 4)])
+def test_group_session_shards_what_it_used_to_refuse(engine, shape, members, variant):
+    """Round 2's group session refused scale_factor > 1, a non-zero tilt and want_means = 2 (THZ_ERR_UNSUPPORTED).
+    Now: block means over slab edges continue the previous slab's partial sums (a block belongs to the slab that
+    holds its last row), the Tilt plan is made for the whole grid, and the reference-order means run slab after slab
+    on a carried running sum — per-pixel outputs and the reference-order means bit for bit one session's."""
+    nx, ny, nt = shape
+    time, cube = synth.make_cube(nx, ny, nt)
+    cfg = _variant_cfg(time, variant)
+    poly = np.array([[1, 1], [4, 1], [5, 6], [2, 9], [0, 5]], np.uint64)
+    bufs = (pkg.BUF_IMG, pkg.BUF_DATA, pkg.BUF_FFT, pkg.BUF_AMPLITUDES, pkg.BUF_PHASES)
+    avgs = (pkg.BUF_AVG_FFT, pkg.BUF_AVG_AMPLITUDES, pkg.BUF_AVG_PHASES)
+    single = pkg.Session(engine, nx, ny, time, 0.5, 0.5)
+    try:
+        single.upload(cube, subtract_bias=False)
+        single.set_rois([poly])
+        single.recompute(cfg)
+        nto = single.nt_out
+        want = {w: single.download(w) for w in bufs + avgs}
+        want_roi = single.roi(0)
+        px = nx // 2
+        want_plot = single.plot(px, 1)
+        grid = single.grid()
+    finally:
+        single.close()
+    if members > 1 and "scale" in variant and min(pkg.host_slab(nx, members, q)[1] for q in range(members)) < cfg.scale_factor:
+        pytest.skip("a slab shorter than the scale factor is refused (a block would span three slabs)")
+    with pkg.Group(devices=[0] * members) as g:
+        gs = pkg.GroupSession(g, nx, ny, time, 0.5, 0.5)
         try:
             gs.upload(cube, subtract_bias=False)
-            for field, val in (("scale_factor", 2), ("tilt_x_deg", 3.0), ("want_means", 2)):
-                cfg = pkg.chain_cfg_default(time)
-                setattr(cfg, field, val)
-                with pytest.raises(pkg.ThzError) as e:
-                    gs.recompute(cfg)
-                assert e.value.code == -2
+            gs.set_rois([poly])
+            gs.recompute(cfg, 1, pkg.GATHER_ALL)
+            # lengths that are not a power of two (1001; any tilted cube) are transformed in PAIRS of traces: a slab that
+            # starts at an odd trace pairs them differently than one session does, and the last bits may differ
+            pairs = nto & (nto - 1) != 0
+            for w in bufs:
+                got = gs.download(w, nt_out=nto)
+                assert got.shape == want[w].shape, (w, got.shape, want[w].shape, grid)
+                if w == pkg.BUF_PHASES and pairs:
+                    d = got.astype(np.float64) - want[w]
+                    assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi))).max() < 3e-3
+                elif pairs:
+                    assert rel(got, want[w]) < 2e-6, w
+                else:
+                    assert np.array_equal(got, want[w]), w
+            for w in avgs:
+                got = gs.download(w, nt_out=nto)
+                if cfg.want_means == 2 and not pairs:
+                    assert np.array_equal(got, want[w]), w          # the reference's order, slab after slab
+                else:
+                    assert rel(got, want[w]) < 2e-6 or (w == pkg.BUF_AVG_PHASES and pairs), w
+            r = gs.roi(0, nt_out=nto)
+            assert r["count"] == want_roi["count"]
+            for k in ("signal_fft", "signal", "roi_data"):
+                assert np.abs(r[k].astype(np.float64) - want_roi[k]).max() <= 2e-6 * max(np.abs(want_roi[k]).max(), 1e-30), k
+            # the plot copy-out of a pixel: raw trace from the slab that holds the row, processed traces from the slab
+            # that holds its block
+            x0s = [pkg.host_slab(nx, members, q)[0] for q in range(members)]
+            got_plot = None
+            for i in range(members):
+                n_i = pkg.host_slab(nx, members, i)[1]
+                if x0s[i] <= px < x0s[i] + n_i:
+                    try:
+                        got_plot = gs.member(i).plot(px - x0s[i], 1, want=["filtered_signal", "filtered_signal_fft"])
+                    except pkg.ThzError:
+                        got_plot = None       # the block is the next slab's
+            if got_plot is not None and not pairs:
+                assert np.array_equal(got_plot["filtered_signal"], want_plot["filtered_signal"])
         finally:
             gs.close()
     with pytest.raises(pkg.ThzError):

@@ -158,3 +158,109 @@ def test_rank_processes_match_single_session(engine, tmp_path, world, shape, dec
             assert int(res[r][f"deconv_status_rank{r}"][0]) == 0
         assert rel(res[0]["deconv_data"], want["deconv_data"]) < TOL     # the band sums associate differently
         assert rel(res[0]["deconv_img"], want["deconv_img"]) < TOL
+
+
+HALO_SCRIPT = textwrap.dedent('''
+    import os, sys, time
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+    import numpy as np
+    import thz_image_explorer_amd as pkg
+    import synth
+    from test_gpu_group import _variant_cfg
+    rank, world, uid_file, out_file = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    nx, ny, nt = {shape!r}
+    if rank == 0:
+        uid = pkg.group_unique_id()
+        with open(uid_file + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(uid_file + ".tmp", uid_file)
+    else:
+        for _ in range(3000):
+            if os.path.exists(uid_file):
+                break
+            time.sleep(0.01)
+        uid = open(uid_file, "rb").read()
+    time_axis, cube = synth.make_cube(nx, ny, nt)
+    res = {{}}
+    with pkg.Group(device=0, rank=rank, world=world, uid=uid) as g:
+        gs = pkg.GroupSession(g, nx, ny, time_axis, 0.5, 0.5)
+        try:
+            gs.upload(cube, subtract_bias=False)
+            gs.set_rois([np.array([[1, 1], [4, 1], [5, 6], [2, 9], [0, 5]], np.uint64)])
+            gs.recompute(_variant_cfg(time_axis, {variant!r}), 1, pkg.GATHER_ALL)
+            nto = gs.member(0).nt_out
+            sess = gs.member(0)
+            for name, w in (("avg_amp", pkg.BUF_AVG_AMPLITUDES), ("avg_ph", pkg.BUF_AVG_PHASES), ("avg_fft", pkg.BUF_AVG_FFT)):
+                res[name + "_rank%d" % rank] = sess.download(w)
+            r = gs.roi(0, nt_out=nto)
+            res["roi_amp_rank%d" % rank] = r["signal_fft"]
+            res["roi_count_rank%d" % rank] = np.array([r["count"]])
+            if rank == 0:
+                for name, w in (("img", pkg.BUF_IMG), ("data", pkg.BUF_DATA), ("fft", pkg.BUF_FFT), ("amp", pkg.BUF_AMPLITUDES)):
+                    res[name] = gs.download(w, nt_out=nto)
+        finally:
+            gs.close()
+    np.savez(out_file, **res)
+''')
+
+
+@pytest.mark.parametrize("world,shape,variant", [(2, (13, 6, 256), "scale2"), (3, (17, 8, 1024), "scale3"), (3, (17, 8, 1024), "means2"),
+                                                 (2, (13, 6, 256), "tilt"), (3, (13, 6, 256), "scale2+tilt+means2")])
+def test_rank_processes_halo_paths(engine, tmp_path, world, shape, variant):
+    """what the group session refused until round 3, with one PROCESS per rank: the partial block sums and the carried
+    running sums of the reference-order means travel rank q -> q + 1 as ncclSend / ncclRecv pairs while the other ranks
+    are elsewhere (the mock's point-to-point is pairwise for this), the Tilt plan is the whole grid's on every rank"""
+    import synth
+    import thz_image_explorer_amd as pkg
+    from test_gpu_group import _variant_cfg
+    from test_gpu_parity import rel
+    _build_mock()
+    nx, ny, nt = shape
+    time_axis, cube = synth.make_cube(nx, ny, nt)
+    cfg = _variant_cfg(time_axis, variant)
+    s = pkg.Session(engine, nx, ny, time_axis, 0.5, 0.5)
+    try:
+        s.upload(cube, subtract_bias=False)
+        s.set_rois([np.array([[1, 1], [4, 1], [5, 6], [2, 9], [0, 5]], np.uint64)])
+        s.recompute(cfg)
+        nto = s.nt_out
+        want = {n: s.download(w) for n, w in (("img", pkg.BUF_IMG), ("data", pkg.BUF_DATA), ("fft", pkg.BUF_FFT), ("amp", pkg.BUF_AMPLITUDES),
+                                              ("avg_amp", pkg.BUF_AVG_AMPLITUDES), ("avg_ph", pkg.BUF_AVG_PHASES), ("avg_fft", pkg.BUF_AVG_FFT))}
+        want_roi = s.roi(0)
+    finally:
+        s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(HALO_SCRIPT.format(root=ROOT, tests=HERE, shape=shape, variant=variant))
+    uid_file = str(tmp_path / "uid.bin")
+    env = dict(os.environ, THZ_RCCL_LIB=MOCK, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), uid_file, str(tmp_path / f"out{r}.npz")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()          # the exact children started above
+            pytest.fail("a rank process did not finish: the ranks' calls do not pair up")
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{o[-3000:]}"
+    res = [np.load(str(tmp_path / f"out{r}.npz")) for r in range(world)]
+    pairs = nto & (nto - 1) != 0
+    for name in ("img", "data", "fft", "amp"):
+        assert res[0][name].shape == want[name].shape, name
+        if pairs:
+            assert rel(res[0][name], want[name]) < 2e-6, name
+        else:
+            assert np.array_equal(res[0][name], want[name]), name
+    for r in range(world):
+        for name in ("avg_amp", "avg_ph", "avg_fft"):
+            got = res[r][f"{name}_rank{r}"]
+            if cfg.want_means == 2 and not pairs:
+                assert np.array_equal(got, want[name]), (name, r)      # the reference's sequential order, rank after rank
+            elif not (name == "avg_ph" and pairs):
+                assert rel(got, want[name]) < 2e-6, (name, r)
+            assert np.array_equal(got, res[0][f"{name}_rank0"]), (name, r)
+        assert int(res[r][f"roi_count_rank{r}"][0]) == want_roi["count"]
+        assert rel(res[r][f"roi_amp_rank{r}"], want_roi["signal_fft"]) < 2e-6

@@ -210,6 +210,7 @@ SYMBOLS = [
     ("thz_group_session_deconvolve", C.c_int, [_P, C.POINTER(Psf), C.POINTER(DeconvCfg), _P, _P]),
     ("thz_group_session_result", _P, [_P, C.c_int]),
     ("thz_group_session_download", C.c_int, [_P, C.c_int, _SZ, _SZ, _P]),
+    ("thz_group_session_grid", C.c_int, [_P, C.POINTER(_SZ), C.POINTER(_SZ)]),
     ("thz_group_session_set_rois", C.c_int, [_P, _SZ, _P, _P]),
     ("thz_group_session_roi", C.c_int, [_P, _SZ, C.POINTER(RoiOut)]),
     ("thz_session_plot", C.c_int, [_P, _SZ, _SZ, C.POINTER(PlotOut)]),
@@ -665,14 +666,21 @@ class GroupSession:
             self.g._check(rc)
         return rc
 
+    def grid(self):
+        """(nx, ny) of the outputs' whole grid: the raw one, or the block grid behind a scaling stage"""
+        nx, ny = _SZ(), _SZ()
+        self.g._check(self.g.lib.thz_group_session_grid(self.h, C.byref(nx), C.byref(ny)))
+        return nx.value, ny.value
+
     def download(self, which, nt_out=None):
         """gathered buffer of rank 0 (whole grid) or a pixel-mean vector"""
         nto = self.nt if nt_out is None else nt_out
         nf = nto // 2 + 1
         per = {BUF_FFT: (nf, 2), BUF_AMPLITUDES: (nf,), BUF_PHASES: (nf,), BUF_DATA: (nto,), BUF_IMG: ()}
         if which in per:
-            out = np.empty((self.nx * self.ny,) + per[which], np.float32)
-            self.g._check(self.g.lib.thz_group_session_download(self.h, which, 0, self.nx * self.ny, out.ctypes.data))
+            gx, gy = self.grid()
+            out = np.empty((gx * gy,) + per[which], np.float32)
+            self.g._check(self.g.lib.thz_group_session_download(self.h, which, 0, gx * gy, out.ctypes.data))
         else:
             out = np.empty((nf, 2) if which == BUF_AVG_FFT else (nf,), np.float32)
             self.g._check(self.g.lib.thz_group_session_download(self.h, which, 0, 1, out.ctypes.data))

@@ -407,7 +407,13 @@ int thz_group_session_create(thz_group *g, size_t nx, size_t ny, size_t nt, cons
             thz_group_session_destroy(gs);
             return rc;
         }
-        s->grid_x0 = gs->x0[(size_t)g->m[i].rank];  // where the slab sits in the whole grid (regions of interest)
+        // where the slab sits in the whole grid: the Tilt plan, block means over slab edges and the regions of
+        // interest depend on it (session_enqueue derives the current grid's placement from these)
+        s->raw_grid_x0 = gs->x0[(size_t)g->m[i].rank];
+        s->raw_grid_rows = nx;
+        s->slab_rank = g->m[i].rank;
+        s->slab_world = g->world;
+        s->grid_x0 = s->raw_grid_x0;
         s->grid_rows = nx;
         gs->sess.push_back(s);
         if (g->m[i].rank == 0) gs->root_local = (int)i;
@@ -447,6 +453,100 @@ int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtr
     if (int rc = thz_group_all_reduce_sum(g, sums.data(), gs->nt)) return rc;
     gs->gathered = -1;
     return thz_group_sync(g);
+}
+
+// rank `from` -> rank `to`: src / dst are indexed by LOCAL member; only the members that hold the two ranks act
+static int group_p2p(thz_group *g, int from, int to, const float *const *d_src, float *const *d_dst, size_t count)
+{
+    if (count == 0 || from == to) return THZ_OK;
+    int lf = -1, lt = -1;
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        if (g->m[i].rank == from) lf = (int)i;
+        if (g->m[i].rank == to) lt = (int)i;
+    }
+    if (lf < 0 && lt < 0) return THZ_OK;
+    if (g->same_device || (lf >= 0 && lt >= 0 && !g->m[(size_t)lf].comm)) {
+        // one process, no fabric: a device-local copy on the receiver's stream behind the sender's work
+        GHIP_TRY(g, hipSetDevice(g->m[(size_t)lt].ctx->device));
+        GHIP_TRY(g, hipEventRecord(g->m[(size_t)lf].ev, g->m[(size_t)lf].ctx->stream));
+        GHIP_TRY(g, hipStreamWaitEvent(g->m[(size_t)lt].ctx->stream, g->m[(size_t)lf].ev, 0));
+        GHIP_TRY(g, hipMemcpyAsync(d_dst[lt], d_src[lf], count * sizeof(float), hipMemcpyDeviceToDevice, g->m[(size_t)lt].ctx->stream));
+        return THZ_OK;
+    }
+    Rccl &r = rccl();
+    NCCL_TRY(g, r.GroupStart());
+    ncclResult_t rc = ncclSuccess;
+    if (lf >= 0) {
+        (void)hipSetDevice(g->m[(size_t)lf].ctx->device);
+        rc = r.Send(d_src[lf], count, ncclFloat, to, g->m[(size_t)lf].comm, g->m[(size_t)lf].ctx->stream);
+    }
+    if (lt >= 0 && rc == ncclSuccess) {
+        (void)hipSetDevice(g->m[(size_t)lt].ctx->device);
+        rc = r.Recv(d_dst[lt], count, ncclFloat, from, g->m[(size_t)lt].comm, g->m[(size_t)lt].ctx->stream);
+    }
+    if (rc != ncclSuccess) {
+        (void)r.GroupEnd();
+        return gfail(g, THZ_ERR_HIP, std::string("ncclSend / ncclRecv: ") + r.GetErrorString(rc));
+    }
+    NCCL_TRY(g, r.GroupEnd());
+    return THZ_OK;
+}
+
+// want_means == 2 over several slabs: the reference's means are SEQUENTIAL sums over all x rows (ndarray mean_axis on
+// axis 0, then on the next: math_tools.rs:421-440), so the slabs take turns in rank order — each continues the running
+// sums of the slabs in front of it (k_sum_axis0's carry) and hands them on; the last one divides by nx, sums over y,
+// divides by ny; the result reaches every member through an all-reduce in which all others add zeros.  Bit for bit
+// one session's means; serial by construction — this mode is for comparing against the reference, not for speed.
+static int group_means_reference_order(thz_group_session *gs)
+{
+    thz_group *g = gs->g;
+    const size_t nl = gs->sess.size(), nt = gs->nt_out, nf = nt / 2 + 1, ny = gs->cur_ny;
+    size_t nx_total = 0;
+    for (size_t v : gs->cur_rows) nx_total += v;
+    std::vector<float *> run(nl, nullptr), avg(nl, nullptr);
+    std::vector<const float *> run_c(nl, nullptr);
+    auto cleanup = [&]() {
+        for (size_t i = 0; i < nl; ++i)
+            if (run[i]) {
+                (void)hipSetDevice(g->m[i].ctx->device);
+                (void)hipStreamSynchronize(g->m[i].ctx->stream);
+                (void)hipFree(run[i]);
+            }
+    };
+    for (size_t i = 0; i < nl; ++i) {
+        GHIP_TRY(g, hipSetDevice(g->m[i].ctx->device));
+        if (hipMalloc((void **)&run[i], ny * 2 * nf * sizeof(float)) != hipSuccess) {
+            cleanup();
+            return gfail(g, THZ_ERR_HIP, "reference-order means: allocation failed");
+        }
+        run_c[i] = run[i];
+        avg[i] = gs->sess[i]->d_avg;
+        if (hipMemsetAsync(avg[i], 0, 4 * nf * sizeof(float), g->m[i].ctx->stream) != hipSuccess) { cleanup(); return gfail(g, THZ_ERR_HIP, "memset"); }
+    }
+    struct Arr { size_t L, off; int which; };
+    const Arr arrs[3] = {{2 * nf, 0, 0}, {nf, 2 * nf, 1}, {nf, 3 * nf, 2}};
+    int rc = THZ_OK;
+    for (const Arr &a : arrs) {
+        for (int q = 0; q < g->world && !rc; ++q) {
+            if (q > 0) rc = group_p2p(g, q - 1, q, run_c.data(), run.data(), ny * a.L);
+            for (size_t i = 0; i < nl && !rc; ++i) {
+                if (g->m[i].rank != q) continue;
+                thz_session *s = gs->sess[i];
+                const float *arr = a.which == 0 ? s->d_fft : (a.which == 1 ? s->d_amp : s->d_ph);
+                if (hipSetDevice(g->m[i].ctx->device) != hipSuccess) { rc = THZ_ERR_HIP; break; }
+                const bool last = q == g->world - 1;
+                launch_sum_axis0(g->m[i].ctx->stream, arr, gs->cur_rows[(size_t)q], ny * a.L, last ? (float)nx_total : 0.0f, run[i], q > 0 ? run[i] : nullptr);
+                if (last) launch_sum_axis0(g->m[i].ctx->stream, run[i], ny, a.L, (float)ny, avg[i] + a.off);
+                if (hipGetLastError() != hipSuccess) rc = THZ_ERR_HIP;
+            }
+        }
+        if (rc) break;
+    }
+    if (!rc) rc = thz_group_all_reduce_sum(g, avg.data(), 4 * nf);  // everybody but the last rank holds zeros
+    cleanup();
+    if (rc) return gfail(g, rc, "reference-order means over the slabs failed");
+    for (thz_session *s : gs->sess) s->have_means = true;
+    return THZ_OK;
 }
 
 // all-reduce of the members' region sums (session_roi.cpp's block layout: the final traces' block is the last
@@ -489,13 +589,26 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     thz_group *g = gs->g;
     if (gather < THZ_GATHER_SMALL || gather > THZ_GATHER_ALL || start_stage < 0 || start_stage > 8)
         return gfail(g, THZ_ERR_INVALID, "thz_group_session_recompute: bad gather level or chain position");
-    const bool single = g->world == 1;  // one slab = the whole grid: everything a session does
-    if (!single && (cfg->scale_factor > 1 || (cfg->tilt_active && (cfg->tilt_x_deg != 0.0 || cfg->tilt_y_deg != 0.0)) || cfg->want_means > 1))
-        return gfail(g, THZ_ERR_UNSUPPORTED,
-                     "a group session of several slabs shards without a halo only: scale_factor 1, zero tilt, want_means 0 or 1 "
-                     "(block means and the tilt's per-pixel shift depend on the position in the whole grid; "
-                     "the reference-order means are sequential over all x rows)");
+    const bool single = g->world == 1;  // one slab = the whole grid
     if (start_stage == 8) return THZ_OK;
+    // Scaling over slab edges (round 3): a block's rows may lie in two slabs.  Every slab sums the first rows of the
+    // block it cannot finish and hands the partial sums to the next slab, which continues the sequence — the block
+    // belongs to the slab that holds its LAST row.  Needed only when the walk re-runs the scaling stage.
+    const size_t sf = cfg->scale_factor > 1 ? (size_t)cfg->scale_factor : 1;
+    if (!single && sf > 1) {
+        std::vector<const float *> out_c;
+        std::vector<float *> in;
+        for (size_t i = 0; i < gs->sess.size(); ++i) {
+            const int rc = session_scale_tail(gs->sess[i], cfg);
+            if (rc) return gfail(g, rc, std::string("scaling over slabs: ") + thz_last_error(g->m[i].ctx));
+            out_c.push_back(gs->sess[i]->d_carry_out);
+            in.push_back(gs->sess[i]->d_carry_in);
+        }
+        const size_t count = (gs->ny / sf) * gs->nt;
+        for (int q = 0; q + 1 < g->world; ++q)
+            if (slab_scale(gs->nx, g->world, q, sf).tail)
+                if (int rc = group_p2p(g, q, q + 1, out_c.data(), in.data(), count)) return rc;
+    }
     // every slab's chain, enqueued side by side on the members' streams
     std::vector<char> tail(gs->sess.size(), 0);
     for (size_t i = 0; i < gs->sess.size(); ++i) {
@@ -509,23 +622,32 @@ int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg,
     // the outputs' grid: the raw one, or — one slab, scaled — the session's block grid
     gs->cur_rows = gs->rows;
     gs->cur_ny = gs->ny;
-    if (single) {
-        gs->cur_rows[0] = gs->sess[0]->nx_cur;
+    if (!gs->sess.empty() && gs->sess[0]->scale > 1) {
+        const size_t s_eff = gs->sess[0]->scale;
         gs->cur_ny = gs->sess[0]->ny_cur;
+        for (int q = 0; q < g->world; ++q) gs->cur_rows[(size_t)q] = single ? gs->sess[0]->nx_cur : slab_scale(gs->nx, g->world, q, s_eff).rows;
     }
     // C2: the slabs' undivided amplitude / phase sums -> the cube's, on every member
-    if (cfg->want_means && !(tail.size() && tail[0]) && single && !gs->sess[0]->msum_fast) {
-        // the whole grid in one slab, means in the reference's order (want_means 2, or a tilted cube): nothing to exchange
+    const bool additive = !gs->sess.empty() && (gs->sess[0]->msum_fast || gs->sess[0]->msum_passes);
+    if (cfg->want_means && !(tail.size() && tail[0]) && !additive && single) {
+        // the whole grid in one slab, means in the reference's order: nothing to exchange
         int rc = session_means(gs->sess[0], cfg, gs->sess[0]->nx_cur * gs->sess[0]->ny_cur);
         if (!rc) rc = session_avg_data(gs->sess[0], cfg);
         if (rc) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[0].ctx));
+    } else if (cfg->want_means && !(tail.size() && tail[0]) && !additive) {
+        if (int rc = group_means_reference_order(gs)) return rc;
+        for (size_t i = 0; i < gs->sess.size(); ++i)
+            if (int rc = session_avg_data(gs->sess[i], cfg)) return gfail(g, rc, std::string("slab means: ") + thz_last_error(g->m[i].ctx));
     } else if (cfg->want_means && !(tail.size() && tail[0])) {
         std::vector<float *> bufs;
-        for (thz_session *s : gs->sess) {
-            if (!s->msum_fast) return gfail(g, THZ_ERR_UNSUPPORTED, "slab means are not additive for this configuration");
-            bufs.push_back(s->d_msum + nt_out);
-        }
-        if (int rc = thz_group_all_reduce_sum(g, bufs.data(), 2 * nf)) return rc;
+        // amplitude / phase sums of the fused launch (2 nf), or — a tilted cube — spectrum, amplitude and phase sums
+        // (4 nf).  The sum of the SOURCE traces in front of them (avg_fft follows from it by linearity) was all-reduced
+        // at upload for the raw cube; a block-averaged source's is the slab's own and goes along.
+        thz_session *s0 = gs->sess[0];
+        const bool src_too = s0->msum_fast && s0->d_src != s0->d_raw;
+        for (thz_session *s : gs->sess) bufs.push_back(src_too ? s->d_msum : s->d_msum + nt_out);
+        const size_t count = (s0->msum_passes ? 4 * nf : 2 * nf) + (src_too ? nt_out : 0);
+        if (int rc = thz_group_all_reduce_sum(g, bufs.data(), count)) return rc;
         for (size_t i = 0; i < gs->sess.size(); ++i) {
             // Σ of the raw traces was all-reduced at upload; the copy in d_msum[0, nt) is already the cube's
             int rc = session_means(gs->sess[i], cfg, gs->cur_pix());
@@ -788,6 +910,14 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
     }
     if (status < 0) return gfail(g, status, "thz_group_session_deconvolve: aborted or failed on a rank; the stage passes its input through");
     return status;
+}
+
+int thz_group_session_grid(const thz_group_session *gs, size_t *nx, size_t *ny)
+{
+    if (!gs) return THZ_ERR_INVALID;
+    if (nx) *nx = gs->cur_ny ? gs->cur_pix() / gs->cur_ny : 0;
+    if (ny) *ny = gs->cur_ny;
+    return THZ_OK;
 }
 
 void *thz_group_session_result(thz_group_session *gs, int which)

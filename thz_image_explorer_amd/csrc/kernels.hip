@@ -559,15 +559,16 @@ __global__ __launch_bounds__(256) void k_intensity(size_t npix, int nt, float *_
 
 // pixel sums in the reference's order (math_tools.rs:421-440):
 // pass 1: acc[y][i] = (sum over x, sequential) / nx   (divide skipped if nx_div == 0)
+// carry (or null): the sum continues from it — the rows of the slabs in front, in a group's reference-order means
 __global__ __launch_bounds__(256) void k_sum_axis0(const float *__restrict__ arr, size_t n0,
                                                    size_t inner, float div,
-                                                   float *__restrict__ out)
+                                                   float *__restrict__ out, const float *carry)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
          i += (size_t)gridDim.x * blockDim.x) {
         // sequential f32 sum over axis 0 (ndarray's order); only the adds are ordered, so the
         // loads of 16 rows go out together
-        float s = 0.0f;
+        float s = carry ? carry[i] : 0.0f;
         size_t a = 0;
         const float *col = arr + i;
         for (; a + 16 <= n0; a += 16) {
@@ -766,6 +767,24 @@ __global__ __launch_bounds__(64) void k_gather_sum_w(const float *__restrict__ a
     }
     for (; c < count; ++c) s += weigh(col[(size_t)list[c] * len]);
     out[z] = (div > 0.0f) ? s / div : s;
+}
+
+// Block means over a slab edge (math_tools.rs:273-301 adds the s x s inputs of a block row by row, column by column,
+// and divides by s^2): `m` of the block's s rows are in `arr`; the sum continues from `carry` (the rows in front, summed by
+// the previous slab — or null) and is divided only when div > 0 (the block's last rows).  One thread per (block
+// column, sample); the same adds in the same order as k_scale3d, the same exact division.
+__global__ __launch_bounds__(256) void k_scale_rows_partial(const float *__restrict__ arr, size_t m, size_t ny, size_t L, size_t s,
+                                                           const float *__restrict__ carry, float div, float *__restrict__ out)
+{
+    const size_t nh = ny / s;
+    const DivConst by(div > 0.0f ? div : 1.0f);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nh * L; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t ay = t / L, z = t % L;
+        float sum = carry ? carry[t] : 0.0f;
+        for (size_t i = 0; i < m; ++i)
+            for (size_t j = 0; j < s; ++j) sum += arr[(i * ny + ay * s + j) * L + z];
+        out[t] = div > 0.0f ? by(sum) : sum;
+    }
 }
 
 // out = in / d (IEEE division, what `result[z] /= pixel_counts[z] as f32` does, math_tools.rs:655-659), or
@@ -2320,9 +2339,9 @@ void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *i
 }
 
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
-                      float *out)
+                      float *out, const float *carry)
 {
-    THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out);
+    THZ_LAUNCH(k_sum_axis0, grid_1d(inner, 256, kNumCU * 16), 256, 0, st, arr, n0, inner, div, out, carry);
 }
 
 void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inner, float *out)
@@ -2369,6 +2388,12 @@ void launch_gather_sum_w(hipStream_t st, const float *arr, size_t len, const uin
                          const float *w1, const float *w2, const float *w3, float *out)
 {
     THZ_LAUNCH(k_gather_sum_w, (unsigned)((len + 63) / 64), 64, 0, st, arr, len, d_list, count, div, w1, w2, w3, out);
+}
+
+void launch_scale_rows_partial(hipStream_t st, const float *arr, size_t m, size_t ny, size_t L, size_t s, const float *carry, float div,
+                               float *out)
+{
+    THZ_LAUNCH(k_scale_rows_partial, grid_1d((ny / s) * L, 256, kNumCU * 8), 256, 0, st, arr, m, ny, L, s, carry, div, out);
 }
 
 void launch_div_vec(hipStream_t st, const float *in, const float *w, float d, size_t n, float *out)

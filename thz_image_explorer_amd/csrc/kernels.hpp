@@ -118,8 +118,12 @@ void launch_add_vec(hipStream_t st, float *dst, const float *src, size_t n);    
 void launch_add_u64(hipStream_t st, unsigned long long *dst, const unsigned long long *src, size_t n);
 void launch_intensity(hipStream_t st, size_t npix, int nt, float *data, float *img,
                       int subtract_bias);
+// carry (or null; may alias out): the sequential sum continues from it
 void launch_sum_axis0(hipStream_t st, const float *arr, size_t n0, size_t inner, float div,
-                      float *out);
+                      float *out, const float *carry = nullptr);
+// m rows of a block of s rows: out[(ny / s) x L] = (carry +) their column-block sums, divided by div when > 0
+void launch_scale_rows_partial(hipStream_t st, const float *arr, size_t m, size_t ny, size_t L, size_t s, const float *carry, float div,
+                               float *out);
 void launch_sum_rows_f64(hipStream_t st, const float *arr, size_t n0, size_t inner, float *out);  // column sums of a few rows, adds in double
 // list (or null): add arr's rows list[0 .. nrows) instead of rows 0 .. nrows - 1 (a region of interest's pixels)
 size_t launch_colsum_partial(hipStream_t st, const float *arr, size_t nrows, size_t L,

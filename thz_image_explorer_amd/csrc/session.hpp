@@ -68,15 +68,39 @@ struct thz_session {
     bool roi_src_fresh = false;    // the last session_roi_sums renewed the source block (a group all-reduces it then)
     int last_sf = -1, last_tilt_active = -1;
     double last_tilt_x = 0.0, last_tilt_y = 0.0;
-    // placement in a group's grid (group_api.cpp): this session holds rows grid_x0 .. of grid_rows rows of the
-    // CURRENT (scaled) grid; grid_rows == 0: the session is the whole grid
+    // Placement in a group's grid (group_api.cpp).  raw_grid_rows == 0: the session is the whole grid.  Otherwise it
+    // holds rows raw_grid_x0 .. + nx of the raw_grid_rows rows of the RAW grid (slab `slab_rank` of `slab_world`, all
+    // slabs cut by thz_host_slab), and session_enqueue derives grid_x0 / grid_rows: the same for the CURRENT grid —
+    // behind a scaling stage the block grid, whose rows belong to the slab that holds a block's LAST raw row.
+    size_t raw_grid_x0 = 0, raw_grid_rows = 0;
+    int slab_rank = 0, slab_world = 1;
     size_t grid_x0 = 0, grid_rows = 0;
+    // scaling over slab edges: the undivided partial sums of the block this slab only holds the first rows of (handed
+    // to the next slab by the group), and the previous slab's for the block this one completes; (ny / s) x nt each
+    float *d_carry_out = nullptr, *d_carry_in = nullptr;
+    size_t carry_floats = 0;
+    bool carry_out_valid = false;
+    bool msum_passes = false;    // a group's slab, tilted: d_msum = [unused nt | sum fft 2 nf | sum amplitudes nf | sum phases nf]
 };
 
 
 // first half of a recompute: everything up to and including the fused launch, enqueued on the context's
 // stream (tail_only: chain positions >= 6 were served from the resident spectrum)
 int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, bool *tail_only);
+// Scaling over slab edges (group_api.cpp; math_tools.rs:273-301 adds a block's s x s inputs row by row): which rows
+// of the block grid slab `rank` of `world` owns when the raw grid's nx rows are cut by thz_host_slab.
+struct SlabScale {
+    size_t head = 0;       // leading raw rows that complete the block the previous slab started (0: none)
+    bool head_valid = false;  // ... and that block lies inside the block grid
+    size_t full = 0;       // blocks that lie wholly inside the slab
+    size_t tail = 0;       // trailing raw rows that start a block the next slab completes (0: none, or beyond the block grid)
+    size_t rows = 0;       // rows of the block grid this slab owns = head_valid + full
+    size_t x0 = 0;         // ... and where they start in the block grid
+    bool ok = true;        // false: a slab shorter than the scale factor (a block would span three slabs)
+};
+SlabScale slab_scale(size_t nx_total, int world, int rank, size_t sf);
+// before session_enqueue of a scaled group recompute: the partial sums of this slab's trailing block into d_carry_out
+int session_scale_tail(thz_session *s, const thz_chain_cfg *cfg);
 // second half: pixel means from the sums in d_msum, which cover total_pix pixels (the slab's own, or all
 // slabs' after the group's all-reduce)
 int session_means(thz_session *s, const thz_chain_cfg *cfg, size_t total_pix);

@@ -98,7 +98,7 @@ void thz_session_destroy(thz_session *s)
     for (void *p : {(void *)s->d_raw, (void *)s->d_fft, (void *)s->d_amp, (void *)s->d_ph, (void *)s->d_data,
                     (void *)s->d_img, (void *)s->d_avg, (void *)s->d_vec, (void *)s->d_tilt, (void *)s->d_ins,
                     (void *)s->d_opacity, (void *)s->d_deconv, (void *)s->d_deconv_img, (void *)s->d_scaled,
-                    (void *)s->d_rawsum, (void *)s->d_msum})
+                    (void *)s->d_rawsum, (void *)s->d_msum, (void *)s->d_carry_in, (void *)s->d_carry_out})
         if (p) (void)hipFree(p);
     if (s->h_vec) (void)hipHostFree(s->h_vec);
     session_roi_free(s);
@@ -181,6 +181,62 @@ static int session_tail(thz_session *s, const thz_chain_cfg *cfg)
     return thz_ifft(ctx, npix, s->d_fft, d_post, s->d_data, s->d_img);
 }
 
+SlabScale slab_scale(size_t nx_total, int world, int rank, size_t sf)
+{
+    SlabScale r;
+    size_t x0 = 0, n = 0, acc = 0;
+    const size_t nb = nx_total / sf;  // rows of the block grid (math_tools.rs:250: floor)
+    for (int q = 0; q <= rank; ++q) {
+        (void)thz_host_slab(nx_total, world, q, &x0, &n);
+        SlabScale c;
+        c.head = (sf - x0 % sf) % sf;
+        if (c.head > n) { c.ok = false; c.head = n; }
+        c.head_valid = c.head > 0 && x0 / sf < nb;
+        const size_t b0 = (x0 + c.head) / sf;  // first block that starts inside the slab
+        c.full = b0 < nb ? (n - c.head) / sf : 0;
+        if (b0 + c.full > nb) c.full = nb - b0;
+        const size_t rest = n - c.head - c.full * sf;
+        c.tail = (b0 + c.full < nb) ? rest : 0;
+        if (c.tail && q + 1 < world) {  // the next slab must hold the rest of that block
+            size_t x1 = 0, n1 = 0;
+            (void)thz_host_slab(nx_total, world, q + 1, &x1, &n1);
+            if (n1 < sf - c.tail) c.ok = false;
+        }
+        c.rows = (c.head_valid ? 1 : 0) + c.full;
+        c.x0 = acc;
+        acc += c.rows;
+        const bool ok = r.ok && c.ok;
+        r = c;
+        r.ok = ok;
+    }
+    return r;
+}
+
+int session_scale_tail(thz_session *s, const thz_chain_cfg *cfg)
+{
+    thz_ctx *ctx = s->ctx;
+    s->carry_out_valid = false;
+    const size_t sf = cfg->scale_factor > 1 ? (size_t)cfg->scale_factor : 1;
+    if (sf <= 1 || !s->raw_grid_rows || s->ny / sf == 0 || s->raw_grid_rows / sf == 0) return THZ_OK;
+    if (int rc = use_device(ctx)) return rc;
+    const SlabScale sl = slab_scale(s->raw_grid_rows, s->slab_world, s->slab_rank, sf);
+    if (!sl.ok) return fail(ctx, THZ_ERR_UNSUPPORTED, "scaling over slabs: a slab has fewer rows than the scale factor");
+    const size_t need = (s->ny / sf) * s->nt;
+    if (s->carry_floats != need) {
+        s->carry_floats = 0;
+        if (int rc = dev_alloc(ctx, &s->d_carry_out, need)) return rc;
+        if (int rc = dev_alloc(ctx, &s->d_carry_in, need)) return rc;
+        s->carry_floats = need;
+    }
+    if (sl.tail) {
+        const float *rows = s->d_raw + (sl.head + sl.full * sf) * s->ny * s->nt;
+        launch_scale_rows_partial(ctx->stream, rows, sl.tail, s->ny, s->nt, sf, nullptr, 0.0f, s->d_carry_out);
+        if (int rc = check_launch(ctx)) return rc;
+        s->carry_out_valid = true;
+    }
+    return THZ_OK;
+}
+
 int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, bool *tail_only)
 {
     thz_ctx *ctx = s->ctx;
@@ -204,11 +260,23 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
     if (s->nx / sf == 0 || s->ny / sf == 0) sf = 1;
     // ---- Tilt Compensation, planned before any buffer is touched: a length no transform exists for
     // leaves the session as it was (the reference re-plans for any length)
-    const size_t nx_c = s->nx / sf, ny_c = s->ny / sf;
+    // a group's slab: the rows of the CURRENT grid it owns and where they sit in the whole grid (the Tilt plan and
+    // the regions of interest depend on the position in the whole grid); behind a scaling stage, slab_scale's split
+    SlabScale sl;
+    const bool slab = s->raw_grid_rows != 0;
+    if (slab && s->raw_grid_rows / sf == 0) sf = 1;
+    if (slab && sf > 1) {
+        sl = slab_scale(s->raw_grid_rows, s->slab_world, s->slab_rank, sf);
+        if (!sl.ok) return fail(ctx, THZ_ERR_UNSUPPORTED, "scaling over slabs: a slab has fewer rows than the scale factor");
+    }
+    const size_t nx_c = slab && sf > 1 ? sl.rows : s->nx / sf, ny_c = s->ny / sf;
+    const size_t g_rows = slab ? s->raw_grid_rows / sf : nx_c, g_x0 = slab ? (sf > 1 ? sl.x0 : s->raw_grid_x0) : 0;
+    s->grid_rows = slab ? g_rows : 0;
+    s->grid_x0 = g_x0;
     const float dx_c = s->dx * (float)sf, dy_c = s->dy * (float)sf;
     size_t steps = 0;
     if (cfg->tilt_active)
-        steps = tilt_plan(time.data(), nt_cur, nx_c, ny_c, cfg->tilt_x_deg, cfg->tilt_y_deg, dx_c, dy_c, nullptr, nullptr);
+        steps = tilt_plan(time.data(), nt_cur, g_rows, ny_c, cfg->tilt_x_deg, cfg->tilt_y_deg, dx_c, dy_c, nullptr, nullptr);
     if (steps) {
         PlanHost probe;
         if (!build_plan(nt_cur + 2 * steps, probe, ctx->allow_f, ctx->allow_p))
@@ -235,7 +303,18 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
             if (int rc = dev_alloc(ctx, &s->d_scaled, npix * s->nt)) return rc;
             s->scaled_floats = npix * s->nt;
         }
-        if (int rc = thz_scale3d(ctx, s->d_raw, s->nx, s->ny, s->nt, 1, sf, s->d_scaled)) return rc;
+        if (slab) {
+            // the block the previous slab started: its partial sums (d_carry_in, put there by the group) + this slab's
+            // leading rows, divided; then the blocks wholly inside.  Same adds in the same order as one session's.
+            float *o = s->d_scaled;
+            if (sl.head_valid) {
+                launch_scale_rows_partial(ctx->stream, s->d_raw, sl.head, s->ny, s->nt, sf, s->d_carry_in, (float)(sf * sf), o);
+                if (int rc = check_launch(ctx)) return rc;
+                o += ny_c * s->nt;
+            }
+            if (sl.full)
+                if (int rc = thz_scale3d(ctx, s->d_raw + sl.head * s->ny * s->nt, sl.full * sf, s->ny, s->nt, 1, sf, o)) return rc;
+        } else if (int rc = thz_scale3d(ctx, s->d_raw, s->nx, s->ny, s->nt, 1, sf, s->d_scaled)) return rc;
         src = s->d_scaled;
     }
 
@@ -250,8 +329,15 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
             const size_t nt2 = nt_cur + 2 * steps;
             std::vector<float> new_time(nt2);
             std::vector<int32_t> ins(npix);
-            tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx_cur, s->dy_cur,
-                      new_time.data(), ins.data());
+            if (slab) {  // the insert index depends on the position in the whole grid: plan it, keep this slab's rows
+                std::vector<int32_t> all(g_rows * s->ny_cur);
+                tilt_plan(time.data(), nt_cur, g_rows, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx_cur, s->dy_cur,
+                          new_time.data(), all.data());
+                std::copy(all.begin() + (long)(g_x0 * s->ny_cur), all.begin() + (long)((g_x0 + s->nx_cur) * s->ny_cur), ins.begin());
+            } else {
+                tilt_plan(time.data(), nt_cur, s->nx_cur, s->ny_cur, cfg->tilt_x_deg, cfg->tilt_y_deg, s->dx_cur, s->dy_cur,
+                          new_time.data(), ins.data());
+            }
             if (s->tilt_floats != npix * nt2) {
                 s->tilt_floats = 0;
                 if (int rc = dev_alloc(ctx, &s->d_tilt, npix * nt2)) return rc;
@@ -344,12 +430,16 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
     // pass over the spectra.  want_means == 2 (and any tilted cube): the reference's summation order
     // (ndarray mean_axis twice, math_tools.rs:421-440), bit for bit, as three passes over the outputs.
     s->msum_fast = cfg->want_means == 1 && !tilted;
-    if (s->msum_fast) {
-        if (s->msum_floats != nt_cur + 2 * nf) {
+    // a group's slab of a tilted cube: sums that add up over the slabs — three passes over the outputs, any order
+    s->msum_passes = cfg->want_means == 1 && tilted && slab;
+    if (s->msum_fast || s->msum_passes) {
+        if (s->msum_floats != nt_cur + 4 * nf) {
             s->msum_floats = 0;
-            if (int rc = dev_alloc(ctx, &s->d_msum, nt_cur + 2 * nf)) return rc;
-            s->msum_floats = nt_cur + 2 * nf;
+            if (int rc = dev_alloc(ctx, &s->d_msum, nt_cur + 4 * nf)) return rc;
+            s->msum_floats = nt_cur + 4 * nf;
         }
+    }
+    if (s->msum_fast) {
         // Σ of the source traces: cached at upload for the raw cube, one small pass for a block-averaged one
         if (src == s->d_raw) HIP_TRY(ctx, hipMemcpyAsync(s->d_msum, s->d_rawsum, nt_cur * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         else if (int rc = thz_pixel_sum(ctx, npix, nt_cur, 1, src, s->d_msum)) return rc;
@@ -359,6 +449,11 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
     io.d_post_win = d_post; io.d_fft = s->d_fft; io.d_amp = s->d_amp; io.d_phase = s->d_ph; io.d_data_out = s->d_data;
     io.d_img = s->d_img; io.d_sums = s->msum_fast ? s->d_msum + nt_cur : nullptr;
     if (int rc = thz_pipeline_ex(ctx, npix, &io)) return rc;
+    if (s->msum_passes) {
+        if (int rc = thz_pixel_sum(ctx, npix, nf, 2, s->d_fft, s->d_msum + nt_cur)) return rc;
+        if (int rc = thz_pixel_sum(ctx, npix, nf, 1, s->d_amp, s->d_msum + nt_cur + 2 * nf)) return rc;
+        if (int rc = thz_pixel_sum(ctx, npix, nf, 1, s->d_ph, s->d_msum + nt_cur + 3 * nf)) return rc;
+    }
     s->have_means = false;
     s->have_outputs = true;
     s->deconv_current = false;  // the stage passes its input through unless it is the one updated
@@ -376,7 +471,10 @@ int session_means(thz_session *s, const thz_chain_cfg *cfg, size_t total_pix)
     if (int rc = use_device(ctx)) return rc;
     const size_t nt = s->nt_out, nf = s->nf_out;
     if (!cfg->want_means) return THZ_OK;
-    if (s->msum_fast) {
+    if (s->msum_passes) {
+        launch_scale_vec(ctx->stream, s->d_msum + nt, 1.0f / (float)total_pix, 4 * nf, s->d_avg);
+        if (int rc = check_launch(ctx)) return rc;
+    } else if (s->msum_fast) {
         const float inv = 1.0f / (float)total_pix;
         // amplitudes and phases: sums / pixels; mean source trace in place
         launch_scale_vec(ctx->stream, s->d_msum + nt, inv, 2 * nf, s->d_avg + 2 * nf);
@@ -588,9 +686,17 @@ int thz_session_plot(thz_session *s, size_t px, size_t py, const thz_plot_out *o
     if (!need_outputs) return THZ_OK;
     if (!s->have_outputs) return fail(ctx, THZ_ERR_NOT_READY, "thz_session_plot: no recompute has run");
     // everything behind the scaling stage lives on the block grid: pixel / scale (a ragged edge has no block)
-    if (px / s->scale >= s->nx_cur || py / s->scale >= s->ny_cur)
+    size_t row = px / s->scale;
+    if (s->raw_grid_rows && s->scale > 1) {
+        // a group's slab behind a scaling stage: the block of raw row px belongs to the slab that holds its LAST row
+        const size_t block = (s->raw_grid_x0 + px) / s->scale;
+        if (block < s->grid_x0 || block >= s->grid_x0 + s->nx_cur)
+            return fail(ctx, THZ_ERR_INVALID, "thz_session_plot: this pixel's block is held by a neighbouring slab (or lies beyond the scaled grid)");
+        row = block - s->grid_x0;
+    }
+    if (row >= s->nx_cur || py / s->scale >= s->ny_cur)
         return fail(ctx, THZ_ERR_INVALID, "thz_session_plot: pixel beyond the scaled grid");
-    const size_t pix = (px / s->scale) * s->ny_cur + py / s->scale;
+    const size_t pix = row * s->ny_cur + py / s->scale;
     const size_t nt = s->nt_out, nf = s->nf_out;
     if (out->filtered_signal)
         if (int rc = thz_session_download(s, THZ_BUF_DATA, pix, 1, out->filtered_signal)) return rc;

@@ -301,7 +301,19 @@ bool GpuEngine::plot(size_t px, size_t py, const thz_plot_out &out)
     if (!session_) return false;
     size_t lx = 0;
     thz_session *s = owner_of(px, &lx);
-    return s && thz_session_plot(s, lx, py, &out) == THZ_OK;
+    if (!s) return false;
+    const size_t sf = pending_.scale_factor > 1 ? (size_t)pending_.scale_factor : 1;
+    if (sf == 1 || thz_group_world(group_) == 1) return thz_session_plot(s, lx, py, &out) == THZ_OK;
+    // Several slabs behind a scaling stage: the raw trace comes from the slab that holds row px, everything else from
+    // the slab that holds the pixel's BLOCK — the one with the block's last raw row (thz_group_session_recompute)
+    thz_plot_out raw{};
+    raw.signal = out.signal;
+    if (out.signal && thz_session_plot(s, lx, py, &raw) != THZ_OK) return false;
+    thz_plot_out rest = out;
+    rest.signal = nullptr;
+    size_t lb = 0;
+    thz_session *sb = owner_of((px / sf) * sf + sf - 1, &lb);
+    return sb && thz_session_plot(sb, lb, py, &rest) == THZ_OK;
 }
 
 bool GpuEngine::roi(const std::string &uuid, const thz_roi_out &out)
