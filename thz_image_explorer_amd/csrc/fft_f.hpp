@@ -641,6 +641,27 @@ struct FSums {
         wpb = waves_per_block;
         give_up = 0u;
     }
+#ifndef THZ_EMU
+    typedef float f4e __attribute__((ext_vector_type(4)));
+    f4e early_a, early_p;
+    unsigned early_t;
+#endif
+    // issues the visit's LDS reads (ticket + the group's accumulators); group() consumes them
+    __device__ __forceinline__ void begin(int g, int lane)
+    {
+#ifndef THZ_EMU
+        const unsigned *tick = reinterpret_cast<const unsigned *>(area + 2 * N) + g;
+        const float *sa = area + 256 * g + 4 * lane;
+        asm volatile("" ::: "memory");
+        early_t = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        early_a = *reinterpret_cast<const f4e *>(sa);
+        early_p = *reinterpret_cast<const f4e *>(sa + N);
+        asm volatile("" ::: "memory");
+#else
+        (void)g; (void)lane;
+#endif
+    }
     // adds this wave's group-g values of its current trace to the block's sums, in ticket order
     __device__ __forceinline__ void group(int g, const float (&a)[4], const float (&y)[4], int lane)
     {
@@ -670,9 +691,13 @@ struct FSums {
         // land: the ticket write is issued behind them and executes behind them.  Only the compiler has to keep the
         // order, hence the barriers.
         typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v va, vp;
+        // the first attempt's reads were issued by begin(), some twenty instructions ago (the phase stores and the
+        // unwrap's carries sit between): most of their latency is behind the wave when it gets here
+        f4v va = early_a, vp = early_p;
+        unsigned t = early_t;
         for (;;) {
-            const unsigned t = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (THZ_UNIFORM((int)t) == (int)mine) break;
+            t = __hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
             va = *reinterpret_cast<const f4v *>(sa);  // (plain loads: a volatile access through the generic pointer
             vp = *reinterpret_cast<const f4v *>(sp);  //  loses the LDS address space and becomes a flat load)
@@ -852,6 +877,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = first + (base + s_[c]);
+            if constexpr (SUMS) sums->begin(g, lane);
             store_f4(A.ph_out + p * nf + k0, y[0], y[1], y[2], y[3]);
             carry += wave_bcast<kWave - 1>(incl);
             prev_tail = wave_bcast<kWave - 1>(ph[3]);
