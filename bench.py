@@ -325,8 +325,11 @@ def main():
             # BASELINE config 5's chain AS A SESSION RUNS IT: complex multiplier AND the in-launch pixel sums
             d_H = eng.to_device(wiener_multiplier(eng, tm))
             d_sums = eng.empty((2 * nf,)) if fused_sums else None
+            # the band pass's own index range (what the session passes along): the kernel stages only those bins of H
+            _, band_lo, band_hi = pkg.host_fd_bandpass(pkg.host_frequency_axis(tm), 0.2, 5.0, 0.1)
             for _ in range(6):
-                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, None, d_sums)
+                eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, None, d_sums,
+                                band=(int(band_lo), int(band_hi)))
             eng.sync()
             w_ns, w_calls = eng.timing_collect(binding.STAGE_PIPELINE)
             if w_calls:

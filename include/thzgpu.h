@@ -260,6 +260,11 @@ typedef struct thz_pipeline_io {
     float *d_data_out;       /* (npix, nt) */
     float *d_img;            /* (npix) or NULL */
     float *d_sums;           /* (2 nf) or NULL */
+    /* Optional: the caller's word that d_fd_mask is ZERO at every bin outside [band_lo, band_hi) — the index range
+     * thz_host_fd_bandpass hands back (lower, upper).  0, 0: unknown.  With d_fd_cmask and d_sums at nt = 4096 the fused
+     * kernel then stages only the band's bins of the complex multiplier (half the table at the default 0.2-5 THz) and
+     * keeps its eighth wave per block; results are the same bit for bit.  A wrong range gives wrong spectra. */
+    size_t band_lo, band_hi;
 } thz_pipeline_io;
 int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io);
 

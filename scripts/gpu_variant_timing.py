@@ -22,11 +22,15 @@ H = np.zeros((nf, 2), np.float32); H[:, 0] = 0.7; H[:, 1] = 0.3
 d_H = eng.to_device(H)
 d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
 d_sums = eng.empty((2 * nf,))
+import thz_image_explorer_amd as _pkg
+_, _lo, _hi = _pkg.host_fd_bandpass(_pkg.host_frequency_axis(tm), 0.2, 5.0, 0.1)
+BAND = (int(_lo), int(_hi))
 m_full, m_fwd, m_inv = 16 * nt + 20, 8 * nt + 8, 8 * nf + 4 * nt + 4
 variants = {
     "plain": (lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img), binding.STAGE_PIPELINE, m_full),
     "sums": (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums), binding.STAGE_PIPELINE, m_full),
     "cmask+sums": (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums), binding.STAGE_PIPELINE, m_full),
+    "cmask+sums+band": (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums, band=BAND), binding.STAGE_PIPELINE, m_full),
     "cmask": (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, d_H, d_post, d_fft, d_amp, d_ph, d_out, d_img, None), binding.STAGE_PIPELINE, m_full),
     "fwd": (lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, None, None, d_fd), binding.STAGE_FFT, m_fwd),
     "fwd+ap": (lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, d_amp, d_ph, d_fd), binding.STAGE_FFT, 4 * nt + 16 * nf),

@@ -93,6 +93,25 @@ int emu_pipeline_sums(int nt, size_t npix, const float *raw, const float *pre, c
     return (int)rows;
 }
 
+// ... with the caller's word on where the real mask is not zero ([band_lo, band_hi), api.cpp pipeline_ex_band): at nt = 4096 with a
+// complex multiplier the kernel then stages a band-limited table (kCfgBand)
+int emu_pipeline_sums_band(int nt, size_t npix, const float *raw, const float *pre, const float *mask, const float *cmask,
+                           const float *post, float *fft, float *amp, float *ph, float *out, float *img, float *sums, int band_lo,
+                           int band_hi)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
+    if (H.family != kFamilyF) return -2;
+    PlanDev D = make_plan(H);
+    const int lo4 = band_lo & ~3, n = ((band_hi + 3) & ~3) - lo4;
+    const size_t rows = pipeline_sum_rows(D, npix, cmask != nullptr, lo4, n);
+    if (rows == 0) return -3;
+    std::vector<float> partial(rows * 2 * (size_t)D.nf, -777.0f);
+    launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img, (const c32 *)cmask, partial.data(), lo4, n);
+    launch_sum_rows_f64(nullptr, partial.data(), rows, 2 * (size_t)D.nf, sums);
+    return (int)rows;
+}
+
 int emu_intensity(size_t npix, int nt, float *data, float *img, int subtract_bias)
 {
     launch_intensity(nullptr, npix, nt, data, img, subtract_bias);

@@ -596,6 +596,44 @@ def test_fused_pipeline_in_kernel_pixel_sums(emu, nt, npix, cap, mode, bar):
         emu.emu_set_grid_cap(0)
 
 
+@pytest.mark.parametrize("band", [(0.2, 5.0), (0.0, 4.9), (2.0, 2.3), (4.0, 9.0)])
+def test_fused_pipeline_band_limited_complex_multiplier(emu, band):
+    """kCfgBand (round 3): at nt = 4096 the chain with a complex multiplier AND the in-launch sums stages only the bins
+    where the real band pass is not zero — between two quads of zeros every other bin's index is clamped to — and so
+    keeps its eighth wave.  Same products, same outputs, bit for bit, as the full table; band edges that are not
+    multiples of four, a band that starts at bin 0, one that reaches the last bin (too wide for the table: the launcher
+    falls back to the full one)"""
+    emu.emu_allow_f(1); emu.emu_allow_p(1)
+    nt, npix = 4096, 11
+    nf = nt // 2 + 1
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(npix) + 3, nt)
+    chain = synth.oracle_chain(time)
+    freq = ob.frequency_axis(time)
+    mask, lo, hi = ob.fd_bandpass_window(freq, band[0], band[1], 0.1)
+    rng = np.random.default_rng(4)
+    H = rng.standard_normal((nf, 2)).astype(np.float32)
+    outs = []
+    for banded in (False, True):
+        fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+        ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+        sums = np.full(2 * nf, np.nan, np.float32)
+        if banded:
+            rows = emu.emu_pipeline_sums_band(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(mask), _p(H), _p(chain["w_post"]),
+                                              _p(fft), _p(amp), _p(ph), _p(out), _p(img), _p(sums), int(lo), int(hi))
+        else:
+            rows = emu.emu_pipeline_sums(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(mask), _p(H), _p(chain["w_post"]),
+                                         _p(fft), _p(amp), _p(ph), _p(out), _p(img), _p(sums))
+        assert rows >= 1
+        outs.append((fft, amp, ph, out, img, sums))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert np.array_equal(a, b)
+    # the sums: seven waves per block against eight add the traces in another order
+    sa, sb = outs[0][5].astype(np.float64), outs[1][5]
+    assert np.abs(sa - sb).max() <= 2e-6 * np.abs(sa).max()
+    assert np.abs(outs[1][0]).max() > 0
+
+
 @pytest.mark.parametrize("mode", ["plain", "cmask"])
 @pytest.mark.parametrize("nt,npix,cap", [(1001, 37, 0), (1000, 40, 0), (1001, 2, 0), (1001, 1, 0), (1001, 75, 1)])
 def test_mixed_radix_pipeline_in_kernel_pixel_sums(emu, nt, npix, cap, mode):

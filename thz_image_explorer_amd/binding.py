@@ -95,7 +95,7 @@ class ChainCfg(C.Structure):
 
 class PipelineIo(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("d_raw", "d_pre_win", "d_fd_mask", "d_fd_cmask", "d_post_win", "d_fft", "d_amp",
-                                          "d_phase", "d_data_out", "d_img", "d_sums")]
+                                          "d_phase", "d_data_out", "d_img", "d_sums")] + [("band_lo", C.c_size_t), ("band_hi", C.c_size_t)]
 
 
 class RoiOut(C.Structure):
@@ -820,9 +820,11 @@ class Engine:
     def ifft(self, npix, fft, td_win, data_out, img=None):
         self._check(self.lib.thz_ifft(self.ctx, npix, _dp(fft), _dp(td_win), _dp(data_out), _dp(img)))
 
-    def pipeline_ex(self, npix, raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img=None, sums=None):
-        """thz_pipeline_ex: the fused chain with a complex per-bin multiplier and / or in-launch pixel sums"""
-        io = PipelineIo(*[_dp(x) for x in (raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img, sums)])
+    def pipeline_ex(self, npix, raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img=None, sums=None, band=None):
+        """thz_pipeline_ex: the fused chain with a complex per-bin multiplier and / or in-launch pixel sums; band = (lo, hi):
+        the bins outside are zero in fd_mask (thz_host_fd_bandpass's index range)"""
+        io = PipelineIo(*[_dp(x) for x in (raw, pre_win, fd_mask, fd_cmask, post_win, fft, amp, phase, data_out, img, sums)],
+                        *(band if band else (0, 0)))
         self._check(self.lib.thz_pipeline_ex(self.ctx, npix, C.byref(io)))
 
     def pipeline(self, npix, raw, pre_win, fd_mask, post_win, fft, amp, phase, data_out, img):

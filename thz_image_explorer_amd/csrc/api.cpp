@@ -443,7 +443,22 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
 
 int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
 {
+    return pipeline_ex_band(ctx, npix, io, io ? io->band_lo : 0, io ? io->band_hi : 0);
+}
+
+}  // extern "C"
+
+// thz_pipeline_ex for a caller that KNOWS where its real multiplier is not zero (the session: thz_host_fd_bandpass hands
+// the band's first and last bin back): every bin outside [band_lo, band_hi) is zero in io->d_fd_mask.  With a complex
+// multiplier the nt = 4096 kernel then stages only the band's bins (fft_f.hpp, kCfgBand).  0, 0: unknown.
+int pipeline_ex_band(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io, size_t band_lo, size_t band_hi)
+{
     if (int rc = need_plan(ctx)) return rc;
+    int band_lo4 = 0, band_n = 0;
+    if (band_hi > band_lo && io && io->d_fd_cmask) {
+        band_lo4 = (int)(band_lo & ~(size_t)3);
+        band_n = (int)(((band_hi + 3) & ~(size_t)3) - (size_t)band_lo4);
+    }
     if (!io || !io->d_raw || !io->d_data_out || !io->d_fft || !io->d_amp || !io->d_phase)
         return fail(ctx, THZ_ERR_INVALID, "thz_pipeline_ex: d_raw, d_fft, d_amp, d_phase and d_data_out are required");
     const size_t nf = (size_t)ctx->plan_d.nf;
@@ -457,7 +472,7 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
     // 4096 samples, profiles/r02_sums_in_kernel.txt), otherwise as a second pass over the two arrays just written
     // (8 nf bytes per trace).  THZ_NO_FUSED_SUMS: developer knob, forces the second pass for A/B measurements.
     const size_t sum_rows = (io->d_sums && !getenv("THZ_NO_FUSED_SUMS"))
-                                ? pipeline_sum_rows(ctx->plan_d, npix, io->d_fd_cmask != nullptr) : 0;
+                                ? pipeline_sum_rows(ctx->plan_d, npix, io->d_fd_cmask != nullptr, band_lo4, band_n) : 0;
     float *d_partial = nullptr;
     if (sum_rows) {
         if (int rc = ensure_ws(ctx, sum_rows * 2 * nf * sizeof(float))) return rc;
@@ -467,7 +482,7 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
         StageTimer t(ctx, THZ_STAGE_PIPELINE);
         launch_pipeline(ctx->stream, ctx->plan_d, npix, io->d_raw, io->d_pre_win, io->d_fd_mask, io->d_post_win,
                         reinterpret_cast<c32 *>(io->d_fft), io->d_amp, io->d_phase, io->d_data_out, io->d_img,
-                        reinterpret_cast<const c32 *>(io->d_fd_cmask), d_partial);
+                        reinterpret_cast<const c32 *>(io->d_fd_cmask), d_partial, band_lo4, band_n);
         if (int rc = check_launch(ctx)) return rc;
     }
     if (!io->d_sums) return THZ_OK;
@@ -479,6 +494,8 @@ int thz_pipeline_ex(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io)
     if (int rc = thz_pixel_sum(ctx, npix, nf, 1, io->d_amp, io->d_sums)) return rc;
     return thz_pixel_sum(ctx, npix, nf, 1, io->d_phase, io->d_sums + nf);
 }
+
+extern "C" {
 
 int thz_apply_td_window(thz_ctx *ctx, size_t npix, const float *d_in, const float *d_win,
                         float *d_out)

@@ -189,6 +189,8 @@ inline int need_plan(thz_ctx *ctx)
 }  // namespace thz_api
 using namespace thz_api;
 
+// api.cpp: thz_pipeline_ex with the real multiplier's non-zero range [band_lo, band_hi) known (0, 0: unknown)
+int pipeline_ex_band(thz_ctx *ctx, size_t npix, const thz_pipeline_io *io, size_t band_lo, size_t band_hi);
 // api.cpp: order-free column sums over all rows (d_list null) or over the listed rows of d_arr
 int pixel_sum_rows(thz_ctx *ctx, const float *d_arr, const uint32_t *d_list, size_t npix, size_t L, float *d_out);
 

@@ -144,7 +144,11 @@ enum : int {
     kCfgAmpPhase = 1,  // also write |X| and the unwrapped phase
     kCfgCMask = 2,     // the per-bin multiplier is complex (K13, reference-pulse Wiener filter)
     kCfgSums = 4,      // the block also sums the stored amplitudes and unwrapped phases of its traces (FSums)
-    kCfgBar = 8        // the block's waves meet at a barrier before each store phase (FArgs::bar says which)
+    kCfgBar = 8,       // the block's waves meet at a barrier before each store phase (FArgs::bar says which)
+    kCfgBand = 16      // with kCfgCMask: the staged multiplier table covers only the bins FArgs::band_lo4 .. + band_n — where
+                       // the real band pass is not zero — between two quads of zeros that every other bin's index is clamped
+                       // to.  Half the table at the default 0.2-5 THz: what lets the nt = 4096 chain with the complex
+                       // multiplier AND the in-launch sums keep eight waves per block (round 3).
 };
 
 // ------------------------------------------------------------------- the plan
@@ -166,7 +170,12 @@ struct FPlan {
     static constexpr int T2_ENTRIES = R2 * R3;
     // N + 1 floats (real multiplier) or N + 1 cx (complex multiplier), padded to 16 bytes; the two
     // floats of padding behind a real mask / the last cx behind a complex one hold the window block bits
-    static constexpr int mask_entries(int cfg) { return (cfg & kCfgCMask) ? N + 2 : (N + 4) / 2; }
+    // kCfgBand: [zero quad][up to BAND_BINS bins][zero quad] + the cx that holds the window block bits
+    static constexpr int BAND_BINS = N / 2;
+    static constexpr int mask_entries(int cfg)
+    {
+        return (cfg & kCfgBand) ? BAND_BINS + 8 + 2 : (cfg & kCfgCMask) ? N + 2 : (N + 4) / 2;
+    }
     static constexpr int WAVE_ENTRIES = N + 2;  // natural order + Z[N] := Z[0], kept 16-byte aligned
     // Small trace-invariant tables the trace loop reads, staged once per block so that no
     // vector-memory load sits between the loop's stores (a load's result can only be waited
@@ -505,6 +514,8 @@ struct FArgs {
     const float *post_win;  // (nt); may be null only when post_blocks == 0
     float *data_out;        // (npix, nt) final trace            [inv, pipeline]
     float *img;             // (npix) or null
+    int band_lo4, band_n;   // kCfgBand: first bin (a multiple of 4) and number of bins (a multiple of 4, <= P::BAND_BINS) of
+                            // the staged complex multiplier; the real mask is zero at every bin outside
     float *sum_partial;     // (gridDim.x, 2 nf): every block's sums of its traces' stored amplitudes | unwrapped
                             // phases, written whole by the block (zeros if it had no trace); kCfgSums only
 };
@@ -586,6 +597,14 @@ __device__ __forceinline__ int f_slot_of(uint32_t slots, int j)
     const int e = j == 0 ? 0 : (j == P::R1 - 2 ? 1 : 2);
     const int v = (int)((slots >> (4 * e)) & 15u);
     return v == 15 ? -1 : v;
+}
+
+// kCfgBand: entry of bin k in the staged table [zero quad][bins lo4 .. lo4 + n)[zero quad] — every bin outside the band
+// lands on a zero (v_add + v_med3)
+__device__ __forceinline__ int f_band_index(int k_minus_lo4_plus4, int n_plus4)
+{
+    const int hi = k_minus_lo4_plus4 < n_plus4 ? k_minus_lo4_plus4 : n_plus4;
+    return hi > 0 ? hi : 0;
 }
 
 // Spectrum epilogue.  buf holds Z[0..N] in the nat() layout; on return it holds
@@ -747,11 +766,13 @@ struct FSums {
 // STORE_FFT = false (fused chain): the masked spectrum is stored by f_inverse_input, which forms the same products
 // X m (X H) anyway and holds them two adjacent bins per lane — sixteen 1 KiB stores in one short burst instead of two
 // per group spread over the whole epilogue; only the Nyquist bin is still stored here.
-template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false, bool WC = false, bool STORE_FFT = true>
+template <class P, bool AMP_PHASE, bool CMASK = false, bool SUMS = false, bool WC = false, bool STORE_FFT = true, bool BAND = false>
 __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, const cx *wg_s,
                                                     const float *mask, size_t p, const FArgs &A,
                                                     int lane, FSums<P> *sums = nullptr)
 {
+    static_assert(!BAND || CMASK, "the band-limited table is the complex multiplier's");
+    const int band_off = 4 - A.band_lo4, band_cap = A.band_n + 4;  // BAND: table entry of bin k = clamp(k + band_off, 0, band_cap)
     static_assert(!SUMS || AMP_PHASE, "the sums are those of the amplitudes and phases");
     constexpr int N = P::N, NG = P::NG;
     static_assert(NG % 2 == 0, "pair ownership splits the groups in halves");
@@ -814,7 +835,9 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
         if constexpr (CMASK) {
             cx Y[4];
             {
-                const cx *hm = reinterpret_cast<const cx *>(mask) + k0;  // LDS copy
+                // BAND: the quad's entries, or — outside the band — one of the two quads of zeros (k0, band_lo4 and band_n
+                // are multiples of 4, so a quad is inside or outside as a whole)
+                const cx *hm = reinterpret_cast<const cx *>(mask) + (BAND ? f_band_index(k0 + band_off, band_cap) : k0);  // LDS copy
                 const cx2 h01 = ld2(hm), h23 = ld2(hm + 2);
                 Y[0] = cx_mul(X[0], h01.a); Y[1] = cx_mul(X[1], h01.b);
                 Y[2] = cx_mul(X[2], h23.a); Y[3] = cx_mul(X[3], h23.b);
@@ -895,7 +918,7 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
         const float xr = buf[N].x;
         float aN;
         if constexpr (CMASK) {
-            const cx hN = reinterpret_cast<const cx *>(mask)[N];
+            const cx hN = reinterpret_cast<const cx *>(mask)[BAND ? f_band_index(N + band_off, band_cap) : N];
             const cx yN = cx{xr * hN.x, xr * hN.y};
             A.fft_out[p * nf + N] = cx{yN.x, 0.0f};
             aN = fast_sqrt(fmaf(yN.x, yN.x, yN.y * yN.y));
@@ -927,10 +950,10 @@ __device__ __forceinline__ void f_spectrum_epilogue(cx *buf, const cx *w2n_s, co
 // imaginary parts after the multiply.
 // STORE (fused chain, with MASKED): fft_row = the trace's row of the spectrum output; the masked bins n < N — the
 // values the inverse transform is built from, to the bit — are stored from here (bin N: the spectrum epilogue).
-template <class P, bool MASKED, bool CMASK = false, bool WC = false, bool STORE = false>
+template <class P, bool MASKED, bool CMASK = false, bool WC = false, bool STORE = false, bool BAND = false>
 __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, const cx *wg_s,
                                                 const float *__restrict__ mask, int lane,
-                                                cx (&r)[P::C1][P::R1], cx *fft_row = nullptr)
+                                                cx (&r)[P::C1][P::R1], cx *fft_row = nullptr, int band_off = 0, int band_cap = 0)
 {
     // the masked values are stored AND consumed: no product of this function may be fused into the split's adds
     // (the stand-alone inverse must land on the same samples from the stored spectrum, bit for bit)
@@ -987,8 +1010,13 @@ __device__ __forceinline__ void f_inverse_input(const cx *buf, const cx *w2n_s, 
             }
             if constexpr (MASKED && CMASK) {
                 const cx *hm = reinterpret_cast<const cx *>(mask);
-                xk = cx_mul(xk, hm[mk_f + off]);
-                xn = cx_mul(xn, hm[mk_r + (TOP - off)]);
+                if constexpr (BAND) {
+                    xk = cx_mul(xk, hm[f_band_index(mk_f + band_off + off, band_cap)]);
+                    xn = cx_mul(xn, hm[f_band_index(mk_r + band_off + (TOP - off), band_cap)]);
+                } else {
+                    xk = cx_mul(xk, hm[mk_f + off]);
+                    xn = cx_mul(xn, hm[mk_r + (TOP - off)]);
+                }
                 if (off == 0 && lane == 0) {
                     xk.y = 0.0f;
                     xn.y = 0.0f;
@@ -1119,6 +1147,7 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     constexpr bool AMP_PHASE = (CFG & kCfgAmpPhase) != 0;
     constexpr bool CMASK = (CFG & kCfgCMask) != 0 && MODE != kInv;
     constexpr bool SUMS = (CFG & kCfgSums) != 0;
+    constexpr bool BAND = (CFG & kCfgBand) != 0 && CMASK;
     static_assert(!SUMS || (MODE == kPipe && AMP_PHASE && (CFG & kCfgBar) != 0), "sums: fused chain, block-uniform trace loop");
     constexpr int ME = P::mask_entries(CFG);
     const int nf = N + 1;
@@ -1144,7 +1173,20 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
         for (int i = (int)threadIdx.x; i < P::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
     }
     for (int i = (int)threadIdx.x; i < P::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
-    if constexpr (CMASK) {
+    if constexpr (BAND) {
+        // [zero quad][bins band_lo4 .. band_lo4 + band_n)[zero quad]: the same products as the full table holds there
+        cx *cm = reinterpret_cast<cx *>(mask_s);
+        for (int i = (int)threadIdx.x; i < A.band_n + 8; i += (int)blockDim.x) {
+            const int k = A.band_lo4 + i - 4;
+            cx v = cx{0.0f, 0.0f};
+            if (i >= 4 && i < A.band_n + 4 && k < nf) {
+                const float m = A.mask[k];
+                const cx h = A.cmask[k];
+                v = cx{h.x * m, h.y * m};
+            }
+            cm[i] = v;
+        }
+    } else if constexpr (CMASK) {
         cx *cm = reinterpret_cast<cx *>(mask_s);
         for (int i = (int)threadIdx.x; i < nf; i += (int)blockDim.x) {
             const float m = A.mask[i];
@@ -1313,13 +1355,13 @@ __global__ __launch_bounds__(512) void k_f(FArgs A, FTables T)
     // spectrum stores (+ the inverse transform of the fused chain)
     auto part_b = [&]() {
         if constexpr (MODE != kInv) {
-            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS, TC, MODE != kPipe>(buf, launder_uniform((const cx *)w2n_s),
+            f_spectrum_epilogue<P, AMP_PHASE, CMASK, SUMS, TC, MODE != kPipe, BAND>(buf, launder_uniform((const cx *)w2n_s),
                                                                               launder_uniform((const cx *)wg_s), mask_l, p, A, lane,
                                                                               &sums);
             if constexpr (MODE == kPipe) {
                 cx r[C1][R1];
-                f_inverse_input<P, true, CMASK, TC, true>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
-                                                          mask_l, lane, r, A.fft_out + p * nf);
+                f_inverse_input<P, true, CMASK, TC, true, BAND>(buf, launder_uniform((const cx *)w2n_s), launder_uniform((const cx *)wg_s),
+                                                                mask_l, lane, r, A.fft_out + p * nf, 4 - A.band_lo4, A.band_n + 4);
                 wave_sync();  // every lane has read Z before the core overwrites buf
                 f_core_pass1<P, TC>(r, buf, t1, ad, lane);
                 if (p + stride < A.npix) f_load_raw<P>(A.in + (p + stride) * NT, lane, raw);

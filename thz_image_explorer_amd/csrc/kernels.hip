@@ -1886,6 +1886,13 @@ static void dispatch_f_size(hipStream_t st, const PlanDev &P, const FArgs &A)
     }
 }
 
+// the band-limited complex multiplier table (kCfgBand) is built for the one configuration it buys a wave for: nt = 4096
+// with the in-launch sums; the caller's band must fit the table
+static bool f_band_fits(const PlanDev &P, int lo4, int n)
+{
+    return P.nt == 4096 && n > 0 && n <= FPlan4096::BAND_BINS && lo4 >= 0 && lo4 % 4 == 0 && n % 4 == 0;
+}
+
 template <int MODE>
 static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool amp_phase)
 {
@@ -1898,7 +1905,9 @@ static void dispatch_f(hipStream_t st, const PlanDev &P, const FArgs &A, bool am
         int cfg = ((MODE == kPipe || amp_phase) ? kCfgAmpPhase : 0) | (A.cmask ? kCfgCMask : 0) | bar;
         if constexpr (MODE == kPipe) {
             if (A.sum_partial) {  // pixel sums inside the launch: the block-uniform trace loop of the barrier builds
-                if (A.cmask) dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A);
+                if (A.cmask && f_band_fits(P, A.band_lo4, A.band_n))   // nt = 4096: the band-limited table keeps the eighth wave
+                    launch_f<FPlan4096, MODE, kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums | kCfgBand>(st, P, A);
+                else if (A.cmask) dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums>(st, P, A);
                 else dispatch_f_size<MODE, kCfgBar | kCfgAmpPhase | kCfgSums>(st, P, A);
                 return;
             }
@@ -2191,8 +2200,12 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 // Rows of the partial-sum workspace (2 nf floats each) a fused launch with in-kernel pixel sums needs for npix
 // traces — one per block of its grid — or 0 when this plan has no fused kernel that sums (other families).
 template <class PL>
-static size_t f_sum_rows(size_t npix, bool cmask)
+static size_t f_sum_rows(size_t npix, bool cmask, bool band = false)
 {
+    if (cmask && band) {
+        constexpr int CFG = kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums | kCfgBand;
+        return f_grid<PL, kPipe, CFG>(npix);
+    }
     if (cmask) {
         constexpr int CFG = kCfgBar | kCfgAmpPhase | kCfgCMask | kCfgSums;
         return f_grid<PL, kPipe, CFG>(npix);
@@ -2201,7 +2214,7 @@ static size_t f_sum_rows(size_t npix, bool cmask)
     return f_grid<PL, kPipe, CFG>(npix);
 }
 
-size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
+size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask, int band_lo4, int band_n)
 {
     if (npix == 0) return 0;
     if (P.family == kFamilyP) {
@@ -2215,7 +2228,7 @@ size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
     }
     if (P.family != kFamilyF) return 0;
     switch (P.nt) {
-    case 4096: return f_sum_rows<FPlan4096>(npix, cmask);
+    case 4096: return f_sum_rows<FPlan4096>(npix, cmask, cmask && f_band_fits(P, band_lo4, band_n));
     case 2048: return f_sum_rows<FPlan2048>(npix, cmask);
     default: return f_sum_rows<FPlan1024>(npix, cmask);
     }
@@ -2224,7 +2237,7 @@ size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask)
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask,
-                     float *sum_partial)
+                     float *sum_partial, int band_lo4, int band_n)
 {
     if (P.family == kFamilyF && fft_out && amp_out && ph_out) {
         FArgs A{};
@@ -2233,6 +2246,7 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.cmask = reinterpret_cast<const cx *>(cmask);
         A.data_out = data_out; A.img = img;
         A.sum_partial = sum_partial;  // pipeline_sum_rows(P, npix, cmask) rows, or null
+        A.band_lo4 = band_lo4; A.band_n = band_n;
         dispatch_f<kPipe>(st, P, A, true);
         return;
     }

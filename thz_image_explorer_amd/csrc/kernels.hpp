@@ -103,11 +103,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
 // sum_partial: pipeline_sum_rows(P, npix, cmask != nullptr) rows of 2 nf floats, or null — every block's sums of the
 // stored amplitudes | unwrapped phases of its traces (the F kernels' kCfgSums, fft_f.hpp); a second small launch
 // (launch_sum_axis0 over the rows) makes the pixel sums of them
-size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask);
+// band_lo4 / band_n (multiples of 4; 0, 0 = unknown): the bins outside [band_lo4, band_lo4 + band_n) are zero in `mask` —
+// lets the nt = 4096 chain with a complex multiplier and the sums stage a band-limited table (fft_f.hpp, kCfgBand)
+size_t pipeline_sum_rows(const PlanDev &P, size_t npix, bool cmask, int band_lo4 = 0, int band_n = 0);
 void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float *raw,
                      const float *pre_win, const float *mask, const float *post_win, c32 *fft_out,
                      float *amp_out, float *ph_out, float *data_out, float *img, const c32 *cmask = nullptr,
-                     float *sum_partial = nullptr);
+                     float *sum_partial = nullptr, int band_lo4 = 0, int band_n = 0);
 void launch_fd_mask(hipStream_t st, size_t npix, int nf, c32 *fft, float *amp, const float *mask);
 void launch_fd_cmask(hipStream_t st, size_t npix, int nf, int nt, c32 *fft, float *amp,
                      const c32 *cmask);

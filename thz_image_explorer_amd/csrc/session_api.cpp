@@ -397,8 +397,9 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
         }
         if (int rc = thz_memcpy_h2d(ctx, s->d_wsep, sep.data(), sep.size() * sizeof(float))) return rc;
     }
+    int64_t band_lo = 0, band_hi = 0;  // [lower, upper) of the Frequency Band Pass: zero outside (band_pass_fd.rs:194-212)
     if (cfg->fd_active)
-        fd_bandpass(ctx->freq.data(), nf, cfg->fd_low, cfg->fd_high, cfg->fd_width, mask.data(), nullptr, nullptr);
+        fd_bandpass(ctx->freq.data(), nf, cfg->fd_low, cfg->fd_high, cfg->fd_width, mask.data(), &band_lo, &band_hi);
     // further Frequency-domain plugins behind the band pass (K14: a real multiplier, one f32 multiply per
     // plugin like the band pass itself)
     if (!s->fd_real.empty())
@@ -448,7 +449,11 @@ int session_enqueue(thz_session *s, const thz_chain_cfg *cfg, int start_stage, b
     io.d_raw = src; io.d_pre_win = d_pre; io.d_fd_mask = d_mask; io.d_fd_cmask = s->fd_cmask.empty() ? nullptr : d_cmask;
     io.d_post_win = d_post; io.d_fft = s->d_fft; io.d_amp = s->d_amp; io.d_phase = s->d_ph; io.d_data_out = s->d_data;
     io.d_img = s->d_img; io.d_sums = s->msum_fast ? s->d_msum + nt_cur : nullptr;
-    if (int rc = thz_pipeline_ex(ctx, npix, &io)) return rc;
+    io.band_lo = io.band_hi = 0;
+    // the band pass's own index range tells the fused kernel where its multiplier is zero (a further real plugin, K14,
+    // only adds zeros inside)
+    const bool band_known = cfg->fd_active && band_hi > band_lo && band_lo >= 0 && (size_t)band_hi <= nf;
+    if (int rc = pipeline_ex_band(ctx, npix, &io, band_known ? (size_t)band_lo : 0, band_known ? (size_t)band_hi : 0)) return rc;
     if (s->msum_passes) {
         if (int rc = thz_pixel_sum(ctx, npix, nf, 2, s->d_fft, s->d_msum + nt_cur)) return rc;
         if (int rc = thz_pixel_sum(ctx, npix, nf, 1, s->d_amp, s->d_msum + nt_cur + 2 * nf)) return rc;
