@@ -471,6 +471,10 @@ static int group_p2p(thz_group *g, int from, int to, const float *const *d_src, 
         GHIP_TRY(g, hipEventRecord(g->m[(size_t)lf].ev, g->m[(size_t)lf].ctx->stream));
         GHIP_TRY(g, hipStreamWaitEvent(g->m[(size_t)lt].ctx->stream, g->m[(size_t)lf].ev, 0));
         GHIP_TRY(g, hipMemcpyAsync(d_dst[lt], d_src[lf], count * sizeof(float), hipMemcpyDeviceToDevice, g->m[(size_t)lt].ctx->stream));
+        // ... and the sender's stream behind the copy, as a send on its own stream would be: the sender may write its
+        // buffer again right away (the carried means reuse one running-sum buffer for all three arrays)
+        GHIP_TRY(g, hipEventRecord(g->m[(size_t)lt].ev, g->m[(size_t)lt].ctx->stream));
+        GHIP_TRY(g, hipStreamWaitEvent(g->m[(size_t)lf].ctx->stream, g->m[(size_t)lt].ev, 0));
         return THZ_OK;
     }
     Rccl &r = rccl();
