@@ -47,6 +47,8 @@ for e in (a, b):
 for r in range(rounds + 1):
     for vname, fn in variants.items():
         for name, e in (("this", a), ("other", b)):
+            if os.environ.get("THZ_AB_VERBOSE"):
+                print(f"round {r} {vname} {name}", flush=True)
             for _ in range(3):
                 fn(e)
             e.sync()

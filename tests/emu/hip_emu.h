@@ -171,6 +171,7 @@ inline float wave_reduce_add(float v) { return wave_bcast<63>(wave_scan_add(v));
 }  // namespace thz
 
 #define THZ_DYN_LDS(name) unsigned char *name = thz_emu::g_dyn_lds
+#define THZ_WAVES_PER_SIMD(n)
 namespace thz {
 template <class T>
 inline const T *launder_uniform(const T *p) { return p; }

@@ -1037,6 +1037,92 @@ __global__ __launch_bounds__(512) void k_dc_energy_f(FTables T, size_t npix, int
     }
 }
 
+// Round 3: the same work at three waves per SIMD.  k_dc_energy_f keeps the NEXT band's multiplier in 32 registers
+// while a band's passes run (206 VGPRs at N = 1024: two waves per SIMD, eight per CU) and is bound by the latency of
+// its five LDS round trips per band, not by arithmetic.  Here the multiplier rows are loaded where they are
+// consumed (157 VGPRs, no scratch), blocks are four waves, three blocks share a CU: twelve waves hide the L2 round
+// trip of the rows and each other's LDS waits.  The band's energy is summed out of the core's output at the top of the
+// next trip, so the stores of one band and the loads of the next are issued back to back.
+template <class PL>
+__global__ __launch_bounds__(256) THZ_WAVES_PER_SIMD(PL::N <= 512 ? 4 : 3) void k_dc_energy_f3(
+    FTables T, size_t npix, int nt, int n_bands, int shift, const cx *__restrict__ spec, const cx *__restrict__ H,
+    float *__restrict__ energy)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int N = PL::N, R1 = PL::R1, C1 = PL::C1;
+    const int nf = N + 1;
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + PL::T1_ENTRIES;
+    cx *w2n_s = t2 + PL::T2_ENTRIES;
+    cx *wg_s = w2n_s + PL::W2N_HEAD;
+    cx *buf = wg_s + PL::WG_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
+    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
+    if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[PL::M1 * (int)threadIdx.x];
+    for (int i = (int)threadIdx.x; i < PL::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < PL::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    __syncthreads();
+    FAddr<PL> ad;
+    ad.init(lane);
+    const int s2 = (lane >> 4) & 3;
+    const int sb2 = (2 * lane) ^ (s2 & 2);
+    const bool swap2 = (s2 & 1) != 0;
+    const int sb1a = nat(lane), sb1b = nat(kWave + lane) - kWave;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        float xs[R1][2 * C1];
+        f_load_spec<PL>(spec + p * nf, lane, xs);
+        const float x_nyq = spec[p * nf + N].x;
+#pragma unroll 1
+        for (int b = 0; b <= n_bands; ++b) {
+            if (b > 0) {  // band b - 1: energy over the "same" slice, out of the core's output
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    float v[2 * C1];
+                    if constexpr (C1 == 2) {
+                        const cx2 rr = ld2(buf + sb2 + 2 * kWave * j);
+                        const cx e0 = swap2 ? rr.b : rr.a, e1 = swap2 ? rr.a : rr.b;
+                        v[0] = e0.y; v[1] = e0.x; v[2] = e1.y; v[3] = e1.x;
+                    } else {
+                        const cx rr = buf[((j & 1) ? sb1b : sb1a) + kWave * j];
+                        v[0] = rr.y; v[1] = rr.x;
+                    }
+                    const int t0 = 2 * C1 * (kWave * j + lane) - shift;
+#pragma unroll
+                    for (int i = 0; i < 2 * C1; ++i)
+                        if (t0 + i >= 0 && t0 + i < nt) acc += v[i] * v[i];
+                }
+                acc = wave_reduce_add(acc);
+                if (lane == 0) energy[(size_t)(b - 1) * npix + p] = acc;
+                wave_sync();
+                if (b == n_bands) break;
+            }
+            ad.refresh();
+            float hs[R1][2 * C1];
+            f_load_spec<PL>(H + (size_t)b * nf, lane, hs);
+            const float h_nyq = H[(size_t)b * nf + N].x;
+#pragma unroll
+            for (int j = 0; j < R1; ++j) {
+                if constexpr (C1 == 2) {
+                    const cx e0 = cx_mul(cx{xs[j][0], xs[j][1]}, cx{hs[j][0], hs[j][1]});
+                    const cx e1 = cx_mul(cx{xs[j][2], xs[j][3]}, cx{hs[j][2], hs[j][3]});
+                    st2(buf + sb2 + 2 * kWave * j, swap2 ? e1 : e0, swap2 ? e0 : e1);
+                } else {
+                    buf[((j & 1) ? sb1b : sb1a) + kWave * j] = cx_mul(cx{xs[j][0], xs[j][1]}, cx{hs[j][0], hs[j][1]});
+                }
+            }
+            if (lane == 0) buf[N] = cx{x_nyq * h_nyq, 0.0f};
+            wave_sync();
+            cx r[C1][R1];
+            f_inverse_input<PL, false>(buf, w2n_s, wg_s, nullptr, lane, r);
+            wave_sync();
+            f_core_pass1<PL>(r, buf, t1, ad, lane);
+            f_core_pass23<PL>(buf, t2, ad, lane);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dc_combine(PlanDev P, size_t npix, int nt, int n_bands,
                                                     int shift, const c32 *__restrict__ spec,
                                                     const c32 *__restrict__ H,
@@ -1531,9 +1617,10 @@ __global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1)
 // Pass A reuses the wide kernel's window arithmetic (four pixels side by side per thread, packed FMAs): a
 // quarter wave reads 16 consecutive halo rows at one column group, conflict-free for an odd row stride in 16-byte
 // units.
-constexpr int kRlSepThreads = kRlSepTileCols * kRlSepTileRows;  // a thread per pixel of the tile
+constexpr int kRlSepThreads = kRlSepTileCols * kRlSepTileRows;  // the largest block: a thread per pixel of the tile
 constexpr int kRlSepQuads = kRlSepTileCols / kRlPix;              // column groups of four per halo row (pass A)
-constexpr int kRlSepRows = (kRlSepTileRows + 48 + kRlSepThreads / 64 - 1) / (kRlSepThreads / 64);  // halo rows a wave has in flight while staging: kernels of up to 49 rows in one batch
+// halo rows a wave has in flight while staging: kernels of up to 49 rows in one batch (of at most twelve rows per wave)
+constexpr int rl_sep_rows(int nt) { return (kRlSepTileRows + 48 + nt / 64 - 1) / (nt / 64) < 12 ? (kRlSepTileRows + 48 + nt / 64 - 1) / (nt / 64) : 12; }
 
 __host__ __device__ inline int rl_sep_stride(int pc)
 {
@@ -1543,56 +1630,73 @@ __host__ __device__ inline int rl_sep_stride(int pc)
     if (w / 4 % 2 == 0) w += 4;
     return w;
 }
-// LDS floats of a block: halo rows | fy (whole chunks) | fx | T
+// T of pass A is kept TRANSPOSED — column tj of the tile is the contiguous row tj of T', halo rows along it — so that
+// pass B is pass A's window arithmetic turned by ninety degrees (four pixels below each other per thread, one 16-byte
+// read per four halo rows and a broadcast of sixteen taps): the stride of a column is the column pass's counterpart of
+// rl_sep_stride
+__host__ __device__ inline int rl_sep_tstride(int pr) { return rl_sep_stride(pr); }
+// LDS floats of a block: halo rows | fy (whole chunks) | fx (whole chunks) | T' (a row per tile column)
 __host__ __device__ inline size_t rl_sep_floats(int pr, int pc)
 {
     const int hs = kRlSepTileRows + pr - 1;
-    return (size_t)hs * rl_sep_stride(pc) + (size_t)((pc + kRlChunk - 1) / kRlChunk) * kRlChunk + (size_t)(pr + 3) / 4 * 4
-           + (size_t)hs * kRlSepTileCols;
+    return (size_t)hs * rl_sep_stride(pc) + (size_t)((pc + kRlChunk - 1) / kRlChunk) * kRlChunk
+           + (size_t)((pr + kRlChunk - 1) / kRlChunk) * kRlChunk + (size_t)kRlSepTileCols * rl_sep_tstride(pr);
 }
 
-__global__ __launch_bounds__(kRlSepThreads, 8) void k_rl_step_sep(const RlTileRef *__restrict__ tiles,
+// NT threads per block (1 024, 512 or 256): a tile's passes need 624 / 256 tasks at most, and what a launch costs is the
+// blocks' latency times the rounds of blocks the chip needs — fewer waves per block put more tiles on a CU at once
+template <int NT>
+__global__ __launch_bounds__(NT, 8) void k_rl_step_sep(const RlTileRef *__restrict__ tiles,
                                                                const int *__restrict__ it_base, int iteration, int step,
                                                                float *__restrict__ ws)
 {
     THZ_DYN_LDS(smem);
+    constexpr int kRows = rl_sep_rows(NT);
     const RlBand B = rl_block_band(tiles, it_base, iteration);
     if (iteration >= B.n_iter) return;  // block-uniform
     const int pr = B.pr, pc = B.pc;
     const int hs = kRlSepTileRows + pr - 1, wsz = kRlSepTileCols + pc - 1;
     const int nch = rl_chunks(pc), wsp = rl_sep_stride(pc);
+    const int nchr = rl_chunks(pr), hsp = rl_sep_tstride(pr);  // the column pass: chunks of fx, stride of a column of T'
     const unsigned a_off = step == 0 ? B.off_u : B.off_t;
     const float *fx = ws + B.off_fx, *fy = ws + B.off_fy;
     float *a_s = reinterpret_cast<float *>(smem);
     float *fy_s = a_s + (size_t)hs * wsp;
     float *fx_s = fy_s + nch * kRlChunk;
-    float *t_s = fx_s + (pr + 3) / 4 * 4;
+    float *t_s = fx_s + nchr * kRlChunk;  // T'[tj][r], r < hsp
     const unsigned lt = blockIdx.x - B.tblk0;
     const int ti0 = (int)(lt / (unsigned)B.tiles_w) * kRlSepTileRows, tj0 = (int)(lt % (unsigned)B.tiles_w) * kRlSepTileCols;
     // first image row / column of the halo: x = i + (pr-1)/2 - m
     const int r0 = ti0 + (pr - 1) / 2 - (pr - 1), c0 = tj0 + (pc - 1) / 2 - (pc - 1);
     const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
     const int px = (int)threadIdx.x;
-    const int ti = px / kRlSepTileCols, tj = px % kRlSepTileCols;
-    const int i = ti0 + ti, j = tj0 + tj;
-    const bool writer = i < B.H && j < B.W;
-    const int idx = i * B.W + j;
+    // pass B and the update: the first 256 threads, each four pixels below each other in one column of the tile
+    constexpr int kColTasks = kRlSepTileCols * (kRlSepTileRows / kRlPix);
+    static_assert(kColTasks <= NT && kRlSepTileCols == 32, "a 16-lane group of pass B reads sixteen different columns");
+    const int tj = px % kRlSepTileCols, tq = (px / kRlSepTileCols) % (kRlSepTileRows / kRlPix);
+    const int i0 = ti0 + kRlPix * tq, j = tj0 + tj;
+    const bool col_task = px < kColTasks;
+    const int idx0 = i0 * B.W + j;
     // Everything the block reads from memory is requested before anything is waited for — one round trip, not four:
     // the profiles (step 0 convolves with the PSF: reversed profiles in this upward walk; step 1 with its mirror
     // image), the update's other operand, which does not depend on the sums, and then the halo.
-    float fy_v = 0.0f, fx_v = 0.0f, other = 0.0f;
+    float fy_v = 0.0f, fx_v = 0.0f, other[kRlPix] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (px < pc) fy_v = fy[step == 0 ? pc - 1 - px : px];
     if (px < pr) fx_v = fx[step == 0 ? pr - 1 - px : px];
-    if (writer) other = ws[(step == 0 ? B.off_d : B.off_u) + idx];
+    if (col_task && j < B.W) {
+        const unsigned o_off = step == 0 ? B.off_d : B.off_u;
+#pragma unroll
+        for (int k = 0; k < kRlPix; ++k) other[k] = ws[i0 + k < B.H ? o_off + (unsigned)(idx0 + k * B.W) : B.off_zero];
+    }
     {   // a wave per halo row, lanes along the row; zeros outside the image and beyond the halo's last column.
         // The tile's input was written by other CUs in the launch before, so every load is a trip to the far side
-        // of the L2s: kRlSepRows rows x 2 column passes of loads are issued before the first is waited for (with the
+        // of the L2s: kRows rows x 2 column passes of loads are issued before the first is waited for (with the
         // plain loop the compiler kept four in flight, and the staging alone lasted eight round trips).
         // Rows are wave-uniform (scalar tests), the column tests of a pass are made once; a position outside the image
         // loads a stored zero, so the loads are unconditional, issue back to back and leave no masks to keep.
         const int wvu = THZ_UNIFORM(wv);
         auto stage = [&](int rb, int cb) {
-            float v[kRlSepRows][2];
+            float v[kRows][2];
             bool cok[2];
             unsigned yv[2];
 #pragma unroll
@@ -1602,16 +1706,16 @@ __global__ __launch_bounds__(kRlSepThreads, 8) void k_rl_step_sep(const RlTileRe
                 yv[p] = (unsigned)y;
             }
 #pragma unroll
-            for (int k = 0; k < kRlSepRows; ++k) {
-                const int r = rb + k * (kRlSepThreads / kWave), x = r0 + r;
+            for (int k = 0; k < kRows; ++k) {
+                const int r = rb + k * (NT / kWave), x = r0 + r;
                 const bool row_ok = r < hs && x >= 0 && x < B.H;
                 const unsigned row_at = a_off + (unsigned)(x * B.W);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) v[k][p] = ws[row_ok && cok[p] ? row_at + yv[p] : B.off_zero];
             }
 #pragma unroll
-            for (int k = 0; k < kRlSepRows; ++k) {
-                const int r = rb + k * (kRlSepThreads / kWave);
+            for (int k = 0; k < kRows; ++k) {
+                const int r = rb + k * (NT / kWave);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int c = cb + p * kWave;
@@ -1622,42 +1726,48 @@ __global__ __launch_bounds__(kRlSepThreads, 8) void k_rl_step_sep(const RlTileRe
         // the first batch — the whole halo for kernels of up to 49 x 80 taps — stands in front of the loops: at a
         // loop head the compiler waits for every load in flight, which would put the profiles' round trip in
         // front of the halo's
-        constexpr int kRowsPerBatch = kRlSepRows * (kRlSepThreads / kWave);
+        constexpr int kRowsPerBatch = kRows * (NT / kWave);
         stage(wvu, ln);
         for (int cb = ln + 2 * kWave; cb < wsp; cb += 2 * kWave) stage(wvu, cb);
         for (int rb = wvu + kRowsPerBatch; rb < hs; rb += kRowsPerBatch)
             for (int cb = ln; cb < wsp; cb += 2 * kWave) stage(rb, cb);
         if (px < nch * kRlChunk) fy_s[px] = fy_v;
-        if (px < pr) fx_s[px] = fx_v;
-        for (int n = px + kRlSepThreads; n < nch * kRlChunk; n += kRlSepThreads)  // profiles of more than 256 taps
+        if (px < nchr * kRlChunk) fx_s[px] = fx_v;  // zeros behind the profile: whole chunks of taps
+        for (int n = px + NT; n < nch * kRlChunk; n += NT)  // profiles of more than 1 024 taps
             fy_s[n] = n < pc ? fy[step == 0 ? pc - 1 - n : n] : 0.0f;
-        for (int m = px + kRlSepThreads; m < pr; m += kRlSepThreads) fx_s[m] = fx[step == 0 ? pr - 1 - m : m];
+        for (int m = px + NT; m < nchr * kRlChunk; m += NT) fx_s[m] = m < pr ? fx[step == 0 ? pr - 1 - m : m] : 0.0f;
+        // what a column window of pass B reaches behind the last halo row is multiplied by those zero taps: finite
+        for (int n = px; n < kRlSepTileCols * (hsp - hs); n += NT) t_s[(n / (hsp - hs)) * hsp + hs + n % (hsp - hs)] = 0.0f;
     }
     __syncthreads();
-    // pass A: (halo row, column group of four) per thread
-    for (int task = px; task < (hs + 15) / 16 * (16 * kRlSepQuads); task += kRlSepThreads) {
+    // pass A: (halo row, column group of four) per thread; T' takes the four sums as four 4-byte stores — a quarter
+    // wave (16 consecutive halo rows, one column group) writes 16 consecutive floats of each of its four columns
+    for (int task = px; task < (hs + 15) / 16 * (16 * kRlSepQuads); task += NT) {
         const int r = task / (16 * kRlSepQuads) * 16 + (task & 15), q = (task >> 4) % kRlSepQuads;  // a quarter wave: 16 rows, one column group
         if (r >= hs) continue;
         float acc[kRlPix];
         rl_tile_taps_split(a_s + r * wsp + 4 * q, wsp, fy_s, pc, 0, 1, acc);  // acc[p] = sum_n w[3 - p + n] fy_s[n]
-        *reinterpret_cast<float4 *>(t_s + r * kRlSepTileCols + 4 * q) = float4{acc[3], acc[2], acc[1], acc[0]};
+        float *tc = t_s + (4 * q) * hsp + r;
+        tc[0] = acc[3];
+        tc[hsp] = acc[2];
+        tc[2 * hsp] = acc[1];
+        tc[3 * hsp] = acc[0];
     }
     __syncthreads();
-    if (!writer) return;
-    // pass B: a pixel per thread, four partial sums
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    const float *col = t_s + ti * kRlSepTileCols + tj;
-    int m = 0;
-    for (; m + 4 <= pr; m += 4) {
-        s0 = fmaf(col[(m + 0) * kRlSepTileCols], fx_s[m + 0], s0);
-        s1 = fmaf(col[(m + 1) * kRlSepTileCols], fx_s[m + 1], s1);
-        s2 = fmaf(col[(m + 2) * kRlSepTileCols], fx_s[m + 2], s2);
-        s3 = fmaf(col[(m + 3) * kRlSepTileCols], fx_s[m + 3], s3);
+    if (!col_task) return;
+    // pass B: column tj, tile rows 4 tq .. 4 tq + 3: out[4 tq + k] = sum_m T'[tj][4 tq + k + m] fx_s[m] — the window
+    // routine over a column of T' (round 3: it was a pixel per thread, one 4-byte read of T and one of fx per tap, the
+    // longest stretch of a tile's LDS time; now 16-byte reads, a quarter of the threads, packed FMAs)
+    float sum[kRlPix];
+    rl_tile_taps_split(t_s + tj * hsp + kRlPix * tq, hsp, fx_s, pr, 0, 1, sum);  // sum[p] = sum_m w[3 - p + m] fx_s[m]
+    if (j >= B.W) return;
+#pragma unroll
+    for (int k = 0; k < kRlPix; ++k) {
+        if (i0 + k >= B.H) break;
+        const float sm = sum[kRlPix - 1 - k];
+        if (step == 0) ws[B.off_t + idx0 + k * B.W] = other[k] / (sm + 1e-12f);
+        else ws[B.off_u + idx0 + k * B.W] = other[k] * sm;
     }
-    for (; m < pr; ++m) s0 = fmaf(col[m * kRlSepTileCols], fx_s[m], s0);
-    const float sum = (s0 + s1) + (s2 + s3);
-    if (step == 0) ws[B.off_t + idx] = other / (sum + 1e-12f);
-    else ws[B.off_u + idx] = other * sum;
 }
 
 __global__ __launch_bounds__(256) void k_dc_filter_spectra(const float *__restrict__ filters, int n_bands,
@@ -2571,6 +2681,25 @@ template <class PL>
 static void launch_dc_energy_f(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                                const c32 *spec, const c32 *H, float *energy)
 {
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
+              reinterpret_cast<const cx *>(P.f_w2n)};
+    // N <= 1024 (nt + 498 <= 2048: every scan of the sample data): four waves per block, three blocks per CU
+    // (k_dc_energy_f3).  THZ_DC_ENERGY_OLD=1 (developer knob) keeps round 2's eight-wave blocks for A/B runs.
+    static const bool old_form = getenv("THZ_DC_ENERGY_OLD") != nullptr;
+    if constexpr (PL::N <= 1024) if (!old_form) {
+        const unsigned w3 = 4;
+        const size_t lds3 = (size_t)(PL::T1_ENTRIES + PL::T2_ENTRIES + PL::W2N_HEAD + PL::WG_ENTRIES + w3 * PL::WAVE_ENTRIES) * sizeof(cx);
+        size_t per_cu3 = kLdsBytesPerCU / lds3;
+        const size_t occ3 = PL::N <= 512 ? 4 : 3;  // waves per SIMD the kernel is compiled for = blocks of four waves per CU
+        if (per_cu3 > occ3) per_cu3 = occ3;
+        if (per_cu3 < 1) per_cu3 = 1;
+        size_t g3 = (npix + w3 - 1) / w3;
+        if (g3 > (size_t)kNumCU * per_cu3) g3 = (size_t)kNumCU * per_cu3;
+        allow_dynamic_lds(k_dc_energy_f3<PL>, lds3);
+        THZ_LAUNCH((k_dc_energy_f3<PL>), (unsigned)g3, w3 * kWave, lds3, st, T, npix, nt, n_bands, shift,
+                   reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), energy);
+        return;
+    }
     const unsigned wpb = 8;
     const size_t lds = (size_t)(PL::T1_ENTRIES + PL::T2_ENTRIES + PL::W2N_HEAD + PL::WG_ENTRIES + wpb * PL::WAVE_ENTRIES)
                        * sizeof(cx);
@@ -2579,8 +2708,6 @@ static void launch_dc_energy_f(hipStream_t st, const PlanDev &P, size_t npix, in
     if (per_cu > 2) per_cu = 2;
     size_t g = (npix + wpb - 1) / wpb;
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
-    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
-              reinterpret_cast<const cx *>(P.f_w2n)};
     allow_dynamic_lds(k_dc_energy_f<PL>, lds);
     THZ_LAUNCH((k_dc_energy_f<PL>), (unsigned)g, wpb * kWave, lds, st, T, npix, nt, n_bands, shift,
                reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), energy);
@@ -2663,9 +2790,31 @@ size_t rl_tile_lds_bytes(int pr, int pc, bool separable)
 
 unsigned rl_tile_block_count(int pr, int pc, unsigned n_tiles) { return rl_tile_blocks(rl_turned(pr, pc), n_tiles); }
 
+// threads of a separable tile's block.  Measured (profiles/r03_rl_block_size.txt): while a launch needs several rounds
+// of blocks on the chip (512 x 512 pixels: 2 128 tiles for 512 places of 1 024 threads) eight waves per tile put three
+// tiles on a CU instead of two and the iterations take 24.0 ms instead of 26.2; once every tile has a place (128 x 128:
+// 112 tiles) the sixteen-wave block is the shorter one (6.65 against 7.07 ms); four waves lose both ways.
+// THZ_RL_SEP_THREADS (developer knob) overrides.
+static int rl_sep_threads(unsigned total_tiles)
+{
+    static const int forced = [] {
+        if (const char *e = getenv("THZ_RL_SEP_THREADS")) {
+            const int v = atoi(e);
+            if (v == 256 || v == 512 || v == 1024) return v;
+        }
+        return 0;
+    }();
+    if (forced) return forced;
+    return total_tiles > 2u * kNumCU ? 512 : 1024;
+}
+
 void prepare_rl_step_tiled(int kind, size_t lds_bytes)
 {
-    if (kind == kRlSeparable) allow_dynamic_lds(k_rl_step_sep, lds_bytes);
+    if (kind == kRlSeparable) {
+        allow_dynamic_lds(k_rl_step_sep<1024>, lds_bytes);
+        allow_dynamic_lds(k_rl_step_sep<512>, lds_bytes);
+        allow_dynamic_lds(k_rl_step_sep<256>, lds_bytes);
+    }
     else if (kind == kRlWide) allow_dynamic_lds(k_rl_step_tiled<true>, lds_bytes);
     else allow_dynamic_lds(k_rl_step_tiled<false>, lds_bytes);
 }
@@ -2674,7 +2823,12 @@ void launch_rl_step_tiled(hipStream_t st, int kind, const RlTileRef *d_tiles, un
                           const int *it_base, int iteration, int step, float *ws)
 {
     if (total_tiles == 0) return;
-    if (kind == kRlSeparable) THZ_LAUNCH(k_rl_step_sep, total_tiles, kRlSepThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    if (kind == kRlSeparable) {
+        const int nt_sep = rl_sep_threads(total_tiles);
+        if (nt_sep == 256) THZ_LAUNCH(k_rl_step_sep<256>, total_tiles, 256, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+        else if (nt_sep == 512) THZ_LAUNCH(k_rl_step_sep<512>, total_tiles, 512, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+        else THZ_LAUNCH(k_rl_step_sep<1024>, total_tiles, 1024, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
+    }
     else if (kind == kRlWide) THZ_LAUNCH(k_rl_step_tiled<true>, total_tiles, kRlThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
     else THZ_LAUNCH(k_rl_step_tiled<false>, total_tiles, kRlNarrowThreads, lds_bytes, st, d_tiles, it_base, iteration, step, ws);
 }

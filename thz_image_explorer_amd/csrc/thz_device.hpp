@@ -136,6 +136,8 @@ __device__ __forceinline__ float wave_scan_add(float v)
 __device__ __forceinline__ float wave_reduce_add(float v) { return wave_bcast<kWave - 1>(wave_scan_add(v)); }
 
 #define THZ_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]
+// waves per SIMD a kernel is compiled for (register budget 512 / n); nothing in the emulation
+#define THZ_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 // Stops the machine scheduler from moving instructions across this point: the
 // fully unrolled passes otherwise get all their LDS/global loads hoisted to the
