@@ -252,9 +252,10 @@ def test_group_session_shards_what_it_used_to_refuse(engine, shape, members, var
 
 
 def test_group_session_band_parallel_deconvolution(engine):
-    """BASELINE config 4's "1 -> 2 GPUs": the Deconvolution stage sharded by band over the group (all-gather of the
-    slabs, each rank its bands, all-reduce of the band sums) == the single-session stage; a guard on every rank and
-    an abort both leave the input as the stage's output"""
+    """BASELINE config 4's "1 -> 2 GPUs": the Deconvolution stage over the group — every member the transform, band
+    energies and recombination of its own rows, the Richardson-Lucy iterations of its own bands over the whole image,
+    energies and gains exchanged as 2-D images (round 2: all-gather of the cube, all-reduce of band sums) — equals the
+    single-session stage; a guard on every rank and an abort both leave the input as the stage's output"""
     import ctypes
     import os
     nx, ny, nt = 36, 32, 256
@@ -282,8 +283,10 @@ def test_group_session_band_parallel_deconvolution(engine):
                 img_plain = gs.download(pkg.BUF_IMG).copy()
                 assert gs.deconvolve(psf, dcfg) == 0
                 got, img = gs.download(pkg.BUF_DATA), gs.download(pkg.BUF_IMG)
-                assert rel(got, want) < TOL          # the band sums associate differently
-                assert rel(img, want_img) < TOL
+                # every pixel's recombination runs over all bands in one member, in the single session's order: what can
+                # differ is which traces share a transform — nothing here (nt = 256)
+                assert rel(got, want) < 1e-6
+                assert rel(img, want_img) < 1e-6
                 # slabs hold their rows of the same result
                 rows = np.concatenate([gs.member(i).download(pkg.BUF_DATA) for i in range(members)])
                 assert np.array_equal(rows, got)

@@ -78,12 +78,22 @@ struct thz_ctx {
         unsigned bank_gen = 0;
         int b0 = -1, b1 = -1;
     } dc_spectra;
+    // the spectra of a slab's traces between the energies phase and the recombination phase of a group's
+    // Deconvolution stage (thz_dc_slab_energies / thz_dc_slab_combine, deconv_api.cpp)
+    struct DcSlab {
+        c32 *d_spec = nullptr;
+        size_t cap = 0;            // entries allocated
+        size_t npix = 0, nk = 0;   // what it holds: npix rows of nk bins
+        size_t M = 0;
+    } dc_slab;
     void drop_dc_tables()
     {
         if (dc_plan.d_tw) (void)hipFree(dc_plan.d_tw);
         if (dc_spectra.d_H) (void)hipFree(dc_spectra.d_H);
+        if (dc_slab.d_spec) (void)hipFree(dc_slab.d_spec);
         dc_plan = DcPlan{};
         dc_spectra = DcSpectra{};
+        dc_slab = DcSlab{};
     }
     int timing = 0;  // 0 off, 1 immediate (host waits per call), 2 deferred (no host wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -95,6 +105,21 @@ struct thz_ctx {
     std::vector<Rec> recs;        // deferred records awaiting thz_timing_collect
     std::vector<hipEvent_t> pool;  // recycled events
 };
+
+// The Deconvolution stage in phases, for a group of GPUs (deconv_api.cpp; C++ linkage, not exported): energies and
+// recombination run over a slab of pixels with every band, the iterations over the whole grid with a range of bands.
+// nx, ny, dx, dy always describe the WHOLE (current) grid.  thz_dc_slab_energies returns THZ_SKIPPED when one of the
+// reference's guards holds (the same on every rank): the stage then passes its input through.
+int thz_dc_slab_energies(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                         const float *d_in, size_t npix_local, float *d_energy /* [n_filters][npix_local] */);
+int thz_dc_band_gains(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg /* band_begin, band_end */, size_t nx, size_t ny,
+                      float dx, float dy, float *d_energy /* [bands][nx ny] */, float *d_gain /* [bands][nx ny] */,
+                      volatile const int *abort_flag, float *progress);
+int thz_dc_slab_combine(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                        size_t npix_local, float *d_gain /* [n_filters][npix_local] */, float *d_out, float *d_img);
+// host only: per band {iterations, iterations x tiles} (2 n_filters values), the same on every rank; THZ_SKIPPED under a guard
+int thz_dc_band_costs(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                      std::vector<double> *costs);
 
 namespace thz_api {
 

@@ -20,13 +20,19 @@ namespace {
 // whatever the next call enqueues.
 struct DevFree {
     thz_ctx *ctx;
-    explicit DevFree(thz_ctx *c) : ctx(c)
+    bool sweep;  // false: a phase that allocates (almost) nothing must not free what the other phases park in the pool
+    explicit DevFree(thz_ctx *c, bool sweep_ = true) : ctx(c), sweep(sweep_)
     {
-        for (auto &b : ctx->dc_pool) b.used_this_call = false;
+        if (sweep)
+            for (auto &b : ctx->dc_pool) b.used_this_call = false;
     }
     ~DevFree()
     {
         auto &pool = ctx->dc_pool;
+        if (!sweep) {
+            for (auto &b : pool) b.in_use = false;
+            return;
+        }
         for (size_t i = 0; i < pool.size();) {
             pool[i].in_use = false;
             if (!pool[i].used_this_call) {  // left over from another geometry
@@ -125,14 +131,38 @@ int thz_host_band_psf(const thz_psf *psf, float center_freq, float dx, float dy,
     return THZ_OK;
 }
 
-int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
-                   float dx, float dy, const float *d_in, float *d_out, float *d_img,
-                   float *d_gains_out, volatile const int *abort_flag, float *progress)
+}  // extern "C"
+
+namespace {
+
+// The stage in ONE call (sp == nullptr: thz_deconvolve) or one of its three PHASES (ctx.hpp: thz_dc_*), which is
+// how a group of GPUs runs it: the transform, the band energies and the recombination are per pixel, the iterations
+// are per band over the whole image (SURVEY 8e's alternative; round 3).
+//   phase 1  spectra + band energies of a slab's pixels, every band   -> sp->d_energy [n_filters][npix_local]
+//   phase 2  Richardson-Lucy of the bands [band_begin, band_end) on their energy images over the whole grid
+//            (sp->d_energy [bands][nx ny]) -> gains sp->d_gain [bands][nx ny]
+//   phase 3  recombination of the slab's traces from every band's gains (sp->d_gain [n_filters][npix_local]) and the
+//            spectra phase 1 left in the context -> d_out, d_img
+// In the phases nothing is passed through: a guard makes phase 1 return THZ_SKIPPED, an abort makes phase 2 return
+// THZ_ERR_ABORTED, and the caller hands every slab its own input.
+struct DcSplit {
+    int phase = 0;                 // 4: only the bands' costs (iterations x tiles), for dealing the bands out
+    size_t npix_local = 0;
+    float *d_energy = nullptr;
+    float *d_gain = nullptr;
+    std::vector<double> *costs = nullptr;
+};
+
+int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
+                    float dx, float dy, const float *d_in, float *d_out, float *d_img,
+                    float *d_gains_out, volatile const int *abort_flag, float *progress, const DcSplit *sp)
 {
     if (int rc = need_plan(ctx)) return rc;
-    if (!psf || !cfg || !d_in || !d_out || nx == 0 || ny == 0)
+    const int phase = sp ? sp->phase : 0;
+    if (!psf || !cfg || nx == 0 || ny == 0 || ((phase == 0 || phase == 1) && !d_in) || ((phase == 0 || phase == 3) && !d_out))
         return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad argument");
     const size_t nt = ctx->time.size(), npix = nx * ny;
+    const size_t npix_t = phase == 1 || phase == 3 ? sp->npix_local : npix;  // pixels the transforms of this call run over
     const int nb = (int)cfg->n_filters;
     if (progress) *progress = 0.0f;
     // developer knob: wall time of the call's phases on stderr (each tick drains the stream)
@@ -181,7 +211,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     // abort — so the input is copied through by the one rank that owns band 0 and every other rank contributes
     // zeros; a rank whose range is empty (more ranks than bands) contributes zeros as well.
     int b0 = (int)cfg->band_begin, b1 = (int)cfg->band_end;
-    if (b0 == 0 && b1 == 0) b1 = nb;
+    if ((b0 == 0 && b1 == 0) || phase == 1 || phase == 3 || phase == 4) { b0 = 0; b1 = nb; }
     if (b0 < 0 || b0 > b1 || (!skip && b1 > nb))
         return fail(ctx, THZ_ERR_INVALID, "thz_deconvolve: bad band range");
     const bool owns_first = b0 == 0;
@@ -194,9 +224,14 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         return THZ_OK;
     };
     if (skip) {
-        if (int rc = pass_through()) return rc;
+        if (phase == 0)
+            if (int rc = pass_through()) return rc;
         if (progress) *progress = 1.0f;
         return THZ_SKIPPED;
+    }
+    if (b0 == b1 && phase == 2) {  // a rank without a band of its own
+        if (progress) *progress = 1.0f;
+        return THZ_OK;
     }
     if (b0 == b1) {  // nothing to add from this rank
         HIP_TRY(ctx, hipMemsetAsync(d_out, 0, npix * nt * sizeof(float), ctx->stream));
@@ -212,7 +247,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     while (M < nt + kDeconvTaps - 1) M <<= 1;
     // the tables of the padded length live in the context until M changes
     thz_ctx::DcPlan &PL = ctx->dc_plan;
-    if (PL.M != M) {
+    if (PL.M != M && phase != 2 && phase != 4) {
         if (PL.d_tw) (void)hipFree(PL.d_tw);
         PL = thz_ctx::DcPlan{};
         if (M > 16384 || !build_plan(M, PL.H, true))  // with the F core's tables where M has them (band energies)
@@ -237,21 +272,25 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     }
     const PlanHost &H = PL.H;
     const size_t N = M / 2, nk = N + 1;
-    DevFree mem(ctx);
+    DevFree mem(ctx, phase == 0 || phase == 2);
+    const bool transforms = phase != 2 && phase != 4;
     c32 *d_tw = PL.d_tw, *d_spec = nullptr, *d_H = nullptr;
     float *d_energy = nullptr, *d_gain = nullptr, *d_ws = nullptr;
     RlBand *d_bands = nullptr;
     // the transform kernels of this call are the generic (LDS) ones; only the F core's tables ride along
-    PlanDev P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
-    P.f_t1 = PL.f ? d_tw + PL.o1 : nullptr;
-    P.f_t2 = PL.f ? d_tw + PL.o2 : nullptr;
-    P.f_w2n = PL.f ? d_tw + PL.o3 : nullptr;
+    PlanDev P{};
+    if (transforms) {  // (the iterations alone transform nothing)
+        P = plan_dev(H, d_tw, d_tw + H.tw.size(), nullptr, nullptr);
+        P.f_t1 = PL.f ? d_tw + PL.o1 : nullptr;
+        P.f_t2 = PL.f ? d_tw + PL.o2 : nullptr;
+        P.f_w2n = PL.f ? d_tw + PL.o3 : nullptr;
+    }
     tick("plan, twiddles");
     // ---- filter spectra H_b[k] = (1/M) sum_j h_b[j] exp(-2 pi i j k / M), in double, for the bands of
     // this call (band-parallel multi-GPU: cfg->band_begin/band_end select a subset of the bank)
     const int nbs = b1 - b0;
     thz_ctx::DcSpectra &SP = ctx->dc_spectra;
-    if (!SP.d_H || SP.M != M || SP.bank_gen != ctx->dc_bank.gen || SP.b0 != b0 || SP.b1 != b1) {
+    if (transforms && (!SP.d_H || SP.M != M || SP.bank_gen != ctx->dc_bank.gen || SP.b0 != b0 || SP.b1 != b1)) {
         if (SP.d_H) (void)hipFree(SP.d_H);
         SP = thz_ctx::DcSpectra{};
         std::vector<double> trig(2 * M);  // cos | sin of -2 pi m / M
@@ -276,6 +315,39 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     d_H = SP.d_H;
     centers = std::vector<float>(centers.begin() + b0, centers.begin() + b1);
     tick("filter spectra");
+    const int shift = (kDeconvTaps - 1) / 2;
+    if (phase == 1) {
+        // ---- a slab's spectra (kept in the context for phase 3) and its band energies, every band
+        thz_ctx::DcSlab &S = ctx->dc_slab;
+        if (S.cap < npix_t * nk) {
+            if (S.d_spec) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(S.d_spec);
+            }
+            S = thz_ctx::DcSlab{};
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&S.d_spec), npix_t * nk * sizeof(c32)));
+            S.cap = npix_t * nk;
+        }
+        S.npix = npix_t; S.nk = nk; S.M = M;
+        launch_dc_fft(ctx->stream, P, npix_t, (int)nt, d_in, S.d_spec);
+        launch_dc_energy(ctx->stream, P, npix_t, (int)nt, nbs, shift, S.d_spec, d_H, sp->d_energy);
+        if (int rc = check_launch(ctx)) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        tick("slab: transform, band energies");
+        return THZ_OK;
+    }
+    if (phase == 3) {
+        // ---- a slab's traces from every band's gains and the spectra phase 1 kept
+        const thz_ctx::DcSlab &S = ctx->dc_slab;
+        if (!S.d_spec || S.npix != npix_t || S.nk != nk || S.M != M)
+            return fail(ctx, THZ_ERR_NOT_READY, "thz_dc_slab_combine: no spectra of this slab (thz_dc_slab_energies comes first)");
+        launch_dc_combine(ctx->stream, P, npix_t, (int)nt, nbs, shift, S.d_spec, d_H, sp->d_gain, d_out, d_img);
+        if (int rc = check_launch(ctx)) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        tick("slab: recombination");
+        if (progress) *progress = 1.0f;
+        return THZ_OK;
+    }
     // ---- per-band PSFs, iteration counts, workspace layout
     std::vector<RlBand> bands((size_t)nbs);
     std::vector<float> psf_pack;
@@ -311,6 +383,15 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
         B.off_d = (unsigned)ws_floats; ws_floats += img;
         B.off_u = (unsigned)ws_floats; ws_floats += img;
         B.off_t = (unsigned)ws_floats; ws_floats += img;
+    }
+    if (phase == 4) {  // what the bands' iterations cost is a function of these: iterations | iterations x tiles, per band
+        sp->costs->assign(2 * (size_t)nbs, 0.0);
+        for (int b = 0; b < nbs; ++b) {
+            const RlBand &B = bands[(size_t)b];
+            (*sp->costs)[2 * (size_t)b] = (double)B.n_iter;
+            (*sp->costs)[2 * (size_t)b + 1] = (double)B.n_iter * (double)rl_tile_block_count(B.pr, B.pc, (unsigned)B.n_tiles);
+        }
+        return THZ_OK;
     }
     // The bands never exchange anything, so the tiled iteration runs as independent CHAINS of launches, one stream
     // each: the wide-kernel bands (more than 256 taps) and the narrow-kernel ones (one dependent sum per pixel: a
@@ -407,15 +488,21 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     HIP_TRY(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RlTileRef), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, mem.alloc(&d_bands, bands.size() * sizeof(RlBand)));
     HIP_TRY(ctx, hipMemcpyAsync(d_bands, bands.data(), bands.size() * sizeof(RlBand), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, mem.alloc(&d_spec, npix * nk * sizeof(c32)));
-    HIP_TRY(ctx, mem.alloc(&d_energy, (size_t)nbs * npix * sizeof(float)));
-    HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nbs * npix * sizeof(float)));
+    if (phase == 2) {  // the energy images come from the group, the gains go back to it
+        d_energy = sp->d_energy;
+        d_gain = sp->d_gain;
+    } else {
+        HIP_TRY(ctx, mem.alloc(&d_spec, npix * nk * sizeof(c32)));
+        HIP_TRY(ctx, mem.alloc(&d_energy, (size_t)nbs * npix * sizeof(float)));
+        HIP_TRY(ctx, mem.alloc(&d_gain, (size_t)nbs * npix * sizeof(float)));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope below
 
     tick("band PSFs, workspace");
-    const int shift = (kDeconvTaps - 1) / 2;
-    launch_dc_fft(ctx->stream, P, npix, (int)nt, d_in, d_spec);
-    launch_dc_energy(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_energy);
+    if (phase == 0) {
+        launch_dc_fft(ctx->stream, P, npix, (int)nt, d_in, d_spec);
+        launch_dc_energy(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_energy);
+    }
     launch_rl_init(ctx->stream, d_bands, nbs, blk, npix, d_energy, d_ws);
     if (int rc = check_launch(ctx)) return rc;
     tick("transform, band energies");
@@ -510,7 +597,8 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     }
     auto aborted = [&]() -> int {
         HIP_TRY(ctx, sync_chains());
-        if (int rc = pass_through()) return rc;
+        if (phase == 0)
+            if (int rc = pass_through()) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return fail(ctx, THZ_ERR_ABORTED, "thz_deconvolve: aborted");
     };
@@ -607,7 +695,7 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     }
     tick("iterations");
     launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);
-    launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
+    if (phase == 0) launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
     if (int rc = check_launch(ctx)) return rc;
     if (d_gains_out)
         HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nbs * npix * sizeof(float),
@@ -616,6 +704,54 @@ int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, 
     tick("gains, recombination");
     if (progress) *progress = 1.0f;
     return THZ_OK;
+}
+
+}  // namespace
+
+int thz_dc_slab_energies(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                         const float *d_in, size_t npix_local, float *d_energy)
+{
+    if (!ctx || !d_energy || npix_local == 0) return THZ_ERR_INVALID;
+    DcSplit sp;
+    sp.phase = 1; sp.npix_local = npix_local; sp.d_energy = d_energy;
+    return deconvolve_impl(ctx, psf, cfg, nx, ny, dx, dy, d_in, nullptr, nullptr, nullptr, nullptr, nullptr, &sp);
+}
+
+int thz_dc_band_gains(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                      float *d_energy, float *d_gain, volatile const int *abort_flag, float *progress)
+{
+    if (!ctx || !cfg) return THZ_ERR_INVALID;
+    if (cfg->band_end > cfg->band_begin && (!d_energy || !d_gain)) return THZ_ERR_INVALID;
+    DcSplit sp;
+    sp.phase = 2; sp.d_energy = d_energy; sp.d_gain = d_gain;
+    return deconvolve_impl(ctx, psf, cfg, nx, ny, dx, dy, nullptr, nullptr, nullptr, nullptr, abort_flag, progress, &sp);
+}
+
+int thz_dc_slab_combine(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                        size_t npix_local, float *d_gain, float *d_out, float *d_img)
+{
+    if (!ctx || !d_gain || npix_local == 0) return THZ_ERR_INVALID;
+    DcSplit sp;
+    sp.phase = 3; sp.npix_local = npix_local; sp.d_gain = d_gain;
+    return deconvolve_impl(ctx, psf, cfg, nx, ny, dx, dy, nullptr, d_out, d_img, nullptr, nullptr, nullptr, &sp);
+}
+
+int thz_dc_band_costs(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny, float dx, float dy,
+                      std::vector<double> *costs)
+{
+    if (!ctx || !costs) return THZ_ERR_INVALID;
+    DcSplit sp;
+    sp.phase = 4; sp.costs = costs;
+    return deconvolve_impl(ctx, psf, cfg, nx, ny, dx, dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp);
+}
+
+extern "C" {
+
+int thz_deconvolve(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
+                   float dx, float dy, const float *d_in, float *d_out, float *d_img,
+                   float *d_gains_out, volatile const int *abort_flag, float *progress)
+{
+    return deconvolve_impl(ctx, psf, cfg, nx, ny, dx, dy, d_in, d_out, d_img, d_gains_out, abort_flag, progress, nullptr);
 }
 
 }  // extern "C"

@@ -10,9 +10,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -762,32 +764,85 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
         if (int rc2 = thz_group_sync(g)) return rc2;
         return rc;
     }
-    // the outputs' grid (rows per rank in gs->cur_rows) and where each rank's rows start in it
+    // ---- several slabs (round 3).  The stage has three parts with two different independences: the transform, the band
+    // energies and the recombination are per PIXEL (every band), the Richardson-Lucy iterations are per BAND (the
+    // whole image).  So every member does the per-pixel parts for its own rows and the iterations for its own bands,
+    // and what crosses the fabric is two sets of 2-D images — n_filters x Nx x Ny energies out, as many gains back —
+    // instead of round 2's all-gather and all-reduce of the whole cube (2 x Nx Ny Nt floats per member, and two
+    // whole-cube buffers on every GPU): SURVEY 8e's alternative.
+    //   A  thz_dc_slab_energies      own rows, every band                      -> E_slab [nb][npix_slab]
+    //   X1 all-gather of the E_slab blocks; a member keeps its bands' images    -> E_mine [bands][npix]
+    //   B  thz_dc_band_gains          own bands (dealt out by cost), whole grid -> G_mine [bands][npix]
+    //   X2 all-gather of the G_mine blocks (rank order = band order); a member keeps its rows' columns -> G_slab
+    //   C  thz_dc_slab_combine        own rows, every band                      -> the slab of the stage's output
+    // A guard (the same on every rank) or an abort / error on any rank makes every slab keep its input.
     std::vector<size_t> cur_x0((size_t)g->world, 0);
     for (int q = 1; q < g->world; ++q) cur_x0[(size_t)q] = cur_x0[(size_t)q - 1] + gs->cur_rows[(size_t)q - 1];
-    const size_t grid_nx = gs->cur_pix() / (gs->cur_ny ? gs->cur_ny : 1), grid_ny = gs->cur_ny;
-    const size_t nt = gs->nt_out, cube = grid_nx * grid_ny * nt;
-    if (cfg->n_filters == 0 || cfg->n_iterations == 0) {
-        // rank-independent guards, checked before the bands are dealt out (an empty band range would read as "all bands"
-        // on every rank and the all-reduce below would return world x input): the stage passes its input through
-        for (thz_session *s : gs->sess) s->deconv_current = false;
-        return THZ_SKIPPED;
+    const size_t grid_ny = gs->cur_ny, npix_all = gs->cur_pix(), grid_nx = npix_all / (grid_ny ? grid_ny : 1);
+    const size_t nt = gs->nt_out;
+    const size_t nb = cfg->n_filters;
+    for (size_t i = 0; i < nl; ++i) {  // the members' engines on the chain's current axis
+        thz_ctx *ctx = g->m[i].ctx;
+        thz_session *s = gs->sess[i];
+        GHIP_TRY(g, hipSetDevice(ctx->device));
+        if (ctx->time.size() != nt || std::memcmp(ctx->time.data(), s->time_out.data(), nt * sizeof(float)) != 0)
+            if (int rc = thz_set_time_axis(ctx, s->time_out.data(), nt)) return gfail(g, rc, thz_last_error(ctx));
     }
-    // Richardson-Lucy is spatially global per band: every member needs the whole "Time Band Pass" output
-    std::vector<float *> full(nl, nullptr), out(nl, nullptr), flag(nl, nullptr);
-    std::vector<const float *> send(nl);
-    std::vector<size_t> counts((size_t)g->world);
-    for (int q = 0; q < g->world; ++q) counts[(size_t)q] = gs->cur_rows[(size_t)q] * grid_ny * nt;
+    // The bands' iteration counts and tile counts (host arithmetic, identical on every rank) -> contiguous band ranges.
+    // A range's iterations run as chains of dependent launches: its time is about alpha x (its longest band's
+    // iterations) + beta x (sum of iterations x tiles) — alpha = 13.2 us per iteration (two launches end to end),
+    // beta = 20 ns per tile and iteration, fitted to the widest band alone at 128 x 128 and 512 x 512 pixels
+    // (profiles/r03_deconv_group_estimate.txt).  The ranges minimise the slowest rank's time (dynamic programme over
+    // the cut points; a rank may stay without a band when there are more ranks than bands).
+    std::vector<double> costs;
+    int status = THZ_OK;
+    bool skipped = false;
+    {
+        // (the reference's guards — no bands, a grid smaller than the widest PSF ... — are rank-independent too)
+        const int rc = thz_dc_band_costs(g->m[0].ctx, psf, cfg, grid_nx, grid_ny, gs->sess[0]->dx_cur, gs->sess[0]->dy_cur, &costs);
+        if (rc < 0) return gfail(g, rc, std::string("thz_group_session_deconvolve: ") + thz_last_error(g->m[0].ctx));
+        skipped = rc == THZ_SKIPPED || costs.size() != 2 * nb;
+    }
+    std::vector<size_t> band0((size_t)g->world + 1, 0);
+    if (!skipped) {
+        const size_t W = (size_t)g->world;
+        const double alpha = 13.2, beta = 0.0204;
+        auto range_cost = [&](size_t a, size_t b) {  // bands [a, b)
+            double it = 0.0, w = 0.0;
+            for (size_t k = a; k < b; ++k) {
+                it = std::max(it, costs[2 * k]);
+                w += costs[2 * k + 1];
+            }
+            return alpha * it + beta * w;
+        };
+        // best[q][b]: the smallest possible slowest-rank time when ranks 0 .. q-1 share the bands [0, b)
+        std::vector<std::vector<double>> best(W + 1, std::vector<double>(nb + 1, 1e300));
+        std::vector<std::vector<size_t>> cut(W + 1, std::vector<size_t>(nb + 1, 0));
+        best[0][0] = 0.0;
+        for (size_t q = 1; q <= W; ++q)
+            for (size_t b = 0; b <= nb; ++b)
+                for (size_t a = 0; a <= b; ++a) {
+                    if (best[q - 1][a] >= 1e300) continue;
+                    const double v = std::max(best[q - 1][a], range_cost(a, b));
+                    if (v < best[q][b]) { best[q][b] = v; cut[q][b] = a; }
+                }
+        size_t b = nb;
+        for (size_t q = W; q >= 1; --q) {
+            band0[q] = b;
+            b = cut[q][b];
+        }
+        band0[0] = 0;
+    }
+    std::vector<float *> bufA(nl, nullptr), bufB(nl, nullptr), bufC(nl, nullptr), bufD(nl, nullptr), flag(nl, nullptr);
     auto cleanup = [&]() {
         for (size_t i = 0; i < nl; ++i) {
             (void)hipSetDevice(g->m[i].ctx->device);
             (void)hipStreamSynchronize(g->m[i].ctx->stream);
-            if (full[i]) (void)hipFree(full[i]);
-            if (out[i]) (void)hipFree(out[i]);
-            if (flag[i]) (void)hipFree(flag[i]);
+            for (float *p : {bufA[i], bufB[i], bufC[i], bufD[i], flag[i]})
+                if (p) (void)hipFree(p);
         }
     };
-    // a HIP error past this point frees the whole-cube buffers before it returns
+    // a HIP error past this point frees the exchange buffers before it returns
 #define GHIP_TRY_C(g, expr)                                                                          \
     do {                                                                                             \
         hipError_t e_ = (expr);                                                                      \
@@ -796,46 +851,36 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
             return gfail(g, THZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
         }                                                                                            \
     } while (0)
+    auto rank_pix = [&](size_t q) { return gs->cur_rows[q] * grid_ny; };
+    // every member's slab output buffers (the stage's result replaces the final cube / image until the next recompute)
     for (size_t i = 0; i < nl; ++i) {
+        thz_session *s = gs->sess[i];
         GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
-        if (hipMalloc((void **)&full[i], cube * sizeof(float)) != hipSuccess || hipMalloc((void **)&out[i], cube * sizeof(float)) != hipSuccess
-            || hipMalloc((void **)&flag[i], sizeof(float)) != hipSuccess) {
-            cleanup();
-            return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: allocation of the whole cube failed");
+        const size_t q = (size_t)g->m[i].rank, n = rank_pix(q) * nt;
+        if (s->deconv_floats != n) {
+            if (s->d_deconv) { (void)hipFree(s->d_deconv); s->d_deconv = nullptr; }
+            if (s->d_deconv_img) { (void)hipFree(s->d_deconv_img); s->d_deconv_img = nullptr; }
+            s->deconv_floats = 0;
+            if (hipMalloc((void **)&s->d_deconv, n * sizeof(float)) != hipSuccess
+                || hipMalloc((void **)&s->d_deconv_img, rank_pix(q) * sizeof(float)) != hipSuccess) {
+                cleanup();
+                return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: slab allocation failed");
+            }
+            s->deconv_floats = n;
         }
-        send[i] = gs->sess[i]->d_data;   // the stage's input is always the Time Band Pass output
+        if (hipMalloc((void **)&flag[i], sizeof(float)) != hipSuccess) { cleanup(); return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: allocation failed"); }
     }
-    if (int rc = group_all_gather(g, send.data(), counts.data(), full.data())) { cleanup(); return rc; }
-    if (int rc = thz_group_sync(g)) { cleanup(); return rc; }
-    // bands [b0, b1) of rank r: the slab rule applied to the bank; the members of this process run side by side
-    std::vector<int> rcs(nl, THZ_OK);
-    {
+    // runs fn(member) for every local member side by side (the calls wait for their streams)
+    auto for_members = [&](const std::function<int(size_t)> &fn, std::vector<int> &rcs) {
+        rcs.assign(nl, THZ_OK);
+        if (nl == 1) { rcs[0] = fn(0); return; }
         std::vector<std::thread> th;
-        for (size_t i = 0; i < nl; ++i)
-            th.emplace_back([&, i]() {
-                thz_deconv_cfg c = *cfg;
-                size_t b0 = 0, nb = 0;
-                (void)thz_host_slab(cfg->n_filters, g->world, g->m[i].rank, &b0, &nb);
-                c.band_begin = (uint32_t)b0;
-                c.band_end = (uint32_t)(b0 + nb);
-                if (g->world == 1) c.band_begin = c.band_end = 0;
-                thz_ctx *ctx = g->m[i].ctx;
-                thz_session *s = gs->sess[i];
-                if (ctx->time.size() != nt || std::memcmp(ctx->time.data(), s->time_out.data(), nt * sizeof(float)) != 0)
-                    if (int rc = thz_set_time_axis(ctx, s->time_out.data(), nt)) { rcs[i] = rc; return; }
-                rcs[i] = thz_deconvolve(ctx, psf, &c, grid_nx, grid_ny, s->dx_cur, s->dy_cur, full[i], out[i], nullptr, nullptr, abort_flag,
-                                        i == 0 ? progress : nullptr);
-            });
+        for (size_t i = 0; i < nl; ++i) th.emplace_back([&, i]() { rcs[i] = fn(i); });
         for (auto &t : th) t.join();
-    }
-    // agree on the outcome: an abort or an error seen by any rank makes every rank pass the input through
-    // (thz_deconvolve's own pass-through already adds up when ALL ranks took it: guards are rank-independent)
-    bool all_skipped = true;
-    for (size_t i = 0; i < nl; ++i)
-        if (rcs[i] != THZ_SKIPPED) all_skipped = false;
-    bool any_bad = false;
-    {
-        for (size_t i = 0; i < nl; ++i) {   // one float per member: 1 where the call failed or was aborted; summed over the group
+    };
+    // one float per member, summed over the group: did anybody fail?
+    auto any_bad = [&](const std::vector<int> &rcs, bool *bad) -> int {
+        for (size_t i = 0; i < nl; ++i) {
             GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
             const float v = rcs[i] < 0 ? 1.0f : 0.0f;
             GHIP_TRY_C(g, hipMemcpyAsync(flag[i], &v, sizeof v, hipMemcpyHostToDevice, g->m[i].ctx->stream));
@@ -846,53 +891,132 @@ int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, cons
         GHIP_TRY_C(g, hipSetDevice(g->m[0].ctx->device));
         GHIP_TRY_C(g, hipMemcpyAsync(&v, flag[0], sizeof v, hipMemcpyDeviceToHost, g->m[0].ctx->stream));
         GHIP_TRY_C(g, hipStreamSynchronize(g->m[0].ctx->stream));
-        any_bad = v != 0.0f;
-    }
-    int status = all_skipped ? THZ_SKIPPED : THZ_OK;
-    if (any_bad) {
+        *bad = v != 0.0f;
+        return THZ_OK;
+    };
+    std::vector<int> rcs;
+    bool bad = false;
+    if (!skipped) {
         for (size_t i = 0; i < nl; ++i) {
             GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
-            if (g->m[i].rank == 0) GHIP_TRY_C(g, hipMemcpyAsync(out[i], full[i], cube * sizeof(float), hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
-            else GHIP_TRY_C(g, hipMemsetAsync(out[i], 0, cube * sizeof(float), g->m[i].ctx->stream));
-        }
-        status = THZ_ERR_ABORTED;
-        for (size_t i = 0; i < nl; ++i)
-            if (rcs[i] < 0 && rcs[i] != THZ_ERR_ABORTED) status = rcs[i];
-    }
-    // C2 of the band sums: every member ends with the whole deconvolved cube, keeps its own rows
-    if (int rc = thz_group_all_reduce_sum(g, out.data(), cube)) { cleanup(); return rc; }
-    for (size_t i = 0; i < nl; ++i) {
-        thz_session *s = gs->sess[i];
-        thz_ctx *ctx = g->m[i].ctx;
-        GHIP_TRY_C(g, hipSetDevice(ctx->device));
-        const size_t q = (size_t)g->m[i].rank, n = counts[q], npix = gs->cur_rows[q] * grid_ny;
-        if (s->deconv_floats != n) {
-            if (s->d_deconv) { (void)hipFree(s->d_deconv); s->d_deconv = nullptr; }
-            if (s->d_deconv_img) { (void)hipFree(s->d_deconv_img); s->d_deconv_img = nullptr; }
-            s->deconv_floats = 0;
-            if (hipMalloc((void **)&s->d_deconv, n * sizeof(float)) != hipSuccess
-                || hipMalloc((void **)&s->d_deconv_img, npix * sizeof(float)) != hipSuccess) {
+            const size_t q = (size_t)g->m[i].rank, nbs = band0[q + 1] - band0[q];
+            if (hipMalloc((void **)&bufA[i], std::max<size_t>(nb * rank_pix(q), 4) * sizeof(float)) != hipSuccess
+                || hipMalloc((void **)&bufB[i], std::max<size_t>(nb * npix_all, 4) * sizeof(float)) != hipSuccess
+                || hipMalloc((void **)&bufC[i], std::max<size_t>(nbs * npix_all, 4) * sizeof(float)) != hipSuccess
+                || hipMalloc((void **)&bufD[i], std::max<size_t>(nbs * npix_all, 4) * sizeof(float)) != hipSuccess) {
                 cleanup();
-                return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: slab allocation failed");
+                return gfail(g, THZ_ERR_HIP, "thz_group_session_deconvolve: allocation of the band images failed");
             }
-            s->deconv_floats = n;
         }
-        GHIP_TRY_C(g, hipMemcpyAsync(s->d_deconv, out[i] + cur_x0[q] * grid_ny * nt, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-        if (int rc = thz_intensity(ctx, npix, s->d_deconv, s->d_deconv_img)) { cleanup(); return gfail(g, rc, thz_last_error(ctx)); }
-        s->deconv_current = status >= 0;
+        // ---- A: own rows, every band
+        for_members([&](size_t i) {
+            thz_session *s = gs->sess[i];
+            (void)hipSetDevice(g->m[i].ctx->device);
+            return thz_dc_slab_energies(g->m[i].ctx, psf, cfg, grid_nx, grid_ny, s->dx_cur, s->dy_cur, s->d_data, rank_pix((size_t)g->m[i].rank), bufA[i]);
+        }, rcs);
+        if (int rc = any_bad(rcs, &bad)) return rc;
     }
+    if (!skipped && !bad) {
+        // ---- X1: every slab's [nb][npix_slab] block to everybody; a member re-tiles its bands' rows into whole images
+        std::vector<const float *> send(nl);
+        std::vector<size_t> counts((size_t)g->world), off((size_t)g->world + 1, 0);
+        for (int q = 0; q < g->world; ++q) {
+            counts[(size_t)q] = nb * rank_pix((size_t)q);
+            off[(size_t)q + 1] = off[(size_t)q] + counts[(size_t)q];
+        }
+        for (size_t i = 0; i < nl; ++i) send[i] = bufA[i];
+        if (int rc = group_all_gather(g, send.data(), counts.data(), bufB.data())) { cleanup(); return rc; }
+        for (size_t i = 0; i < nl; ++i) {
+            GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
+            const size_t me = (size_t)g->m[i].rank, b_lo = band0[me], nbs = band0[me + 1] - b_lo;
+            for (int q = 0; q < g->world && nbs; ++q) {
+                const size_t pq = rank_pix((size_t)q);
+                if (pq)
+                    GHIP_TRY_C(g, hipMemcpy2DAsync(bufC[i] + cur_x0[(size_t)q] * grid_ny, npix_all * sizeof(float), bufB[i] + off[(size_t)q] + b_lo * pq,
+                                                   pq * sizeof(float), pq * sizeof(float), nbs, hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
+            }
+        }
+        if (int rc = thz_group_sync(g)) { cleanup(); return rc; }
+        // ---- B: own bands, whole grid
+        for_members([&](size_t i) {
+            thz_session *s = gs->sess[i];
+            (void)hipSetDevice(g->m[i].ctx->device);
+            const size_t me = (size_t)g->m[i].rank;
+            thz_deconv_cfg c = *cfg;
+            c.band_begin = (uint32_t)band0[me];
+            c.band_end = (uint32_t)band0[me + 1];
+            if (c.band_begin == c.band_end) return (int)THZ_OK;  // more ranks than bands
+            return thz_dc_band_gains(g->m[i].ctx, psf, &c, grid_nx, grid_ny, s->dx_cur, s->dy_cur, bufC[i], bufD[i], abort_flag, i == 0 ? progress : nullptr);
+        }, rcs);
+        if (int rc = any_bad(rcs, &bad)) return rc;
+        if (bad) {
+            status = THZ_ERR_ABORTED;
+            for (int rc : rcs)
+                if (rc < 0 && rc != THZ_ERR_ABORTED) status = rc;
+        }
+    } else if (!skipped) {
+        status = THZ_ERR_HIP;
+        for (int rc : rcs)
+            if (rc < 0) status = rc;
+    }
+    if (!skipped && !bad) {
+        // ---- X2: the ranks' [bands][npix] gain blocks, in rank order = band order -> [nb][npix] on everybody; a member
+        // keeps the columns of its own rows
+        std::vector<const float *> send(nl);
+        std::vector<size_t> counts((size_t)g->world);
+        for (int q = 0; q < g->world; ++q) counts[(size_t)q] = (band0[(size_t)q + 1] - band0[(size_t)q]) * npix_all;
+        for (size_t i = 0; i < nl; ++i) send[i] = bufD[i];
+        if (int rc = group_all_gather(g, send.data(), counts.data(), bufB.data())) { cleanup(); return rc; }
+        for (size_t i = 0; i < nl; ++i) {
+            GHIP_TRY_C(g, hipSetDevice(g->m[i].ctx->device));
+            const size_t me = (size_t)g->m[i].rank, pq = rank_pix(me);
+            if (pq)
+                GHIP_TRY_C(g, hipMemcpy2DAsync(bufA[i], pq * sizeof(float), bufB[i] + cur_x0[me] * grid_ny, npix_all * sizeof(float), pq * sizeof(float), nb,
+                                               hipMemcpyDeviceToDevice, g->m[i].ctx->stream));
+        }
+        if (int rc = thz_group_sync(g)) { cleanup(); return rc; }
+        // ---- C: own rows, every band
+        for_members([&](size_t i) {
+            thz_session *s = gs->sess[i];
+            (void)hipSetDevice(g->m[i].ctx->device);
+            return thz_dc_slab_combine(g->m[i].ctx, psf, cfg, grid_nx, grid_ny, s->dx_cur, s->dy_cur, rank_pix((size_t)g->m[i].rank), bufA[i], s->d_deconv,
+                                       s->d_deconv_img);
+        }, rcs);
+        if (int rc = any_bad(rcs, &bad)) return rc;
+        if (bad) {
+            status = THZ_ERR_HIP;
+            for (int rc : rcs)
+                if (rc < 0) status = rc;
+        }
+    }
+    if (skipped) status = THZ_SKIPPED;
+    if (skipped || bad) {
+        // the stage passes its input through: every slab keeps its own "Time Band Pass" output
+        for (size_t i = 0; i < nl; ++i) {
+            thz_session *s = gs->sess[i];
+            thz_ctx *ctx = g->m[i].ctx;
+            GHIP_TRY_C(g, hipSetDevice(ctx->device));
+            const size_t pq = rank_pix((size_t)g->m[i].rank);
+            GHIP_TRY_C(g, hipMemcpyAsync(s->d_deconv, s->d_data, pq * nt * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            if (int rc = thz_intensity(ctx, pq, s->d_deconv, s->d_deconv_img)) { cleanup(); return gfail(g, rc, thz_last_error(ctx)); }
+        }
+    }
+    for (thz_session *s : gs->sess) s->deconv_current = status >= 0;
     // C1: the new image (and, if the last recompute gathered it, the new final cube) to rank 0
     {
-        std::vector<const float *> im;
-        std::vector<size_t> ic((size_t)g->world);
-        for (int q = 0; q < g->world; ++q) ic[(size_t)q] = gs->cur_rows[(size_t)q] * grid_ny;
-        for (thz_session *s : gs->sess) im.push_back(s->deconv_current ? s->d_deconv_img : s->d_img);
-        if (int rc = thz_group_gather(g, im.data(), ic.data(), gs->d_img)) { cleanup(); return rc; }
-        if (gs->gathered >= THZ_GATHER_TIME && gs->root_local >= 0) {
-            GHIP_TRY_C(g, hipSetDevice(g->m[(size_t)gs->root_local].ctx->device));
-            GHIP_TRY_C(g, hipMemcpyAsync(gs->d_data, out[(size_t)gs->root_local], cube * sizeof(float), hipMemcpyDeviceToDevice,
-                                       g->m[(size_t)gs->root_local].ctx->stream));
+        std::vector<const float *> im, dat;
+        std::vector<size_t> ic((size_t)g->world), dc((size_t)g->world);
+        for (int q = 0; q < g->world; ++q) {
+            ic[(size_t)q] = rank_pix((size_t)q);
+            dc[(size_t)q] = rank_pix((size_t)q) * nt;
         }
+        for (thz_session *s : gs->sess) {
+            im.push_back(s->deconv_current ? s->d_deconv_img : s->d_img);
+            dat.push_back(s->deconv_current ? s->d_deconv : s->d_data);
+        }
+        if (int rc = thz_group_gather(g, im.data(), ic.data(), gs->d_img)) { cleanup(); return rc; }
+        if (gs->gathered >= THZ_GATHER_TIME && (gs->root_local < 0 || gs->d_data))
+            if (int rc = thz_group_gather(g, dat.data(), dc.data(), gs->d_data)) { cleanup(); return rc; }
     }
     cleanup();
 #undef GHIP_TRY_C
