@@ -30,6 +30,13 @@ int emu_family(int nt)
     return H.family;
 }
 
+int emu_half_n(int nt)
+{
+    PlanHost H;
+    if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
+    return H.half_n;
+}
+
 int emu_fft_fwd(int nt, size_t npix, const float *in, const float *wa, const float *wb,
                 float *data_out, float *fft, float *amp, float *ph, const float *mask)
 {

@@ -182,6 +182,44 @@ def test_mixed_radix_pipeline_vs_oracle(emu, nt, npix_shape, pairs):
 
 
 
+@pytest.mark.parametrize("nt,npix", [(2002, 5), (2400, 3), (3000, 14), (4000, 9), (2002, 1)])
+def test_half_length_pipeline_vs_oracle(emu, nt, npix):
+    """PH kernels (fft_ph.hpp): an even length whose half is a P plan (2 x 1001, 2 x 1200, 2 x 1500, 2 x 2000) runs as
+    a half-length mixed-radix transform + split, one trace per wave, one launch; more traces than a block has waves,
+    and the stand-alone forward / inverse kernels land on the fused launch's values"""
+    emu.emu_allow_f(1)
+    emu.emu_allow_p(1)
+    emu.emu_set_p_pairs(1)
+    assert emu.emu_half_n(nt) == nt // 2
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(npix) + 23, max(nt, 320))[:, :nt].reshape(npix, 1, nt).copy()
+    chain = synth.default_chain(time)
+    nf = nt // 2 + 1
+    fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+    ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+    assert emu.emu_pipeline(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(chain["w_post"]),
+                            _p(fft), _p(amp), _p(ph), _p(out), _p(img)) == 0
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+    assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+    assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / max(np.abs(ref["data"]).max(), 1e-30) < 1e-5
+    assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / max(ref["img"].max(), 1e-30) < 1e-5
+    assert np.all(fft[:, 0, 1] == 0.0) and np.all(fft[:, -1, 1] == 0.0) and not np.signbit(fft[:, [0, -1], 1]).any()
+    st = ob.fft_stage((cube * chain["w_pre"]).astype(np.float32), time, 0, 0.0, 0.0)
+    strong = st["amplitudes"] > 0.05 * st["amplitudes"].max(axis=-1, keepdims=True)
+    d = ph.reshape(ref["phases"].shape).astype(np.float64) - ref["phases"]
+    assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))[strong].max() < 3e-3
+    # the stage entry points: the same spectrum from the forward kernel, the same samples from the inverse kernel
+    fft2 = np.zeros_like(fft); amp2 = np.zeros_like(amp); ph2 = np.zeros_like(ph)
+    assert emu.emu_fft_fwd(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), None, None, _p(fft2), _p(amp2), _p(ph2),
+                           _p(chain["fd_mask"])) == 0
+    assert np.array_equal(fft2, fft) and np.array_equal(amp2, amp) and np.array_equal(ph2, ph)
+    out2 = np.zeros_like(out); img2 = np.zeros_like(img)
+    assert emu.emu_fft_inv(nt, C.c_size_t(npix), _p(fft), _p(chain["w_post"]), _p(out2), _p(img2)) == 0
+    assert np.array_equal(out2, out) and np.array_equal(img2, img)
+
+
 @pytest.mark.parametrize("nt", [1024, 4096])
 def test_f_kernels_full_window_and_data_out(emu, nt):
     """non-edge windows (Hann: every block != 1) take the F kernels' "full" path;

@@ -692,6 +692,46 @@ def test_mixed_radix_fused_pipeline(engine, shape, family):
     assert rel(back, st_o["data"]) < TOL   # C2R(R2C(w x)) / nt = w x
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 2002), (5, 1, 2400), (37, 9, 3000), (33, 5, 4000), (1, 1, 4000), (2, 1, 3000)])
+def test_half_length_fused_pipeline(engine, shape):
+    """even lengths whose half is a P plan — 2002, 2400, 3000, 4000 — run as a half-length mixed-radix transform +
+    split (PH kernels, fft_ph.hpp: one trace per wave, one launch) instead of the chirp-z kernels; same oracle and
+    tolerances as every other length, stage entry points included, and the fused launch inverts exactly the spectrum
+    it stored"""
+    nx, ny, nt = shape
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) + 5, max(nt, 1024))[:, :nt].reshape(nx, ny, nt).copy()
+    engine.set_time_axis(time)
+    assert engine.kernel_variant().startswith("ph-half-length-mixed-radix")
+    got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+    st_g = gpu_fft_stage(engine, cube, pkg.host_fft_window(time, 0, 1.0, 7.0))
+    d_f = engine.to_device(st_g["fft"]); d_o = engine.empty((nx * ny, nt)); d_i = engine.empty((nx * ny,))
+    engine.ifft(nx * ny, d_f, None, d_o, d_i)
+    back = d_o.download((nx, ny, nt), np.float32)
+    # Filter(6 / 7): the stand-alone inverse on the stored (masked) spectrum lands on the fused launch's samples
+    d_f.upload(got["fft"])
+    d_w = engine.to_device(synth.default_chain(time)["w_post"])
+    engine.ifft(nx * ny, d_f, d_w, d_o, d_i)
+    again = d_o.download((nx, ny, nt), np.float32)
+    for b in (d_f, d_o, d_i, d_w):
+        b.free()
+    chain = synth.oracle_chain(time)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"], ref["amplitudes"], scale) < TOL
+    assert rel(got["data"], ref["data"]) < TOL
+    assert rel(got["img"], ref["img"]) < TOL
+    st = ob.fft_stage(cube * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(got["phases"], ref["phases"], st["amplitudes"])
+    st_o = ob.fft_stage(cube, time, 0, 1.0, 7.0)
+    assert np.array_equal(st_g["data"], st_o["data"])
+    assert rel(st_g["fft"], st_o["fft"], np.abs(st_o["fft"]).max()) < TOL
+    assert phase_ok(st_g["phases"], st_o["phases"], st_o["amplitudes"])
+    assert rel(back, st_o["data"]) < TOL   # C2R(R2C(w x)) / nt = w x
+    assert np.array_equal(again, got["data"])
+
+
 @pytest.mark.parametrize("nt", [3, 6, 7, 1001, 2000, 4000])
 def test_chirpz_without_windows_matches_numpy(engine, nt):
     """no multipliers at all: X = rfft(x) and y = irfft(X) = x, against numpy fp64"""

@@ -21,6 +21,7 @@
 #include "fft_f.hpp"
 #include "fft_fb.hpp"
 #include "fft_p.hpp"
+#include "fft_ph.hpp"
 
 #include <cstdlib>
 
@@ -1617,7 +1618,7 @@ __global__ __launch_bounds__(WIDE ? kRlThreads : kRlNarrowThreads, WIDE ? 8 : 1)
 // Pass A reuses the wide kernel's window arithmetic (four pixels side by side per thread, packed FMAs): a
 // quarter wave reads 16 consecutive halo rows at one column group, conflict-free for an odd row stride in 16-byte
 // units.
-constexpr int kRlSepThreads = kRlSepTileCols * kRlSepTileRows;  // the largest block: a thread per pixel of the tile
+static_assert(kRlSepTileCols * kRlSepTileRows == 1024, "the largest block of a separable tile: a thread per pixel");
 constexpr int kRlSepQuads = kRlSepTileCols / kRlPix;              // column groups of four per halo row (pass A)
 // halo rows a wave has in flight while staging: kernels of up to 49 rows in one batch (of at most twelve rows per wave)
 constexpr int rl_sep_rows(int nt) { return (kRlSepTileRows + 48 + nt / 64 - 1) / (nt / 64) < 12 ? (kRlSepTileRows + 48 + nt / 64 - 1) / (nt / 64) : 12; }
@@ -2162,6 +2163,36 @@ static void dispatch_p(hipStream_t st, const PlanDev &P, FBArgs &A)
     }
 }
 
+// PH kernels (fft_ph.hpp): even lengths whose half is a P plan
+template <class PL, int MODE>
+static void launch_ph(hipStream_t st, const PlanDev &P, FBArgs &A)
+{
+    A.nt = P.nt;
+    A.nf = P.nf;
+    const unsigned waves = (unsigned)PHLayout<PL>::waves();
+    size_t g = (A.npix + waves - 1) / waves;
+    if (g > (size_t)kNumCU) g = kNumCU;
+    if (g_grid_cap_override > 0 && g > (size_t)g_grid_cap_override) g = (size_t)g_grid_cap_override;
+    if (g < 1) g = 1;
+    const size_t lds = PHLayout<PL>::lds_bytes((int)waves);
+    PHTables T{reinterpret_cast<const cx *>(P.p_t1), reinterpret_cast<const cx *>(P.p_t2),
+               reinterpret_cast<const cx *>(P.p_t2) + PL::T2_ENTRIES};
+    allow_dynamic_lds(k_ph<PL, MODE>, lds);
+    THZ_LAUNCH((k_ph<PL, MODE>), (unsigned)g, waves * kWave, lds, st, A, T);
+}
+
+template <int MODE>
+static void dispatch_ph(hipStream_t st, const PlanDev &P, FBArgs &A)
+{
+    switch (P.half_n) {
+    case 1001: launch_ph<PPlan1001, MODE>(st, P, A); break;
+    case 1200: launch_ph<PPlan1200, MODE>(st, P, A); break;
+    case 1500: launch_ph<PPlan1500, MODE>(st, P, A); break;
+    case 2000: launch_ph<PPlan2000, MODE>(st, P, A); break;
+    default: launch_ph<PPlan1000, MODE>(st, P, A); break;
+    }
+}
+
 // FBC: S waves per pair (fft_fb.hpp), forward and inverse as separate kernels, for the lengths
 // 1024 < nt < 8192 that are not a power of two
 
@@ -2224,6 +2255,13 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
             launch_td_window(st, npix, P.nt, in, wa, data_out);
             if (wb) launch_td_window(st, npix, P.nt, data_out, wb, data_out);
             launch_fft_fwd(st, P, npix, data_out, nullptr, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+            return;
+        }
+        if (!wb && !data_out && P.half_n) {  // half-length mixed-radix transform + split (fft_ph.hpp)
+            FBArgs A{};
+            A.npix = npix; A.in = in; A.pre_win = wa; A.mask = mask ? mask : P.ones;
+            A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+            dispatch_ph<kFwd>(st, P, A);
             return;
         }
         if (!wb && !data_out) {
@@ -2291,6 +2329,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.mask = P.ones; A.post_win = win;
         A.data_out = out; A.img = img;
         dispatch_fb<kInv>(st, P, A);
+        return;
+    }
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && P.half_n) {
+        FBArgs A{};
+        A.npix = npix; A.fft_in = reinterpret_cast<const cx *>(fft_in); A.mask = P.ones; A.post_win = win;
+        A.data_out = out; A.img = img;
+        dispatch_ph<kInv>(st, P, A);
         return;
     }
     if (P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) {
@@ -2364,6 +2409,14 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         // every other family: the complex multiply is its own pass over the stored spectrum
         launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask, cmask);
         launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
+        return;
+    }
+    if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && P.half_n && fft_out && amp_out && ph_out && data_out) {
+        FBArgs A{};  // one launch: half-length transform, split, epilogue, merge, inverse (fft_ph.hpp)
+        A.npix = npix; A.in = raw; A.pre_win = pre_win; A.mask = mask ? mask : P.ones;
+        A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
+        A.data_out = data_out; A.img = img;
+        dispatch_ph<kPipe>(st, P, A);
         return;
     }
     if ((P.family == kFamilyFB2 || P.family == kFamilyFB4 || P.family == kFamilyFB8) && fft_out && data_out) {

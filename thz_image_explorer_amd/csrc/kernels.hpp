@@ -37,6 +37,10 @@ struct PlanDev {
     // "P" family (mixed-radix three-pass transform of length nt = R1 R2 R3, fft_p.hpp); family == kFamilyP
     const c32 *p_t1;   // [k1][m]    W_nt^(m k1), nt entries
     const c32 *p_t2;   // [k2][j3]   W_(R2 R3)^(j3 k2)
+    // "PH" kernels (fft_ph.hpp): an even length whose half N is a P plan — p_t1 / p_t2 are then those of length N, with
+    // the split twiddles W_2N^k, k <= N / 2, behind p_t2's (even-padded) entries; the family stays the chirp-z one, whose
+    // kernels serve what the PH kernels do not (a complex multiplier, thz_set_kernel_family)
+    int half_n;        // N, or 0
 };
 
 enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4, kFamilyFB8 = 5, kFamilyP = 6 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)

@@ -19,7 +19,8 @@ struct PlanHost {
     std::vector<c32> tw, tw_split, chirp_conj, bfft;
     int family = kFamilyG;
     std::vector<c32> f_t1, f_t2, f_w2n;
-    std::vector<c32> p_t1, p_t2;  // P family
+    std::vector<c32> p_t1, p_t2;  // P family (PH: of the half length, the split twiddles behind p_t2)
+    int half_n = 0;                // PH kernels: nt = 2 half_n
     const char *variant = "";
 };
 
@@ -199,6 +200,34 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
                 P.p_t2[(size_t)k2 * q3 + j3] = c32{(float)std::cos(a), (float)std::sin(a)};
             }
     }
+    // PH kernels (fft_ph.hpp): an even length whose half is a P plan runs as a half-length complex transform + split
+    // (2000 itself stays on its pair-of-traces P kernels, which carry the complex multiplier and the in-launch sums)
+    P.half_n = 0;
+    if (allow_f && allow_p && nt % 2 == 0 && nt != 2000 && P.family != kFamilyP && p_factors(nt / 2, q1, q2, q3)) {
+        const size_t Nh = nt / 2, m1 = (size_t)q2 * q3;
+        P.half_n = (int)Nh;
+        static const char *const kHalf[] = {"ph-half-length-mixed-radix-7x11x13-regs-lds", "ph-half-length-mixed-radix-10x10x10-regs-lds",
+                                            "ph-half-length-mixed-radix-10x10x12-regs-lds", "ph-half-length-mixed-radix-10x10x15-regs-lds",
+                                            "ph-half-length-mixed-radix-10x10x20-regs-lds"};
+        P.variant = kHalf[Nh == 1001 ? 0 : Nh == 1000 ? 1 : Nh == 1200 ? 2 : Nh == 1500 ? 3 : 4];
+        P.p_t1.resize(Nh);
+        for (int k1 = 0; k1 < q1; ++k1)
+            for (size_t m = 0; m < m1; ++m) {
+                const double a = -2.0 * pi * (double)((m * (size_t)k1) % Nh) / (double)Nh;
+                P.p_t1[(size_t)k1 * m1 + m] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+        const size_t t2e = m1 + (m1 & 1);
+        P.p_t2.assign(t2e + Nh / 2 + 1, c32{0.0f, 0.0f});
+        for (int k2 = 0; k2 < q2; ++k2)
+            for (int j3 = 0; j3 < q3; ++j3) {
+                const double a = -2.0 * pi * (double)((j3 * k2) % (int)m1) / (double)m1;
+                P.p_t2[(size_t)k2 * q3 + j3] = c32{(float)std::cos(a), (float)std::sin(a)};
+            }
+        for (size_t k = 0; k <= Nh / 2; ++k) {
+            const double a = -pi * (double)k / (double)Nh;
+            P.p_t2[t2e + k] = c32{(float)std::cos(a), (float)std::sin(a)};
+        }
+    }
     return true;
 }
 
@@ -227,6 +256,7 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     if (H.family == kFamilyP && p_t1 && p_t2 && ones) D.family = kFamilyP;
     D.p_t1 = p_t1;
     D.p_t2 = p_t2;
+    D.half_n = (H.half_n && p_t1 && p_t2 && ones) ? H.half_n : 0;
     D.ones = ones;
     D.f_t1 = f_t1;
     D.f_t2 = f_t2;
