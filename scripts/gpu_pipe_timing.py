@@ -14,7 +14,9 @@ npix = nx * ny
 d_t = eng.to_device(tm); d_raw = eng.empty((npix, nt)); eng.synth_cube(d_raw, npix, 0, d_t)
 d_pre = eng.to_device(chain["w_pre"]); d_fd = eng.to_device(chain["fd_mask"]); d_post = eng.to_device(chain["w_post"])
 d_fft = eng.empty((npix, nf, 2)); d_amp = eng.empty((npix, nf)); d_ph = eng.empty((npix, nf)); d_out = eng.empty((npix, nt)); d_img = eng.empty((npix,))
-cases = [("pipeline", lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img), 16 * nt + 20),
+d_sums = eng.empty((2 * nf,)) if os.environ.get('THZ_SUMS') else None  # THZ_SUMS=1: the pixel sums a session recompute carries
+cases = [("pipeline", (lambda: eng.pipeline_ex(npix, d_raw, d_pre, d_fd, None, d_post, d_fft, d_amp, d_ph, d_out, d_img, d_sums)) if d_sums is not None
+          else (lambda: eng.pipeline(npix, d_raw, d_pre, d_fd, d_post, d_fft, d_amp, d_ph, d_out, d_img)), 16 * nt + 20),
          ("fwd M_fwd", lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, None, None, d_fd), 8 * nt + 8),
          ("fwd all", lambda: eng.fft(npix, d_raw, d_pre, None, None, d_fft, d_amp, d_ph, d_fd), 4 * nt + 16 * nf),
          ("probe", lambda: eng.traffic_probe(npix, nt, d_raw, d_fft, d_amp, d_ph, d_out), 16 * nt + 16),
