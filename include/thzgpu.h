@@ -99,13 +99,16 @@ int thz_memset(thz_ctx *ctx, void *d_dst, int value, size_t bytes);
  * Replaces RealFftPlanner::plan_fft_forward/inverse + the frequency-axis rule
  * at io.rs:614-621, data_thread.rs:1194-1207, tilt_compensation.rs:206-217:
  * frequency[i] = i / (time[nt-1] - time[0]), i = 0..nt/2.
- * Supported nt: powers of two 4..16384 and any other length 2..8191 (chirp-z;
- * with the G kernels forced — thz_set_kernel_family(1) — any other 2..4096). */
+ * Supported nt: any length 2..65536, as realfft plans any length.  Lengths whose transform buffers do not fit a
+ * CU's LDS — not a power of two above 8191 (4096 with thz_set_kernel_family(1)), powers of two above 16384 — run
+ * with those buffers in global scratch (up to 1 GiB, allocated here): correct, two orders of magnitude slower per
+ * sample than the lengths with a kernel of their own. */
 int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt);
 /* Kernel family selection: 0 = automatic (register-resident three-pass "F"
  * kernels for nt = 1024/2048/4096; mixed-radix "P" kernels for the lengths that
  * factor into three small radices — nt = 1001 = 7 x 11 x 13, the length of the
- * reference's real scans, and 1000 / 1200 / 1500 / 2000; chirp-z over the F core — "FB" kernels —
+ * reference's real scans, and 1000 / 1200 / 1500 / 2000; half-length mixed-radix "PH" kernels for
+ * 2002 / 2400 / 3000 / 4000 (twice a P length); chirp-z over the F core — "FB" kernels —
  * for the other lengths that are not a power of two; LDS Stockham "G" kernels
  * for the remaining powers of two), 1 = G kernels (Stockham / Bluestein in LDS)
  * for every length, 2 = automatic without the P kernels (A/B measurements, tests).

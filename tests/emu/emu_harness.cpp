@@ -10,13 +10,15 @@ namespace thz { extern int g_f_bar_override; extern int g_p_pairs_override; exte
 
 static int g_allow_f = 1, g_allow_p = 1;
 static std::vector<float> g_ones;
+static std::vector<c32> g_big;  // "global scratch" of a plan whose buffers do not fit LDS
 static PlanDev make_plan(PlanHost &H)
 {
     g_ones.assign((size_t)H.nf, 1.0f);
+    if (H.big) g_big.assign((size_t)H.big_waves * (size_t)H.lds_per_wave / sizeof(c32), c32{0.0f, 0.0f});
     return plan_dev(H, H.tw.data(), H.tw_split.data(), H.chirp_conj.data(), H.bfft.data(),
                     H.f_t1.empty() ? nullptr : H.f_t1.data(), H.f_t2.empty() ? nullptr : H.f_t2.data(),
                     H.f_w2n.empty() ? nullptr : H.f_w2n.data(), g_ones.data(), H.p_t1.empty() ? nullptr : H.p_t1.data(),
-                    H.p_t2.empty() ? nullptr : H.p_t2.data());
+                    H.p_t2.empty() ? nullptr : H.p_t2.data(), H.big ? g_big.data() : nullptr);
 }
 
 extern "C" {
@@ -61,7 +63,7 @@ int emu_pipeline(int nt, size_t npix, const float *raw, const float *pre, const 
 {
     PlanHost H;
     if (!build_plan((size_t)nt, H, g_allow_f != 0, g_allow_p != 0)) return -2;
-    if (H.mode != kModePow2 && H.family < kFamilyFB) return -2;
+    if (H.mode != kModePow2 && H.family < kFamilyFB && !H.big) return -2;
     PlanDev D = make_plan(H);
     launch_pipeline(nullptr, D, npix, raw, pre, mask, post, (c32 *)fft, amp, ph, out, img);
     return 0;

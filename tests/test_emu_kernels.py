@@ -220,6 +220,37 @@ def test_half_length_pipeline_vs_oracle(emu, nt, npix):
     assert np.array_equal(out2, out) and np.array_equal(img2, img)
 
 
+@pytest.mark.parametrize("nt,npix", [(8200, 3), (8193, 1), (32768, 2)])
+def test_long_traces_global_scratch_vs_oracle(emu, nt, npix):
+    """trace lengths whose transform buffers do not fit the CU's LDS — not a power of two above 8191, powers of two
+    above 16384 — run the G kernels with their buffers in global scratch (round 3: realfft plans any length, these were
+    THZ_ERR_UNSUPPORTED); forward, inverse and the two-launch chain against the oracle"""
+    emu.emu_allow_f(1)
+    emu.emu_allow_p(1)
+    emu.emu_set_grid_cap(1)   # one block of four waves: the emulation runs every lane as a host thread
+    try:
+        time = synth.make_time(nt)
+        cube = synth.make_traces(np.arange(npix) + 3, max(nt, 320))[:, :nt].reshape(npix, 1, nt).copy()
+        chain = synth.default_chain(time)
+        nf = nt // 2 + 1
+        fft = np.zeros((npix, nf, 2), np.float32); amp = np.zeros((npix, nf), np.float32)
+        ph = np.zeros((npix, nf), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+        assert emu.emu_pipeline(nt, C.c_size_t(npix), _p(cube), _p(chain["w_pre"]), _p(chain["fd_mask"]), _p(chain["w_post"]),
+                                _p(fft), _p(amp), _p(ph), _p(out), _p(img)) == 0
+    finally:
+        emu.emu_set_grid_cap(0)
+    ref = ob.run_pipeline(cube, time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert np.abs(fft.reshape(ref["fft"].shape) - ref["fft"]).max() / scale < 1e-5
+    assert np.abs(amp.reshape(ref["amplitudes"].shape) - ref["amplitudes"]).max() / scale < 1e-5
+    assert np.abs(out.reshape(ref["data"].shape) - ref["data"]).max() / max(np.abs(ref["data"]).max(), 1e-30) < 1e-5
+    assert np.abs(img.reshape(ref["img"].shape) - ref["img"]).max() / max(ref["img"].max(), 1e-30) < 1e-5
+    st = ob.fft_stage((cube * chain["w_pre"]).astype(np.float32), time, 0, 0.0, 0.0)
+    strong = st["amplitudes"] > 0.05 * st["amplitudes"].max(axis=-1, keepdims=True)
+    d = ph.reshape(ref["phases"].shape).astype(np.float64) - ref["phases"]
+    assert np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))[strong].max() < 3e-3
+
+
 @pytest.mark.parametrize("nt", [1024, 4096])
 def test_f_kernels_full_window_and_data_out(emu, nt):
     """non-edge windows (Hann: every block != 1) take the F kernels' "full" path;

@@ -732,6 +732,36 @@ def test_half_length_fused_pipeline(engine, shape):
     assert np.array_equal(again, got["data"])
 
 
+@pytest.mark.parametrize("shape", [(3, 1, 8193), (2, 3, 10000), (5, 1, 32768), (1, 1, 16386), (2100, 1, 8200)])
+def test_long_traces_global_scratch(engine, shape):
+    """trace lengths whose transform buffers do not fit the CU's LDS (not a power of two above 8191, powers of two above
+    16384; realfft plans any length, io.rs:616-618) run the G kernels with their buffers in global scratch: the fused
+    entry point (two launches) and the stage entry points against the oracle; more traces than the scratch has waves"""
+    nx, ny, nt = shape
+    time = synth.make_time(nt)
+    cube = synth.make_traces(np.arange(nx * ny) % 7 + 5, max(nt, 1024))[:, :nt].reshape(nx, ny, nt).copy()
+    engine.set_time_axis(time)
+    assert "global-scratch" in engine.kernel_variant()
+    got = synth.run_gpu_pipeline(engine, cube, synth.default_chain(time))
+    chain = synth.oracle_chain(time)
+    sel = slice(0, min(nx, 3))          # the oracle's generic transform is slow at these lengths: a few traces
+    ref = ob.run_pipeline(cube[sel], time, chain)
+    scale = np.abs(ref["fft"]).max()
+    assert rel(got["fft"][sel], ref["fft"], scale) < TOL
+    assert rel(got["amplitudes"][sel], ref["amplitudes"], scale) < TOL
+    assert rel(got["data"][sel], ref["data"]) < TOL
+    assert rel(got["img"][sel], ref["img"]) < TOL
+    st = ob.fft_stage(cube[sel] * chain["w_tilt"] * chain["w_td_before"], time, 0, 1.0, 7.0)
+    assert phase_ok(got["phases"][sel], ref["phases"], st["amplitudes"])
+    if nx >= 21:   # every slot of the scratch is reused: the traces repeat with period 7
+        assert np.array_equal(got["data"][7:14], got["data"][0:7]) and np.array_equal(got["fft"][-7:], got["fft"][nx - 14:nx - 7])
+    st_g = gpu_fft_stage(engine, cube[sel], pkg.host_fft_window(time, 0, 1.0, 7.0))
+    st_o = ob.fft_stage(cube[sel], time, 0, 1.0, 7.0)
+    assert np.array_equal(st_g["data"], st_o["data"])
+    assert rel(st_g["fft"], st_o["fft"], np.abs(st_o["fft"]).max()) < TOL
+    assert phase_ok(st_g["phases"], st_o["phases"], st_o["amplitudes"])
+
+
 @pytest.mark.parametrize("nt", [3, 6, 7, 1001, 2000, 4000])
 def test_chirpz_without_windows_matches_numpy(engine, nt):
     """no multipliers at all: X = rfft(x) and y = irfft(X) = x, against numpy fp64"""

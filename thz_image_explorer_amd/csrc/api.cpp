@@ -49,6 +49,7 @@ void thz_destroy(thz_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (auto &g : ctx->dc_graph) g.drop();
     ctx->drop_dc_tables();
@@ -159,7 +160,7 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
     if (!build_plan(nt, H, ctx->allow_f, ctx->allow_p))
         return fail(ctx, THZ_ERR_UNSUPPORTED,
                     "unsupported trace length " + std::to_string(nt) +
-                        " (powers of two 4..16384, or any length 2..8191)");
+                        " (any length 2..65536)");
     const size_t n_tw = H.tw.size(), n_sp = H.tw_split.size(), n_ch = H.chirp_conj.size(),
                  n_bf = H.bfft.size();
     const size_t n_f1 = H.f_t1.size(), n_f2 = H.f_t2.size(), n_fw = H.f_w2n.size();
@@ -186,8 +187,16 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
         (void)hipFree(d);
         return fail(ctx, THZ_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
     }
+    c32 *d_big = nullptr;
+    if (H.big && hipMalloc((void **)&d_big, (size_t)H.big_waves * (size_t)H.lds_per_wave) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return fail(ctx, THZ_ERR_HIP, "scratch of the long-trace transform: allocation failed");
+    }
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_big) (void)hipFree(ctx->d_big);
     ctx->d_tables = d;
+    ctx->d_big = d_big;
     ctx->plan_h = H;
     const size_t o_f = n_tw + n_sp + n_ch + n_bf;
     ctx->plan_d = plan_dev(H, d, n_sp ? d + n_tw : nullptr, n_ch ? d + n_tw + n_sp : nullptr,
@@ -195,7 +204,7 @@ int thz_set_time_axis(thz_ctx *ctx, const float *time, size_t nt)
                            n_f2 ? d + o_f + n_f1 : nullptr, n_fw ? d + o_f + n_f1 + n_f2 : nullptr,
                            reinterpret_cast<const float *>(d + o_f + n_f1 + n_f2 + n_fw),
                            n_p1 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones : nullptr,
-                           n_p2 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones + n_p1 : nullptr);
+                           n_p2 ? d + o_f + n_f1 + n_f2 + n_fw + n_ones + n_p1 : nullptr, d_big);
     ctx->plan_allow_f = ctx->allow_f;
     ctx->plan_allow_p = ctx->allow_p;
     ctx->time.assign(time, time + nt);
@@ -421,6 +430,7 @@ int thz_pipeline(thz_ctx *ctx, size_t npix, const float *d_raw, const float *d_p
     if (int rc = need_plan(ctx)) return rc;
     if (!d_raw || !d_data_out) return fail(ctx, THZ_ERR_INVALID, "thz_pipeline: null input/output");
     if (npix == 0) return THZ_OK;
+    if (ctx->plan_d.big_scratch && !d_fft) return fail(ctx, THZ_ERR_INVALID, "thz_pipeline: d_fft is required for this trace length");
     StageTimer t(ctx, THZ_STAGE_PIPELINE);
     if (ctx->plan_d.mode == kModePow2
         || ((ctx->plan_d.family == kFamilyFB || ctx->plan_d.family == kFamilyFB2 || ctx->plan_d.family == kFamilyFB4

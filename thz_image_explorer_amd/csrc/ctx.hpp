@@ -21,6 +21,7 @@ struct thz_ctx {
     PlanHost plan_h;
     PlanDev plan_d{};
     c32 *d_tables = nullptr;  // one allocation: tw | tw_split | chirp_conj | bfft
+    c32 *d_big = nullptr;     // global scratch of a plan whose buffers do not fit LDS (plan_d.big_scratch), or null
     bool have_plan = false;
     bool allow_f = true, allow_p = true;  // thz_set_kernel_family
     bool plan_allow_f = true, plan_allow_p = true;  // the switches the current plan was built under

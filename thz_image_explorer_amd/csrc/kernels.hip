@@ -27,12 +27,32 @@
 
 namespace thz {
 
+// Where a wave's two transform buffers live decides what orders its accesses: in LDS the DS instructions of one wave
+// execute in issue order and wave_sync() (a compiler fence) is all it takes; in GLOBAL scratch — trace lengths whose
+// buffers do not fit the CU's LDS: not a power of two above 8191, powers of two above 16384 (round 3) — a lane's loads
+// must see what other lanes of the wave stored in the pass before: a workgroup-scope fence (the waves of a block share the
+// CU's vector cache, whatever else the compiler knows the target needs).
+struct SyncLds {
+    static __device__ __forceinline__ void sync() { wave_sync(); }
+};
+struct SyncGlobal {
+    static __device__ __forceinline__ void sync()
+    {
+#ifdef THZ_EMU
+        wave_sync();
+#else
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+    }
+};
+
 // ---------------------------------------------------------------------------
 // wave-level complex FFT in LDS (Stockham autosort, radix-4 then radix-2)
 // a, b: ping-pong buffers of N = 1 << log2n entries, input in a.
 // tw:   W_N^m = exp(-2*pi*i*m/N), m in [0, N)
 // Returns the buffer that holds the result.  Ends with a wave_sync().
 // ---------------------------------------------------------------------------
+template <class S = SyncLds>
 __device__ __forceinline__ c32 *wave_cfft(c32 *a, c32 *b, int log2n, const c32 *__restrict__ tw,
                                           int lane)
 {
@@ -60,7 +80,7 @@ __device__ __forceinline__ c32 *wave_cfft(c32 *a, c32 *b, int log2n, const c32 *
             dst[j + 2 * Ns] = csub(s02, s13);
             dst[j + 3 * Ns] = c32{d02.re - d13.im, d02.im + d13.re};
         }
-        wave_sync();
+        S::sync();
         c32 *t_ = src; src = dst; dst = t_;
         log2ns += 2;
         rem -= 2;
@@ -77,7 +97,7 @@ __device__ __forceinline__ c32 *wave_cfft(c32 *a, c32 *b, int log2n, const c32 *
             dst[j] = cadd(u0, u1);
             dst[j + Ns] = csub(u0, u1);
         }
-        wave_sync();
+        S::sync();
         c32 *t_ = src; src = dst; dst = t_;
     }
     return src;
@@ -86,17 +106,18 @@ __device__ __forceinline__ c32 *wave_cfft(c32 *a, c32 *b, int log2n, const c32 *
 // Bluestein core: on entry `a` holds the chirp-premultiplied, zero-padded
 // sequence (M entries).  Leaves c = IFFT_M(FFT_M(a) .* bfft) SWAPPED (re<->im)
 // in the returned buffer; bfft already carries 1/M.
+template <class S = SyncLds>
 __device__ __forceinline__ c32 *wave_bluestein_core(c32 *a, c32 *b, const PlanDev &P, int lane)
 {
     const int M = 1 << P.log2n;
-    c32 *Z = wave_cfft(a, b, P.log2n, P.tw, lane);
+    c32 *Z = wave_cfft<S>(a, b, P.log2n, P.tw, lane);
     c32 *other = (Z == a) ? b : a;
     for (int i = lane; i < M; i += kWave) {
         const c32 v = cmul(Z[i], P.bfft[i]);
         Z[i] = c32{v.im, v.re};  // swap: inverse transform through the forward passes
     }
-    wave_sync();
-    return wave_cfft(Z, other, P.log2n, P.tw, lane);
+    S::sync();
+    return wave_cfft<S>(Z, other, P.log2n, P.tw, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -106,7 +127,7 @@ __device__ __forceinline__ c32 *wave_bluestein_core(c32 *a, c32 *b, const PlanDe
 // When KEEP_MASKED the masked spectrum is also written back into Xb (the fused
 // pipeline feeds it to the inverse transform).
 // ---------------------------------------------------------------------------
-template <bool KEEP_MASKED>
+template <bool KEEP_MASKED, class S = SyncLds>
 __device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int nf, size_t p,
                                                   c32 *__restrict__ fft_out,
                                                   float *__restrict__ amp_out,
@@ -126,7 +147,7 @@ __device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int n
         if (fft_out) fft_out[p * nf + k] = Xm;
         if (KEEP_MASKED) Xb[k] = Xm;
     }
-    wave_sync();
+    S::sync();
     if (!want_phase) return;
 
     // numpy_unwrap (math_tools.rs:211-240) as a two-level scan: each lane owns
@@ -139,7 +160,7 @@ __device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int n
     const int end = (start + C < nf) ? start + C : nf;
     float prev = (start > 0 && start < nf) ? scratch[start - 1] : 0.0f;
     const float first = scratch[0];
-    wave_sync();
+    S::sync();
     float s = 0.0f;
     for (int i = start; i < end; ++i) {
         const float v = scratch[i];
@@ -156,13 +177,14 @@ __device__ __forceinline__ void spectrum_epilogue(c32 *Xb, float *scratch, int n
     const float incl = wave_scan_add(s);
     const float excl = wave_shr1(incl);
     for (int i = start; i < end; ++i) scratch[i] = first + (excl + scratch[i]);
-    wave_sync();
+    S::sync();
     for (int k = lane; k < nf; k += kWave) ph_out[p * nf + k] = scratch[k];
-    wave_sync();
+    S::sync();
 }
 
 // R2C split for the power-of-two path: Z = FFT_N(z), z[n] = x[2n] + i x[2n+1]
 // -> X[0..N] into Xb (N+1 entries).
+template <class S = SyncLds>
 __device__ __forceinline__ void r2c_split(const c32 *Z, c32 *Xb, int N,
                                           const c32 *__restrict__ tw_split, int lane)
 {
@@ -180,11 +202,12 @@ __device__ __forceinline__ void r2c_split(const c32 *Z, c32 *Xb, int N,
             Xb[N - k] = cconj(csub(E, t));
         }
     }
-    wave_sync();
+    S::sync();
 }
 
 // Inverse of r2c_split for the unnormalised C2R, written SWAPPED (re<->im) so
 // that the forward passes compute the inverse transform.
+template <class S = SyncLds>
 __device__ __forceinline__ void c2r_merge_swapped(const c32 *X, c32 *Zs, int N,
                                                   const c32 *__restrict__ tw_split, int lane)
 {
@@ -205,7 +228,7 @@ __device__ __forceinline__ void c2r_merge_swapped(const c32 *X, c32 *Zs, int N,
             Zs[N - k] = c32{zn.im, zn.re};
         }
     }
-    wave_sync();
+    S::sync();
 }
 
 __device__ __forceinline__ float apply2(float v, const float *__restrict__ wa,
@@ -242,24 +265,18 @@ __device__ __forceinline__ void c2r_store(const c32 *R, int N, int nt, size_t p,
 // ---------------------------------------------------------------------------
 // forward:  math_tools::fft (+ optional band-pass multiply)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fft_fwd(PlanDev P, size_t npix,
-                                                 const float *__restrict__ in,
-                                                 const float *__restrict__ wa,
-                                                 const float *__restrict__ wb,
-                                                 float *__restrict__ data_out,
-                                                 c32 *__restrict__ fft_out,
-                                                 float *__restrict__ amp_out,
-                                                 float *__restrict__ ph_out,
-                                                 const float *__restrict__ mask)
+template <class S>
+__device__ __forceinline__ void fft_fwd_body(const PlanDev &P, size_t npix, const float *__restrict__ in,
+                                             const float *__restrict__ wa, const float *__restrict__ wb,
+                                             float *__restrict__ data_out, c32 *__restrict__ fft_out,
+                                             float *__restrict__ amp_out, float *__restrict__ ph_out,
+                                             const float *__restrict__ mask, c32 *A, c32 *B)
 {
-    THZ_DYN_LDS(lds);
     const int lane = lane_id();
     const int wib = (int)(threadIdx.x >> 6);
     const int wpb = (int)(blockDim.x >> 6);
     const int N = 1 << P.log2n;
     const int nt = P.nt, nf = P.nf;
-    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
-    c32 *B = A + P.buf_entries;
 
     for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
         const float *x = in + p * nt;
@@ -273,10 +290,10 @@ __global__ __launch_bounds__(256) void k_fft_fwd(PlanDev P, size_t npix,
                 if (data_out) *reinterpret_cast<float2 *>(data_out + p * nt + 2 * i) = v;
                 A[i] = c32{v.x, v.y};
             }
-            wave_sync();
-            c32 *Z = wave_cfft(A, B, P.log2n, P.tw, lane);
+            S::sync();
+            c32 *Z = wave_cfft<S>(A, B, P.log2n, P.tw, lane);
             Xb = (Z == A) ? B : A;
-            r2c_split(Z, Xb, N, P.tw_split, lane);
+            r2c_split<S>(Z, Xb, N, P.tw_split, lane);
             scratch = reinterpret_cast<float *>(Z);
         } else {
             for (int i = lane; i < N; i += kWave) {
@@ -289,28 +306,60 @@ __global__ __launch_bounds__(256) void k_fft_fwd(PlanDev P, size_t npix,
                 }
                 A[i] = v;
             }
-            wave_sync();
-            c32 *R = wave_bluestein_core(A, B, P, lane);
+            S::sync();
+            c32 *R = wave_bluestein_core<S>(A, B, P, lane);
             Xb = (R == A) ? B : A;
             for (int k = lane; k < nf; k += kWave) {
                 const c32 r = R[k];
                 Xb[k] = cmul(c32{r.im, r.re}, P.chirp_conj[k]);
             }
-            wave_sync();
+            S::sync();
             if (lane == 0) {
                 Xb[0].im = 0.0f;  // real input: DC (and Nyquist) bins are real
                 if ((nt & 1) == 0) Xb[nf - 1].im = 0.0f;
             }
-            wave_sync();
+            S::sync();
             scratch = reinterpret_cast<float *>(R);
         }
-        spectrum_epilogue<false>(Xb, scratch, nf, p, fft_out, amp_out, ph_out, mask, lane);
+        spectrum_epilogue<false, S>(Xb, scratch, nf, p, fft_out, amp_out, ph_out, mask, lane);
     }
+}
+
+__global__ __launch_bounds__(256) void k_fft_fwd(PlanDev P, size_t npix,
+                                                 const float *__restrict__ in,
+                                                 const float *__restrict__ wa,
+                                                 const float *__restrict__ wb,
+                                                 float *__restrict__ data_out,
+                                                 c32 *__restrict__ fft_out,
+                                                 float *__restrict__ amp_out,
+                                                 float *__restrict__ ph_out,
+                                                 const float *__restrict__ mask)
+{
+    THZ_DYN_LDS(lds);
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)(threadIdx.x >> 6) * P.lds_per_wave);
+    fft_fwd_body<SyncLds>(P, npix, in, wa, wb, data_out, fft_out, amp_out, ph_out, mask, A, A + P.buf_entries);
+}
+
+// the same transform with the wave's buffers in global scratch (P.big_scratch: 2 buf_entries per wave of the grid)
+__global__ __launch_bounds__(256) void k_fft_fwd_big(PlanDev P, size_t npix,
+                                                     const float *__restrict__ in,
+                                                     const float *__restrict__ wa,
+                                                     const float *__restrict__ wb,
+                                                     float *__restrict__ data_out,
+                                                     c32 *__restrict__ fft_out,
+                                                     float *__restrict__ amp_out,
+                                                     float *__restrict__ ph_out,
+                                                     const float *__restrict__ mask)
+{
+    const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c32 *A = P.big_scratch + gw * 2 * (size_t)P.buf_entries;
+    fft_fwd_body<SyncGlobal>(P, npix, in, wa, wb, data_out, fft_out, amp_out, ph_out, mask, A, A + P.buf_entries);
 }
 
 // ---------------------------------------------------------------------------
 // inverse:  math_tools::ifft per-pixel part (+ optional window, intensity)
 // ---------------------------------------------------------------------------
+template <class S = SyncLds>
 __device__ __forceinline__ void inverse_from_lds(const PlanDev &P, c32 *X, c32 *other, size_t p,
                                                  const float *__restrict__ win,
                                                  float *__restrict__ out, float *__restrict__ img,
@@ -318,32 +367,29 @@ __device__ __forceinline__ void inverse_from_lds(const PlanDev &P, c32 *X, c32 *
 {
     const int N = 1 << P.log2n;
     // pow2 only: X holds nf = N+1 bins in natural order
-    c2r_merge_swapped(X, other, N, P.tw_split, lane);
-    c32 *R = wave_cfft(other, X, P.log2n, P.tw, lane);
+    c2r_merge_swapped<S>(X, other, N, P.tw_split, lane);
+    c32 *R = wave_cfft<S>(other, X, P.log2n, P.tw, lane);
     c2r_store(R, N, P.nt, p, win, out, img, lane);
-    wave_sync();
+    S::sync();
 }
 
-__global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
-                                                 const c32 *__restrict__ fft_in,
-                                                 const float *__restrict__ win,
-                                                 float *__restrict__ out, float *__restrict__ img)
+template <class S>
+__device__ __forceinline__ void fft_inv_body(const PlanDev &P, size_t npix, const c32 *__restrict__ fft_in,
+                                             const float *__restrict__ win, float *__restrict__ out,
+                                             float *__restrict__ img, c32 *A, c32 *B)
 {
-    THZ_DYN_LDS(lds);
     const int lane = lane_id();
     const int wib = (int)(threadIdx.x >> 6);
     const int wpb = (int)(blockDim.x >> 6);
     const int N = 1 << P.log2n;
     const int nt = P.nt, nf = P.nf;
-    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * P.lds_per_wave);
-    c32 *B = A + P.buf_entries;
 
     for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
         const c32 *Xg = fft_in + p * nf;
         if (P.mode == kModePow2) {
             for (int k = lane; k < nf; k += kWave) A[k] = Xg[k];
-            wave_sync();
-            inverse_from_lds(P, A, B, p, win, out, img, lane);
+            S::sync();
+            inverse_from_lds<S>(P, A, B, p, win, out, img, lane);
         } else {
             // x[t] = Re DFT(conj Xfull)[t]; Xfull = Hermitian extension
             const int half = nt / 2;
@@ -359,8 +405,8 @@ __global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
                 }
                 A[j] = v;
             }
-            wave_sync();
-            c32 *R = wave_bluestein_core(A, B, P, lane);
+            S::sync();
+            c32 *R = wave_bluestein_core<S>(A, B, P, lane);
             const DivConst by_nt((float)nt);
             float acc = 0.0f;
             for (int t = lane; t < nt; t += kWave) {
@@ -376,9 +422,29 @@ __global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
                 acc = wave_reduce_add(acc);
                 if (lane == 0) img[p] = acc;
             }
-            wave_sync();
+            S::sync();
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_fft_inv(PlanDev P, size_t npix,
+                                                 const c32 *__restrict__ fft_in,
+                                                 const float *__restrict__ win,
+                                                 float *__restrict__ out, float *__restrict__ img)
+{
+    THZ_DYN_LDS(lds);
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)(threadIdx.x >> 6) * P.lds_per_wave);
+    fft_inv_body<SyncLds>(P, npix, fft_in, win, out, img, A, A + P.buf_entries);
+}
+
+__global__ __launch_bounds__(256) void k_fft_inv_big(PlanDev P, size_t npix,
+                                                     const c32 *__restrict__ fft_in,
+                                                     const float *__restrict__ win,
+                                                     float *__restrict__ out, float *__restrict__ img)
+{
+    const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c32 *A = P.big_scratch + gw * 2 * (size_t)P.buf_entries;
+    fft_inv_body<SyncGlobal>(P, npix, fft_in, win, out, img, A, A + P.buf_entries);
 }
 
 // ---------------------------------------------------------------------------
@@ -2300,6 +2366,13 @@ void launch_fft_fwd(hipStream_t st, const PlanDev &P, size_t npix, const float *
         dispatch_f<kFwd>(st, P, A, amp_out != nullptr);
         return;
     }
+    if (P.big_scratch) {  // buffers in global scratch: four waves per block, at most big_waves waves
+        unsigned g = (unsigned)((npix + 3) / 4);
+        if (g > (unsigned)(P.big_waves / 4)) g = (unsigned)(P.big_waves / 4);
+        if (g_grid_cap_override > 0 && g > (unsigned)g_grid_cap_override) g = (unsigned)g_grid_cap_override;
+        THZ_LAUNCH(k_fft_fwd_big, g ? g : 1, 256, 0, st, P, npix, in, wa, wb, data_out, fft_out, amp_out, ph_out, mask);
+        return;
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
@@ -2343,6 +2416,13 @@ void launch_fft_inv(hipStream_t st, const PlanDev &P, size_t npix, const c32 *ff
         B.a.npix = npix; B.a.fft_in = reinterpret_cast<const cx *>(fft_in); B.a.mask = P.ones; B.a.post_win = win;
         B.a.data_out = out; B.a.img = img;
         dispatch_fbc<kInv>(st, P, B);
+        return;
+    }
+    if (P.big_scratch) {
+        unsigned g = (unsigned)((npix + 3) / 4);
+        if (g > (unsigned)(P.big_waves / 4)) g = (unsigned)(P.big_waves / 4);
+        if (g_grid_cap_override > 0 && g > (unsigned)g_grid_cap_override) g = (unsigned)g_grid_cap_override;
+        THZ_LAUNCH(k_fft_inv_big, g ? g : 1, 256, 0, st, P, npix, fft_in, win, out, img);
         return;
     }
     unsigned grid, block;
@@ -2443,6 +2523,11 @@ void launch_pipeline(hipStream_t st, const PlanDev &P, size_t npix, const float 
         A.post_win = post_win; A.fft_out = reinterpret_cast<cx *>(fft_out); A.amp_out = amp_out; A.ph_out = ph_out;
         A.data_out = data_out; A.img = img;
         dispatch_fb<kPipe>(st, P, A);
+        return;
+    }
+    if (P.big_scratch && fft_out) {  // long traces: a forward and an inverse launch around the stored spectrum
+        launch_fft_fwd(st, P, npix, raw, pre_win, nullptr, nullptr, fft_out, amp_out, ph_out, mask);
+        launch_fft_inv(st, P, npix, fft_out, post_win, data_out, img);
         return;
     }
     if (P.mode != kModePow2 && fft_out) {

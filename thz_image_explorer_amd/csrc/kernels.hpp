@@ -41,6 +41,10 @@ struct PlanDev {
     // the split twiddles W_2N^k, k <= N / 2, behind p_t2's (even-padded) entries; the family stays the chirp-z one, whose
     // kernels serve what the PH kernels do not (a complex multiplier, thz_set_kernel_family)
     int half_n;        // N, or 0
+    // lengths whose transform buffers do not fit the CU's LDS (not a power of two above 8191, powers of two above
+    // 16384): the G kernels with their buffers in global scratch — 2 buf_entries per wave of a grid of big_waves waves
+    c32 *big_scratch;  // or nullptr
+    int big_waves;
 };
 
 enum : int { kFamilyG = 0, kFamilyF = 1, kFamilyFB = 2, kFamilyFB2 = 3, kFamilyFB4 = 4, kFamilyFB8 = 5, kFamilyP = 6 };  // FB / FB2: chirp-z over the F core (fft_fb.hpp)

@@ -21,6 +21,8 @@ struct PlanHost {
     std::vector<c32> f_t1, f_t2, f_w2n;
     std::vector<c32> p_t1, p_t2;  // P family (PH: of the half length, the split twiddles behind p_t2)
     int half_n = 0;                // PH kernels: nt = 2 half_n
+    bool big = false;              // buffers in global scratch (k_fft_fwd_big / k_fft_inv_big)
+    int big_waves = 0;             // waves of their grid = slots of the scratch
     const char *variant = "";
 };
 
@@ -81,20 +83,26 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
     P.nt = (int)nt;
     P.nf = (int)(nt / 2 + 1);
     size_t N;
+    // Lengths whose buffers do not fit the CU's LDS run the G kernels on global scratch (round 3; realfft plans any
+    // length, io.rs:616-618): powers of two above 16384, anything else above 8191 (4096 without the F core's
+    // kernels) — up to kMaxTraceLength, where a wave's two buffers are 2 MB.
+    constexpr size_t kMaxTraceLength = 65536;
+    if (nt > kMaxTraceLength) return false;
+    P.big = false;
     if (is_pow2(nt) && nt >= 4) {
-        if (nt > 16384) return false;
+        P.big = nt > 16384;
         P.mode = kModePow2;
         N = nt / 2;
-        P.variant = "g-stockham-lds-r4r2";
+        P.variant = P.big ? "g-stockham-global-scratch-r4r2" : "g-stockham-lds-r4r2";
     } else {
-        // chirp-z: the G kernels hold 2 M entries per wave in LDS (nt <= 4096); above that only the
-        // FBS kernels (eight F-core runs per transform) exist, up to nt = 8191
-        if (nt > (allow_f ? 8191u : 4096u)) return false;
+        // chirp-z: the G kernels hold 2 M entries per wave in LDS (nt <= 4096); above that the
+        // FBS kernels (eight F-core runs per transform) up to nt = 8191
+        P.big = nt > (allow_f ? 8191u : 4096u);
         P.mode = kModeBluestein;
         N = 1;
         while (N < 2 * nt - 1) N <<= 1;
         if (allow_f && N < 512) N = 512;  // smallest convolution length of the FB kernels (fft_fb.hpp)
-        P.variant = "g-bluestein-stockham-lds-r4r2";
+        P.variant = P.big ? "g-bluestein-stockham-global-scratch-r4r2" : "g-bluestein-stockham-lds-r4r2";
     }
     int lg = 0;
     while (((size_t)1 << lg) < N) ++lg;
@@ -102,7 +110,16 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
     P.buf_entries = (int)(((N > (size_t)P.nf ? N : (size_t)P.nf) + 1) & ~(size_t)1);
     P.lds_per_wave = 2 * P.buf_entries * (int)sizeof(c32);
     int wpb = (int)(kLdsBytesPerCU / (size_t)P.lds_per_wave);
-    if (wpb < 1) {
+    P.big_waves = 0;
+    if (P.big) {
+        // as many waves as 1 GiB of scratch holds (a pass of a wave is a chain of dependent memory round trips: the
+        // chip wants thousands of them in flight), 256 at least, in blocks of four
+        size_t w = ((size_t)1 << 30) / (size_t)P.lds_per_wave;
+        if (w > 4096) w = 4096;
+        if (w < 256) w = 256;
+        P.big_waves = (int)(w & ~(size_t)3);
+        wpb = 4;
+    } else if (wpb < 1) {
         if (!(allow_f && P.mode == kModeBluestein && N == 16384)) return false;
         wpb = 1;  // no G kernel can run this plan; every entry point goes through k_fbs<8>
     }
@@ -151,7 +168,7 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
     // F core of complex length Nc: the half-length transform of a power-of-two trace (family F), or
     // the length-M convolution transform of a chirp-z length with M <= 2048 (family FB)
     // ... or two core runs per length-4096 convolution (family FB2, 1024 < nt < 2048)
-    const bool fb8 = allow_f && P.mode == kModeBluestein && N == 16384 && f_factors(N / 4, r1, r2, r3);
+    const bool fb8 = allow_f && !P.big && P.mode == kModeBluestein && N == 16384 && f_factors(N / 4, r1, r2, r3);
     const bool fb4 = allow_f && P.mode == kModeBluestein && N == 8192 && f_factors(N / 2, r1, r2, r3);
     const bool fb2 = allow_f && P.mode == kModeBluestein && N == 4096 && f_factors(N, r1, r2, r3);
     const bool fb = !fb2 && allow_f && P.mode == kModeBluestein && f_factors(2 * N, r1, r2, r3);
@@ -234,7 +251,8 @@ inline bool build_plan(size_t nt, PlanHost &P, bool allow_f = true, bool allow_p
 inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
                         const c32 *chirp_conj, const c32 *bfft, const c32 *f_t1 = nullptr,
                         const c32 *f_t2 = nullptr, const c32 *f_w2n = nullptr,
-                        const float *ones = nullptr, const c32 *p_t1 = nullptr, const c32 *p_t2 = nullptr)
+                        const float *ones = nullptr, const c32 *p_t1 = nullptr, const c32 *p_t2 = nullptr,
+                        c32 *big_scratch = nullptr)
 {
     PlanDev D;
     D.nt = H.nt;
@@ -257,6 +275,8 @@ inline PlanDev plan_dev(const PlanHost &H, const c32 *tw, const c32 *tw_split,
     D.p_t1 = p_t1;
     D.p_t2 = p_t2;
     D.half_n = (H.half_n && p_t1 && p_t2 && ones) ? H.half_n : 0;
+    D.big_scratch = H.big ? big_scratch : nullptr;
+    D.big_waves = H.big_waves;
     D.ones = ones;
     D.f_t1 = f_t1;
     D.f_t2 = f_t2;
