@@ -624,14 +624,15 @@ thz_session *thz_group_session_member(thz_group_session *gs, int i);
 int thz_group_session_upload(thz_group_session *gs, const float *cube, int subtract_bias);
 /* UpdateType::Filter(start_stage) on every slab + C2 + C1.  Collective; blocking. */
 int thz_group_session_recompute(thz_group_session *gs, const thz_chain_cfg *cfg, int start_stage, int gather);
-/* UpdateType::Filter(<Deconvolution>) over the group — BASELINE config 4's "1 -> 2 GPUs".  Richardson-Lucy is
- * spatially global per band, so the stage shards by BAND: all-gather of the slabs' "Time Band Pass" output
- * (every member then holds the whole cube), thz_deconvolve with the rank's bands (thz_host_slab over n_filters),
- * all-reduce of the band sums, every member keeps its rows; image (and the final cube, if the last recompute
- * gathered it) re-gathered to rank 0.  Members of one process run on host threads.  An abort or error on any
- * rank makes every rank pass its input through (agreed by a one-float all-reduce).  Same return codes as
- * thz_session_deconvolve.  NOTE: the call's critical path is the widest band's 500 dependent
- * iterations on whichever GPU owns it, so two GPUs shorten the call by little — the split is correct, not fast. */
+/* UpdateType::Filter(<Deconvolution>) over the group — BASELINE config 4's "1 -> 2 GPUs".  The stage's transform, band
+ * energies and recombination are per PIXEL, its Richardson-Lucy iterations per BAND over the whole image: every member
+ * runs the per-pixel parts for its own rows and the iterations for its own bands (contiguous ranges dealt out by a
+ * fitted time model), and what crosses the fabric is two sets of 2-D images — n_filters x Nx x Ny energies out, as many
+ * gains back (grouped ncclBroadcast) — not the cube (round 2's form gathered and all-reduced it).  The output slab stays
+ * on its member; image (and the final cube, if the last recompute gathered it) are re-gathered to rank 0.  Members of
+ * one process run on host threads.  A guard of the reference (the same on every rank) or an abort / error on any rank
+ * (agreed by a one-float all-reduce after each part) makes every slab keep its input.  Same return codes as
+ * thz_session_deconvolve.  DESIGN.md §5: expected times on 2 / 4 / 8 GPUs from measured phase times. */
 int thz_group_session_deconvolve(thz_group_session *gs, const thz_psf *psf, const thz_deconv_cfg *cfg,
                                  volatile const int *abort_flag, float *progress);
 /* Regions of interest over the whole (nx, ny) grid (thz_session_set_rois): every slab sums its rows of the

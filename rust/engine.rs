@@ -240,7 +240,7 @@ impl GpuEngine {
     }
 
     /// The Deconvolution stage over the WHOLE group (`thz_group_session_deconvolve`: on one GPU the session's own
-    /// stage, on several the band-parallel form); everything in front of the stage is flushed first.  Progress
+    /// stage, on several the phased form: per-pixel parts on every member's rows, per-band iterations); everything in front of the stage is flushed first.  Progress
     /// and abort are forwarded live: the engine polls a plain `int` between iteration batches and writes its
     /// progress into a `float`; a watcher thread bridges them to `abort_flag` / `progress_lock`.
     pub fn deconvolve(&mut self, psf: &ThzPsf, cfg: &ThzDeconvCfg, progress_lock: &Arc<RwLock<Option<f32>>>,
