@@ -316,3 +316,42 @@ extern "C" int emu_dc_filter_spectra(const float *filters, int n_bands, int n_ta
                              (c32 *)H);
     return 0;
 }
+
+// The band energies in Parseval form (k_dc_energy_pv) from the filters themselves: spectra at M, the 512-point
+// spectra of the two filter halves, the G / Hp / Hm tables, the traces' spectra, the energies.
+extern "C" int emu_dc_energy_pv(int M, int nt, size_t npix, int n_bands, int n_taps, const float *in, const float *filters,
+                                float *energy)
+{
+    if (!dc_energy_pv_supported((size_t)M, n_taps)) return -4;
+    PlanHost P;
+    if (!build_plan((size_t)M, P, false)) return -2;
+    PlanDev D = plan_dev(P, P.tw.data(), P.tw_split.data(), nullptr, nullptr);
+    const int nk = M / 2 + 1, s = (n_taps - 1) / 2, gstride = dc_pv_gstride(nk);
+    auto trig = [](int m_, std::vector<double> &cs, std::vector<double> &sn) {
+        cs.resize((size_t)m_); sn.resize((size_t)m_);
+        for (int m = 0; m < m_; ++m) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)m / (double)m_;
+            cs[(size_t)m] = std::cos(a);
+            sn[(size_t)m] = std::sin(a);
+        }
+    };
+    std::vector<double> cs, sn, cs_e, sn_e;
+    trig(M, cs, sn);
+    trig(512, cs_e, sn_e);
+    std::vector<c32> H((size_t)n_bands * nk), hht((size_t)2 * n_bands * 512), hpm((size_t)n_bands * 1024), spec(npix * (size_t)nk);
+    std::vector<float> halves((size_t)2 * n_bands * s), g((size_t)n_bands * gstride);
+    for (int b = 0; b < n_bands; ++b) {
+        const float *h = filters + (size_t)b * n_taps;
+        std::copy(h, h + s, halves.begin() + (size_t)(2 * b) * s);
+        std::copy(h + s + 1, h + 2 * s + 1, halves.begin() + (size_t)(2 * b + 1) * s);
+    }
+    launch_dc_filter_spectra(nullptr, filters, n_bands, n_taps, cs.data(), sn.data(), (unsigned)M, (unsigned)nk, H.data());
+    launch_dc_filter_spectra(nullptr, halves.data(), 2 * n_bands, s, cs_e.data(), sn_e.data(), 512u, 512u, hht.data());
+    launch_dc_pv_tables(nullptr, n_bands, nk, gstride, (size_t)M, H.data(), hht.data(), g.data(), hpm.data());
+    std::vector<c32> t1, t2;
+    dc_pv_core_tables(t1, t2);
+    launch_dc_fft(nullptr, D, npix, nt, in, spec.data());
+    const DcPvTables T{t1.data(), t2.data(), hpm.data(), g.data(), gstride};
+    launch_dc_energy_pv(nullptr, T, npix, nt, n_bands, (n_taps - 1) / 2, nk, in, spec.data(), energy);
+    return 0;
+}

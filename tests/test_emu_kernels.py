@@ -456,6 +456,44 @@ def test_deconvolution_transform_kernels(emu, M, nt):
     assert np.abs(res[0][0] - res[1][0]).max() / e_ref.max() < 5e-6
 
 
+@pytest.mark.parametrize("M,nt,kind", [(1024, 300, "pulse"), (2048, 1001, "pulse"), (2048, 1001, "noise"),
+                                       (2048, 1001, "edges"), (4096, 2000, "pulse"), (1024, 100, "noise")])
+def test_deconvolution_band_energies_parseval_form(emu, M, nt, kind):
+    """k_dc_energy_pv: band energies over the 'same' slice as Parseval's sum over |X|^2 c_k M |H_b|^2 minus the
+    energies of the first / last 249 samples of the full convolution (one 512-point complex transform per band),
+    against numpy float64 and against the transform-per-band kernel; pulses, noise up to both ends of the trace
+    (head and tail corrections of the size of the result) and a trace that lives only in its first and last samples"""
+    rng = np.random.default_rng(M + nt)
+    npix, nb, taps = 6, 4, 499
+    shift = (taps - 1) // 2
+    if kind == "pulse":
+        x = synth.make_traces(np.arange(npix) + 3, max(nt, 320))[:, :nt].astype(np.float32)
+    elif kind == "noise":
+        x = rng.standard_normal((npix, nt)).astype(np.float32)
+    else:
+        x = np.zeros((npix, nt), np.float32)
+        x[:, :5] = rng.standard_normal((npix, 5))
+        x[:, -7:] = rng.standard_normal((npix, 7))
+    h = (rng.standard_normal((nb, taps)) * np.hanning(taps)).astype(np.float32) / 20
+    h = (0.5 * (h + h[:, ::-1])).astype(np.float32)      # linear phase, as the Kaiser bank's filters are
+    h[-1] = (rng.standard_normal(taps) / 20).astype(np.float32)   # ... and one that is not: the form does not need it
+    y = np.stack([[np.convolve(x[p].astype(np.float64), h[b].astype(np.float64))[shift:shift + nt] for p in range(npix)]
+                  for b in range(nb)])
+    e_ref = (y ** 2).sum(-1)
+    en = np.zeros((nb, npix), np.float32)
+    rc = emu.emu_dc_energy_pv(M, nt, C.c_size_t(npix), nb, taps, _p(x), _p(h), _p(en))
+    assert rc == 0
+    err = np.abs(en - e_ref).max() / e_ref.max()
+    assert err < 5e-6, err
+    # against the kernel it replaces (same forward transform, same f32 filter spectra)
+    Hs = np.fft.rfft(h.astype(np.float64), M, axis=-1) / M
+    H = np.stack([Hs.real, Hs.imag], -1).astype(np.float32)
+    gain = np.ones((nb, npix), np.float32)
+    en0 = np.zeros((nb, npix), np.float32); out = np.zeros((npix, nt), np.float32); img = np.zeros(npix, np.float32)
+    assert emu.emu_dc_chain(M, nt, C.c_size_t(npix), nb, shift, _p(x), _p(H), _p(gain), 1, _p(en0), _p(out), _p(img)) == 0
+    assert np.abs(en - en0).max() / e_ref.max() < 5e-6
+
+
 def test_helper_kernels(emu):
     """the bandwidth-shaped kernels around the transforms, each in its batched / wave-per-trace form:
     window multiply, two-level column sums (ragged row length), pixel-list sums in list order, block means

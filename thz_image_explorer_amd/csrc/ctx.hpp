@@ -78,6 +78,10 @@ struct thz_ctx {
         size_t M = 0;
         unsigned bank_gen = 0;
         int b0 = -1, b1 = -1;
+        // tables of the Parseval band energies (k_dc_energy_pv), one block: [t1 512][t2 64][hpm nb 1024] c32, then g
+        c32 *d_pv = nullptr;
+        size_t pv_g_off = 0;  // in c32 units from d_pv
+        int pv_gstride = 0;
     } dc_spectra;
     // the spectra of a slab's traces between the energies phase and the recombination phase of a group's
     // Deconvolution stage (thz_dc_slab_energies / thz_dc_slab_combine, deconv_api.cpp)
@@ -91,6 +95,7 @@ struct thz_ctx {
     {
         if (dc_plan.d_tw) (void)hipFree(dc_plan.d_tw);
         if (dc_spectra.d_H) (void)hipFree(dc_spectra.d_H);
+        if (dc_spectra.d_pv) (void)hipFree(dc_spectra.d_pv);
         if (dc_slab.d_spec) (void)hipFree(dc_slab.d_spec);
         dc_plan = DcPlan{};
         dc_spectra = DcSpectra{};

@@ -31,10 +31,39 @@ static_assert(sizeof(cx) == 8, "cx must alias c32");
 struct alignas(16) cx2 {
     cx a, b;
 };
+__device__ __forceinline__ cx cx_mul_pk(cx a, cx b);
 __device__ __forceinline__ cx cx_mul(cx a, cx b)
 {
+#ifdef THZ_CX_MUL_ASM  // A/B builds (scripts/gpu_ab_builds.py): every complex product through cx_mul_pk
+    return cx_mul_pk(a, b);
+#else
     const cx bs = {-b.y, b.x};
     return a.xx * b + a.yy * bs;
+#endif
+}
+// The same product in two instructions: hipcc builds {-b.y, b.x} with a v_xor and a v_mov in front of every cx_mul
+// whose b is not loop-invariant (it folds the broadcasts a.xx / a.yy into op_sel, but not a one-sided negation or a
+// swap), i.e. four VALU instructions and a wait state per product.  Here the negation and the swap ride on the
+// first instruction's modifiers:  t = {-a.y b.y, a.y b.x};  r = {a.x b.x + t.x, a.x b.y + t.y}.
+// A packed-fp32 result needs one wait state before a dependent VALU reads it (the compiler's own listings put an
+// s_nop 0 there); inline asm is opaque to its hazard recognizer, so the wait states are written out.
+// Same roundings as cx_mul as hipcc compiles it: a.y's products rounded, a.x's fused onto them.
+__device__ __forceinline__ cx cx_mul_pk(cx a, cx b)
+{
+#ifdef THZ_EMU
+    const cx bs = {-b.y, b.x};
+    return a.xx * b + a.yy * bs;
+#else
+    cx t, r;
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel_hi:[0,1,1]\n\t"
+        "s_nop 0"
+        : "=&v"(t), "=v"(r)
+        : "v"(a), "v"(b));
+    return r;
+#endif
 }
 __device__ __forceinline__ cx cx_conj(cx a) { return cx{a.x, -a.y}; }
 __device__ __forceinline__ cx cx_mnegi(cx a) { return cx{a.y, -a.x}; }  // a * (-i)
@@ -296,7 +325,8 @@ constexpr float f_unit_im(int e, int d) { return (float)-f_small_sin(kFTwoPi * e
 //     W_N^(2 lane k1) = product of the rows of k1's bits  (at most three multiplies deep: 7 = (1 2) 4, 15 = 7 8)
 //     W_N^((2 lane + 1) k1) = that  x  W_N^k1              (a compile-time constant)
 // — 26 complex multiplies per pass where the full table costs 15 16-byte LDS reads, and 14 KiB of LDS less.
-template <class P, bool COMPACT = false>
+// PK: twiddle products through cx_mul_pk (two VALU instructions each instead of four)
+template <class P, bool COMPACT = false, bool PK = false>
 __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, const cx *t1,
                                              const FAddr<P> &ad, int lane)
 {
@@ -339,13 +369,13 @@ __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, con
             cx v0 = r[0][k1], v1 = r[1][k1];
             if (k1 > 0) {
                 const cx2 w = ld2(t1l + k1 * M1);
-                v0 = cx_mul(v0, w.a);
-                v1 = cx_mul(v1, w.b);
+                v0 = PK ? cx_mul_pk(v0, w.a) : cx_mul(v0, w.a);
+                v1 = PK ? cx_mul_pk(v1, w.b) : cx_mul(v1, w.b);
             }
             st2(buf + ad.w1[k1 & 3] + k1 * M1, v0, v1);  // = e1(k1, 2*lane + {0,1})
         } else {
             cx v = r[0][k1];
-            if (k1 > 0) v = cx_mul(v, t1l[k1 * M1]);
+            if (k1 > 0) v = PK ? cx_mul_pk(v, t1l[k1 * M1]) : cx_mul(v, t1l[k1 * M1]);
             buf[ad.w1[k1 & 3] + k1 * M1] = v;  // = e1(k1, lane)
         }
         if ((k1 & 3) == 3) THZ_SCHED_FENCE();
@@ -353,7 +383,7 @@ __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, con
     wave_sync();
 }
 
-template <class P>
+template <class P, bool PK = false>
 __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr<P> &ad, int lane)
 {
     constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, C2 = P::C2, C3 = P::C3;
@@ -376,7 +406,7 @@ __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) {
             cx v = b[c2][k2];
-            if (k2 > 0) v = cx_mul(v, t2l[k2 * 8]);
+            if (k2 > 0) v = PK ? cx_mul_pk(v, t2l[k2 * 8]) : cx_mul(v, t2l[k2 * 8]);
             // row = k2*R1 + k1, k1 = (lane>>3) + 8*c2
             constexpr int kq = R1 / 4;
             const int variant = (((k2 * kq) & 3) >> 1) ^ c2;  // ((k2*R1/4) + 2*c2) & 3 is 0 or 2

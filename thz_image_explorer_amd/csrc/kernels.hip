@@ -1190,6 +1190,223 @@ __global__ __launch_bounds__(256) THZ_WAVES_PER_SIMD(PL::N <= 512 ? 4 : 3) void 
     }
 }
 
+// Round 3 (second half): the band energies WITHOUT a transform per band and per 2 M samples.  The "same" slice is the
+// full linear convolution (nt + 2 s samples, s = shift = (taps - 1) / 2; no wrap in the M-point circular one) minus its
+// first s and last s samples, so
+//     E_b = sum_n y_b[n]^2  -  sum_(n < s) y_b[n]^2  -  sum_(n >= s + nt) y_b[n]^2
+// * the first sum is Parseval's: (1 / M) sum_k |X[k] M H_b[k]|^2 = sum_(k <= M/2) |X[k]|^2 G_b[k],
+//   G_b[k] = c_k M |H_b[k]|^2 (c = 1 at DC and Nyquist, 2 between) — seventeen multiply-adds per lane and band;
+// * the head y_b[0 .. s) depends only on x[0 .. s) and h_b[0 .. s), the tail only on x[nt - s .. nt) and
+//   h_b[s + 1 .. 2 s]: two linear convolutions of s x s samples (2 s - 1 <= 512), both real — so ONE complex 512-point
+//   inverse transform per band gives both, head in the real part and tail in the imaginary part:
+//       z = xh + i xt,  Z = FFT_512(z)  (once per pixel),   W_b[k] = Z[k] Hp_b[k] + conj(Z[-k]) Hm_b[k],
+//       Hp = (Hh + Ht) / 2, Hm = (Hh - Ht) / 2   (Hh / Ht: 512-point spectra of the two filter halves, / 512)
+//       w = IFFT(W_b):  head[n] = Re w[n], n < s;   tail[r] = Im w[s - 1 + r], r < s.
+// A 512-point complex transform on the FPlan1024 core instead of a 1024-point one with its C2R merge (M = 2048): about
+// a third of the instructions per band, a quarter of the LDS traffic, 4 KiB of LDS per wave.  A band's same-slice
+// energy is at least about half of its full energy for a pulse anywhere in the trace (the filters are symmetric about
+// tap s, which always falls inside the slice), so the subtraction costs at most about one bit.
+struct DcPvDev {
+    const cx *t1, *t2;  // FPlan1024 core tables (complex length 512)
+    const cx2 *hpm;     // [n_bands][512] {Hp, Hm}
+    const float *g;     // [n_bands][gstride], zero beyond bin M / 2
+    int gstride;
+};
+
+// g[b][k] = c_k M |H_b[k]|^2 (k < nk; 0 up to gstride), hpm[b][k] = {(Hh + Ht) / 2, (Hh - Ht) / 2}; hht: [2 b] = Hh_b, [2 b + 1] = Ht_b
+__global__ __launch_bounds__(256) void k_dc_pv_tables(int n_bands, int nk, int gstride, float M, const c32 *__restrict__ H,
+                                                      const c32 *__restrict__ hht, float *__restrict__ g,
+                                                      cx2 *__restrict__ hpm)
+{
+    const int total_g = n_bands * gstride, total_h = n_bands * 512;
+    for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < total_g + total_h; e += (int)(gridDim.x * blockDim.x)) {
+        if (e < total_g) {
+            const int b = e / gstride, k = e % gstride;
+            float v = 0.0f;
+            if (k < nk) {
+                const c32 h = H[(size_t)b * nk + k];
+                const double m2 = (double)h.re * (double)h.re + (double)h.im * (double)h.im;
+                v = (float)(((k == 0 || k == nk - 1) ? 1.0 : 2.0) * (double)M * m2);
+            }
+            g[e] = v;
+        } else {
+            const int f = e - total_g, b = f / 512, k = f % 512;
+            const c32 hh = hht[(size_t)(2 * b) * 512 + k], ht = hht[(size_t)(2 * b + 1) * 512 + k];
+            hpm[f] = cx2{cx{0.5f * (hh.re + ht.re), 0.5f * (hh.im + ht.im)}, cx{0.5f * (hh.re - ht.re), 0.5f * (hh.im - ht.im)}};
+        }
+    }
+}
+
+// Two launches.  k_dc_energy_full: the Parseval sums — PX pixels per wave (their |X|^2 in registers, bins 256 i + 4 lane
+// + c, the Nyquist bin apart), every band's G row read once per PX pixels; bound by reading the spectra.
+// k_dc_energy_edges: one pixel per wave, eight waves per block; the block walks the bands together and stages each
+// band's {Hp, Hm} row (8 KiB) in LDS one band ahead — read from L2 by every wave the rows were 80 GB per call at
+// 512 x 512 pixels and the kernel waited for them 83 % of its time (first build) — and subtracts the edges' energy
+// from what the first launch stored.
+template <int NG, int PX>
+__global__ __launch_bounds__(256) void k_dc_energy_full(DcPvDev T, size_t npix, int n_bands, int nk,
+                                                        const cx *__restrict__ spec, float *__restrict__ energy)
+{
+    const int lane = lane_id();
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t p0 = wave * PX; p0 < npix; p0 += n_waves * PX) {
+        float pw[PX][NG][4], pn[PX];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const bool on = p0 + q < npix;
+            const cx *xs = spec + (on ? p0 + q : p0) * (size_t)nk;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {  // rows of nk = 256 NG + 1 bins start 8-byte aligned only
+                    const cx u = xs[256 * i + 4 * lane + c];
+                    pw[q][i][c] = on ? u.x * u.x + u.y * u.y : 0.0f;
+                }
+            const cx xn = xs[256 * NG];
+            pn[q] = (on && lane == 0) ? xn.x * xn.x + xn.y * xn.y : 0.0f;
+        }
+#pragma unroll 1
+        for (int b = 0; b < n_bands; ++b) {
+            const float *gt = T.g + (size_t)b * T.gstride;
+            float4 g4[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) g4[i] = *reinterpret_cast<const float4 *>(gt + 256 * i + 4 * lane);
+            const float gn = gt[256 * NG];
+            float mine = 0.0f;
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                float acc = pn[q] * gn;
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    acc += pw[q][i][0] * g4[i].x;
+                    acc += pw[q][i][1] * g4[i].y;
+                    acc += pw[q][i][2] * g4[i].z;
+                    acc += pw[q][i][3] * g4[i].w;
+                }
+                acc = wave_reduce_add(acc);
+                if (lane == q) mine = acc;
+            }
+            if (lane < PX && p0 + lane < npix) energy[(size_t)b * npix + p0 + lane] = mine;
+        }
+    }
+}
+
+constexpr int kDcPvWaves = 8;
+struct DcPvLds {
+    using PL = FPlan1024;
+    static constexpr int TAB_ENTRIES = 2 * PL::N;                       // cx units: a band's 512 {Hp, Hm}
+    static constexpr int TAB_UNITS = TAB_ENTRIES / 2;                   // 16-byte units = threads of a block
+    static constexpr int TAB_OFF = PL::T1_ENTRIES + PL::T2_ENTRIES + kDcPvWaves * PL::WAVE_ENTRIES;
+    static constexpr size_t bytes() { return (size_t)(TAB_OFF + 2 * TAB_ENTRIES) * sizeof(cx); }
+    static_assert(TAB_OFF % 2 == 0 && TAB_UNITS == kDcPvWaves * 64, "16-byte units, one per thread");
+};
+
+// SHIFT: the edges' length as a compile-time number (249 for the reference's 499 taps: which of a lane's eight output
+// samples are head, tail or neither is then known per j, only j = 3 and j = 7 keep a lane test), or 0: run-time `shift`
+template <int SHIFT>
+__global__ __launch_bounds__(kDcPvWaves * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edges(DcPvDev T, size_t npix, int nt,
+                                                                                           int n_bands, int shift_rt,
+                                                                                           const float *__restrict__ in,
+                                                                                           float *__restrict__ energy)
+{
+    using PL = FPlan1024;
+    using L = DcPvLds;
+    THZ_DYN_LDS(lds);
+    constexpr int R1 = PL::R1, NC = PL::N, W = kDcPvWaves;
+    static_assert(PL::C1 == 1 && NC == 512 && R1 == 8, "edge transform: 512 complex points, one column per lane");
+    const int shift = SHIFT > 0 ? SHIFT : shift_rt;
+    const int lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int wib = THZ_UNIFORM((int)(threadIdx.x >> 6));
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + PL::T1_ENTRIES;
+    cx *buf = t2 + PL::T2_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
+    cx *tab = t1 + L::TAB_OFF;
+    for (int i = tid; i < PL::T1_ENTRIES; i += W * kWave) t1[i] = T.t1[i];
+    for (int i = tid; i < PL::T2_ENTRIES; i += W * kWave) t2[i] = T.t2[i];
+    const float4 *hsrc = reinterpret_cast<const float4 *>(T.hpm) + tid;  // a band's row: 512 16-byte units, one per thread
+    float4 *hdst = reinterpret_cast<float4 *>(tab) + tid;
+    float4 stage = hsrc[0];
+    hdst[0] = stage;
+    FAddr<PL> ad;
+    ad.init(lane);
+    const int sba = nat(lane), sbb = nat(kWave + lane) - kWave;  // nat(64 j + lane) - 64 j for even / odd j
+    const size_t n_batches = (npix + W - 1) / W;
+    cx za[R1], zb[R1];  // Z[k], conj Z[512 - k] at k = 64 j + lane
+    unsigned t = 0;
+    for (size_t q = blockIdx.x; q < n_batches; q += gridDim.x) {
+        const size_t p = q * W + (size_t)wib;
+        const bool live = p < npix;  // wave-uniform
+        const bool last_batch = q + gridDim.x >= n_batches;
+#pragma unroll 1
+        for (int b = 0; b < n_bands; ++b, ++t) {
+            __syncthreads();  // this band's row is in tab[t & 1]; nobody reads the other half any more
+            const bool more = !(last_batch && b + 1 == n_bands);
+            if (more) stage = hsrc[(size_t)(b + 1 < n_bands ? b + 1 : 0) * NC];
+            const cx *tb = tab + (size_t)(t & 1u) * L::TAB_ENTRIES;
+            if (live) {
+                float full = 0.0f;
+                if (lane == 0) full = energy[(size_t)b * npix + p];  // what k_dc_energy_full stored
+                if (b == 0) {
+                    // ---- Z = FFT_512(xh + i xt): xh[n] = x[n], xt[n] = x[nt - s + n], n < s
+                    const float *x = in + p * (size_t)nt;
+                    ad.refresh();
+                    cx r[1][R1];
+#pragma unroll
+                    for (int j = 0; j < R1; ++j) {
+                        const int n = kWave * j + lane, m = nt - shift + n;
+                        const float xa = (n < shift && n < nt) ? x[n] : 0.0f;
+                        const float xb = (n < shift && m >= 0) ? x[m] : 0.0f;
+                        r[0][j] = cx{xa, xb};
+                    }
+                    f_core_pass1<PL>(r, buf, t1, ad, lane);
+                    f_core_pass23<PL>(buf, t2, ad, lane);
+#pragma unroll
+                    for (int j = 0; j < R1; ++j) {
+                        za[j] = buf[((j & 1) ? sbb : sba) + kWave * j];
+                        zb[j] = cx_conj(buf[nat(NC - kWave * j - lane)]);
+                    }
+                    wave_sync();
+                }
+                ad.refresh();
+                cx r[1][R1];
+                const cx *hb = tb + 2 * launder_v(lane);
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    const cx2 h = ld2(hb + 2 * kWave * j);
+                    const cx w = cx_mul_pk(za[j], h.a) + cx_mul_pk(zb[j], h.b);
+                    r[0][j] = cx{w.y, w.x};  // swapped in, swapped out: the inverse transform through the forward core
+                }
+                f_core_pass1<PL, false, true>(r, buf, t1, ad, lane);
+                f_core_pass23<PL, true>(buf, t2, ad, lane);
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    const cx v = buf[((j & 1) ? sbb : sba) + kWave * j];  // {Im w[n], Re w[n]}, n = 64 j + lane
+                    const int n = kWave * j + lane;
+                    // with SHIFT known the j-th sample's range [64 j, 64 j + 63] settles most of these at compile time
+                    const bool all_h = SHIFT > 0 && kWave * j + kWave - 1 < SHIFT, no_h = SHIFT > 0 && kWave * j >= SHIFT;
+                    const bool all_t = SHIFT > 0 && kWave * j >= SHIFT - 1 && kWave * j + kWave - 1 < 2 * SHIFT - 1;
+                    const bool no_t = SHIFT > 0 && (kWave * j + kWave - 1 < SHIFT - 1 || kWave * j >= 2 * SHIFT - 1);
+                    if (!no_h) {
+                        const float hd = (all_h || n < shift) ? v.y : 0.0f;
+                        acc += hd * hd;
+                    }
+                    if (!no_t) {
+                        const float tl = (all_t || (n >= shift - 1 && n < 2 * shift - 1)) ? v.x : 0.0f;
+                        acc += tl * tl;
+                    }
+                }
+                acc = wave_reduce_add(acc);
+                if (lane == 0) energy[(size_t)b * npix + p] = full - acc;
+                wave_sync();
+            }
+            if (more) hdst[(size_t)((t + 1u) & 1u) * L::TAB_UNITS] = stage;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dc_combine(PlanDev P, size_t npix, int nt, int n_bands,
                                                     int shift, const c32 *__restrict__ spec,
                                                     const c32 *__restrict__ H,
@@ -2867,6 +3084,64 @@ void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int
     dc_geometry(P, npix, 3, &grid, &block, &lds);
     allow_dynamic_lds(k_dc_energy, lds);
     THZ_LAUNCH(k_dc_energy, grid, block, lds, st, P, npix, nt, n_bands, shift, spec, H, energy);
+}
+
+// ---- the band energies in Parseval form (k_dc_energy_pv)
+bool dc_energy_pv_supported(size_t M, int n_taps)
+{
+    const int s = (n_taps - 1) / 2;
+    return (n_taps & 1) && s >= 1 && 2 * s - 1 <= 512 && (M == 1024 || M == 2048 || M == 4096);
+}
+
+void launch_dc_pv_tables(hipStream_t st, int n_bands, int nk, int gstride, size_t M, const c32 *H, const c32 *hht, float *g,
+                         c32 *hpm)
+{
+    const int total = n_bands * (gstride + 512);
+    THZ_LAUNCH(k_dc_pv_tables, (unsigned)((total + 255) / 256), 256, 0, st, n_bands, nk, gstride, (float)M, H, hht, g,
+               reinterpret_cast<cx2 *>(hpm));
+}
+
+template <int NG, int PX>
+static void launch_dc_energy_pv_n(hipStream_t st, const DcPvDev &T, size_t npix, int nt, int n_bands, int shift, int nk,
+                                  const float *in, const c32 *spec, float *energy)
+{
+    {
+        const size_t waves = (npix + PX - 1) / PX;
+        size_t g = (waves + 3) / 4;
+        if (g > (size_t)kNumCU * 8) g = (size_t)kNumCU * 8;
+        THZ_LAUNCH((k_dc_energy_full<NG, PX>), (unsigned)g, 256, 0, st, T, npix, n_bands, nk, reinterpret_cast<const cx *>(spec),
+                   energy);
+    }
+    const size_t lds = DcPvLds::bytes();
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu > 2) per_cu = 2;  // sixteen waves per CU: the kernel is compiled for four per SIMD
+    size_t g = (npix + kDcPvWaves - 1) / kDcPvWaves;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    if (shift == 249) {
+        allow_dynamic_lds(k_dc_energy_edges<249>, lds);
+        THZ_LAUNCH(k_dc_energy_edges<249>, (unsigned)g, kDcPvWaves * kWave, lds, st, T, npix, nt, n_bands, shift, in, energy);
+    } else {
+        allow_dynamic_lds(k_dc_energy_edges<0>, lds);
+        THZ_LAUNCH(k_dc_energy_edges<0>, (unsigned)g, kDcPvWaves * kWave, lds, st, T, npix, nt, n_bands, shift, in, energy);
+    }
+}
+
+int dc_pv_gstride(int nk) { return nk + 3; }  // [bins 0 .. nk - 1)[Nyquist][0 0 0], see DcPvLds
+
+void launch_dc_energy_pv(hipStream_t st, const DcPvTables &Tb, size_t npix, int nt, int n_bands, int shift, int nk,
+                         const float *in, const c32 *spec, float *energy)
+{
+    const DcPvDev T{reinterpret_cast<const cx *>(Tb.t1), reinterpret_cast<const cx *>(Tb.t2),
+                    reinterpret_cast<const cx2 *>(Tb.hpm), Tb.g, Tb.gstride};
+    if (Tb.gstride == dc_pv_gstride(nk)) switch (nk) {
+        case 513: launch_dc_energy_pv_n<2, 4>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
+        case 1025: launch_dc_energy_pv_n<4, 4>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
+        case 2049: launch_dc_energy_pv_n<8, 2>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
+        default: break;
+        }
+    fprintf(stderr, "thzgpu: launch_dc_energy_pv: no kernel for %d bins, row stride %d (dc_energy_pv_supported, dc_pv_gstride)\n",
+            nk, Tb.gstride);
+    abort();
 }
 
 template <class PL>

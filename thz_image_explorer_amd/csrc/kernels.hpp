@@ -80,6 +80,23 @@ void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands,
 void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec);
 void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                       const c32 *spec, const c32 *H, float *energy);
+// The same energies in Parseval form (round 3; k_dc_energy_pv in kernels.hip): full-convolution energy from |X|^2 and
+// c_k M |H_b|^2, minus the energies of the first / last `shift` samples of the full convolution from ONE 512-point
+// complex transform per band.  M in {1024, 2048, 4096}, odd tap count with 2 shift - 1 <= 512.
+struct DcPvTables {
+    const c32 *t1, *t2;  // FPlan1024 core tables (dc_pv_core_tables)
+    const c32 *hpm;      // [n_bands][512][2]: (Hh + Ht) / 2, (Hh - Ht) / 2
+    const float *g;      // [n_bands][gstride]
+    int gstride;         // dc_pv_gstride(nk)
+};
+bool dc_energy_pv_supported(size_t M, int n_taps);
+int dc_pv_gstride(int nk);
+// H: [n_bands][nk] as launch_dc_filter_spectra leaves them; hht: [2 n_bands][512] the 512-point spectra (/ 512) of
+// h_b[0 .. shift) and h_b[shift + 1 .. 2 shift]
+void launch_dc_pv_tables(hipStream_t st, int n_bands, int nk, int gstride, size_t M, const c32 *H, const c32 *hht, float *g,
+                         c32 *hpm);
+void launch_dc_energy_pv(hipStream_t st, const DcPvTables &T, size_t npix, int nt, int n_bands, int shift, int nk,
+                         const float *in, const c32 *spec, float *energy);
 void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                        const c32 *spec, const c32 *H, const float *gain, float *out, float *img);
 void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,

@@ -50,6 +50,26 @@ inline bool f_factors(size_t nt, int &r1, int &r2, int &r3)
     }
 }
 
+// Core tables of the 512-point complex transform (FPlan1024 = 8 x 8 x 8) on their own: the edge transform of the
+// deconvolution's Parseval band energies (k_dc_energy_pv) — the same formulas as build_plan's F tables below
+inline void dc_pv_core_tables(std::vector<c32> &t1, std::vector<c32> &t2)
+{
+    const double pi = 3.14159265358979323846;
+    const size_t Nc = 512, m1 = 64;
+    t1.resize(8 * m1);
+    for (size_t k1 = 0; k1 < 8; ++k1)
+        for (size_t m = 0; m < m1; ++m) {
+            const double a = -2.0 * pi * (double)((m * k1) % Nc) / (double)Nc;
+            t1[k1 * m1 + m] = c32{(float)std::cos(a), (float)std::sin(a)};
+        }
+    t2.resize(64);
+    for (int k2 = 0; k2 < 8; ++k2)
+        for (int j3 = 0; j3 < 8; ++j3) {
+            const double a = -2.0 * pi * (double)((j3 * k2) % 64) / 64.0;
+            t2[(size_t)k2 * 8 + j3] = c32{(float)std::cos(a), (float)std::sin(a)};
+        }
+}
+
 inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
 
 // in-place iterative radix-2 FFT in double (host, table construction only)
