@@ -689,11 +689,36 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
             for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&done.ev[c][k], hipEventDisableTiming));
         std::vector<hipEvent_t> marks[kRlChains];
         hipEvent_t t_start = nullptr;
+        // The first chain (the widest kernels, most iterations) is the call's critical path and ends latency-bound — one
+        // band left, about a tile per CU — while the other chains are throughput work that competes with it when all
+        // start together.  THZ_RL_DELAY (developer knob, batches; default 0) starts them late, beside the first chain's
+        // thin end instead of its full beginning: measured at 512 x 512 x 1001 for 0 / 2 / 4 / 6 / 8 / 10 batches, the
+        // iterations take 23.9 / 24.0 / 23.9 / 24.0 / 23.9 / 23.7 ms — the narrow launches cost the same 5.5-5.9 ms
+        // wherever they run (profiles/r03_rl_chain_placement.txt): the two chains' launches take turns, they do not overlap.
+        int chain_batches[kRlChains] = {0, 0, 0, 0}, delay[kRlChains] = {0, 0, 0, 0};
+        for (size_t c = 0; c < lists.size(); ++c)
+            while (chain_batches[c] * kRlBatch < max_iter && lists[c].live_blocks(chain_batches[c] * kRlBatch) > 0) ++chain_batches[c];
+        for (size_t c = 1; c < lists.size(); ++c) {
+            const char *e = getenv("THZ_RL_DELAY");
+            const int slack = chain_batches[0] - chain_batches[c];
+            delay[c] = e ? atoi(e) : 0;
+            if (delay[c] > slack) delay[c] = slack;
+            if (delay[c] < 0) delay[c] = 0;
+        }
         auto submit = [&](int batch) -> int {
-            const int base = batch * kRlBatch, end = std::min(base + kRlBatch, max_iter);
             for (size_t c = 0; c < lists.size(); ++c) {
-                if (lists[c].live_blocks(base) == 0) continue;
-                if (hipGraphExec_t exec = graph_of(c)) {
+                if (batch < delay[c]) continue;
+                const int base = (batch - delay[c]) * kRlBatch, end = std::min(base + kRlBatch, max_iter);
+                if (base >= max_iter || lists[c].live_blocks(base) == 0) continue;
+                // Chains other than the first are throughput work off the critical path: plain launches, each over
+                // exactly the tiles that still iterate (a prefix of the list) — a replayed graph dispatches the whole
+                // list every time, and at 512 x 512 pixels the narrow list is 19 602 blocks of which most have left
+                // after the first few iterations (THZ_RL_EXACT=0, developer knob: the graph for every chain)
+                static const bool exact = [] { const char *e = getenv("THZ_RL_EXACT"); return !(e && e[0] == '0'); }();
+                if (exact && c > 0 && lists[c].blocks >= 4096) {  // (smaller lists: equal within the noise; 512 x 512: 24.1 -> 23.1 ms)
+                    for (int it = base; it < end; ++it)
+                        if (const unsigned live = lists[c].live_blocks(it)) chain_launches(c, chain_stream[c], nullptr, it, it + 1, live);
+                } else if (hipGraphExec_t exec = graph_of(c)) {
                     HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_it + c), base, 1, chain_stream[c]));
                     HIP_TRY(ctx, hipGraphLaunch(exec, chain_stream[c]));
                 } else {
