@@ -324,8 +324,13 @@ extern "C" int emu_dc_energy_pv(int M, int nt, size_t npix, int n_bands, int n_t
 {
     if (!dc_energy_pv_supported((size_t)M, n_taps)) return -4;
     PlanHost P;
-    if (!build_plan((size_t)M, P, false)) return -2;
+    if (!build_plan((size_t)M, P, true)) return -2;
     PlanDev D = plan_dev(P, P.tw.data(), P.tw_split.data(), nullptr, nullptr);
+    if (!P.f_t1.empty()) {  // the forward transform on the F core too (k_dc_fft_f) where M has one, as deconv_api.cpp runs it
+        D.f_t1 = P.f_t1.data();
+        D.f_t2 = P.f_t2.data();
+        D.f_w2n = P.f_w2n.data();
+    }
     const int nk = M / 2 + 1, s = (n_taps - 1) / 2, gstride = dc_pv_gstride(nk);
     auto trig = [](int m_, std::vector<double> &cs, std::vector<double> &sn) {
         cs.resize((size_t)m_); sn.resize((size_t)m_);

@@ -1269,23 +1269,30 @@ __global__ __launch_bounds__(256) void k_dc_energy_full(DcPvDev T, size_t npix, 
 #pragma unroll 1
         for (int b = 0; b < n_bands; ++b) {
             const float *gt = T.g + (size_t)b * T.gstride;
-            float4 g4[NG];
-#pragma unroll
-            for (int i = 0; i < NG; ++i) g4[i] = *reinterpret_cast<const float4 *>(gt + 256 * i + 4 * lane);
+            constexpr int GB = NG < 8 ? NG : 8;  // rows of G in flight at a time
             const float gn = gt[256 * NG];
-            float mine = 0.0f;
+            float mine = 0.0f, acc[PX];
+#pragma unroll
+            for (int q = 0; q < PX; ++q) acc[q] = pn[q] * gn;
+#pragma unroll
+            for (int i0 = 0; i0 < NG; i0 += GB) {
+                float4 g4[GB];
+#pragma unroll
+                for (int i = 0; i < GB; ++i) g4[i] = *reinterpret_cast<const float4 *>(gt + 256 * (i0 + i) + 4 * lane);
+#pragma unroll
+                for (int q = 0; q < PX; ++q)
+#pragma unroll
+                    for (int i = 0; i < GB; ++i) {
+                        acc[q] += pw[q][i0 + i][0] * g4[i].x;
+                        acc[q] += pw[q][i0 + i][1] * g4[i].y;
+                        acc[q] += pw[q][i0 + i][2] * g4[i].z;
+                        acc[q] += pw[q][i0 + i][3] * g4[i].w;
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
-                float acc = pn[q] * gn;
-#pragma unroll
-                for (int i = 0; i < NG; ++i) {
-                    acc += pw[q][i][0] * g4[i].x;
-                    acc += pw[q][i][1] * g4[i].y;
-                    acc += pw[q][i][2] * g4[i].z;
-                    acc += pw[q][i][3] * g4[i].w;
-                }
-                acc = wave_reduce_add(acc);
-                if (lane == q) mine = acc;
+                const float a = wave_reduce_add(acc[q]);
+                if (lane == q) mine = a;
             }
             if (lane < PX && p0 + lane < npix) energy[(size_t)b * npix + p0 + lane] = mine;
         }
@@ -2922,8 +2929,100 @@ void launch_dc_filter_spectra(hipStream_t st, const float *filters, int n_bands,
                nk, H);
 }
 
+// The forward transform of the zero-padded traces on the F core (round 3; k_dc_fft above is the generic LDS transform:
+// 2.4 ms at 512 x 512 x 1001 for 3.2 GB of traffic): samples beyond nt enter as zeros — whole pass-1 blocks of them are
+// not loaded at all — and the spectrum leaves through the F kernels' own epilogue (split in place, 16-byte stores).
+// LDS: [T1][T2][ones: N + 4 floats][w2n head][wg][per wave: N + 2].
+template <class PL>
+__global__ __launch_bounds__(256) void k_dc_fft_f(FTables T, size_t npix, int nt, const float *__restrict__ in,
+                                                  cx *__restrict__ spec)
+{
+    THZ_DYN_LDS(lds);
+    constexpr int N = PL::N, R1 = PL::R1, C1 = PL::C1, M1 = PL::M1;
+    constexpr int ONES = (N + 4) / 2;  // cx entries
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    cx *t1 = reinterpret_cast<cx *>(lds);
+    cx *t2 = t1 + PL::T1_ENTRIES;
+    float *ones_s = reinterpret_cast<float *>(t2 + PL::T2_ENTRIES);
+    cx *w2n_s = t2 + PL::T2_ENTRIES + ONES;
+    cx *wg_s = w2n_s + PL::W2N_HEAD;
+    cx *buf = wg_s + PL::WG_ENTRIES + (size_t)wib * PL::WAVE_ENTRIES;
+    for (int i = (int)threadIdx.x; i < PL::W2N_HEAD; i += (int)blockDim.x) w2n_s[i] = f_stage_w2n(T.w2n[i]);
+    if ((int)threadIdx.x < R1) wg_s[threadIdx.x] = T.w2n[M1 * (int)threadIdx.x];
+    for (int i = (int)threadIdx.x; i < PL::T1_ENTRIES; i += (int)blockDim.x) t1[i] = T.t1[i];
+    for (int i = (int)threadIdx.x; i < PL::T2_ENTRIES; i += (int)blockDim.x) t2[i] = T.t2[i];
+    for (int i = (int)threadIdx.x; i < 2 * ONES; i += (int)blockDim.x) ones_s[i] = 1.0f;
+    __syncthreads();
+    FAddr<PL> ad;
+    ad.init(lane);
+    FArgs A{};
+    A.npix = npix;
+    A.fft_out = spec;
+    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
+        const float *x = in + p * (size_t)nt;
+        ad.refresh();
+        cx r[C1][R1];
+        // z[n] = x[2 n] + i x[2 n + 1], n = M1 j1 + C1 lane + c: block j1 holds the samples [2 M1 j1, 2 M1 (j1 + 1))
+#pragma unroll
+        for (int j1 = 0; j1 < R1; ++j1) {
+            const int s0 = 2 * (M1 * j1 + C1 * lane);
+            if (2 * M1 * j1 >= nt) {  // wave-uniform: nothing of this block exists
+#pragma unroll
+                for (int c = 0; c < C1; ++c) r[c][j1] = cx{0.0f, 0.0f};
+            } else if (2 * M1 * (j1 + 1) <= nt) {  // wave-uniform: all of it does
+                if constexpr (C1 == 2) {
+                    float a, b, c_, d;
+                    load_f4(x + s0, a, b, c_, d);
+                    r[0][j1] = cx{a, b};
+                    r[1][j1] = cx{c_, d};
+                } else {
+                    r[0][j1] = cx{x[s0], x[s0 + 1]};
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C1; ++c) {
+                    const int i0 = s0 + 2 * c;
+                    r[c][j1] = cx{i0 < nt ? x[i0] : 0.0f, i0 + 1 < nt ? x[i0 + 1] : 0.0f};
+                }
+            }
+        }
+        f_core_pass1<PL>(r, buf, t1, ad, lane);
+        f_core_pass23<PL>(buf, t2, ad, lane);
+        f_spectrum_epilogue<PL, false>(buf, w2n_s, wg_s, ones_s, p, A, lane);
+        wave_sync();
+    }
+}
+
+template <class PL>
+static void launch_dc_fft_f(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec)
+{
+    FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
+              reinterpret_cast<const cx *>(P.f_w2n)};
+    const unsigned wpb = 4;
+    const size_t lds = (size_t)(PL::T1_ENTRIES + PL::T2_ENTRIES + (PL::N + 4) / 2 + PL::W2N_HEAD + PL::WG_ENTRIES
+                                + wpb * PL::WAVE_ENTRIES) * sizeof(cx);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    size_t g = (npix + wpb - 1) / wpb;
+    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    allow_dynamic_lds(k_dc_fft_f<PL>, lds);
+    THZ_LAUNCH((k_dc_fft_f<PL>), (unsigned)g, wpb * kWave, lds, st, T, npix, nt, in, reinterpret_cast<cx *>(spec));
+}
+
 void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const float *in, c32 *spec)
 {
+    // THZ_DC_FFT_OLD=1 (developer knob, A/B runs): the generic LDS transform for every padded length
+    static const bool old_form = getenv("THZ_DC_FFT_OLD") != nullptr;
+    if (!old_form && P.f_t1 && P.f_t2 && P.f_w2n && nt <= P.nt) {  // the F core's tables came with the plan
+        switch (P.nt) {
+        case 4096: launch_dc_fft_f<FPlan4096>(st, P, npix, nt, in, spec); return;
+        case 2048: launch_dc_fft_f<FPlan2048>(st, P, npix, nt, in, spec); return;
+        case 1024: launch_dc_fft_f<FPlan1024>(st, P, npix, nt, in, spec); return;
+        default: break;
+        }
+    }
     unsigned grid, block;
     size_t lds;
     wave_launch_geometry(P, npix, &grid, &block, &lds);
@@ -3090,7 +3189,7 @@ void launch_dc_energy(hipStream_t st, const PlanDev &P, size_t npix, int nt, int
 bool dc_energy_pv_supported(size_t M, int n_taps)
 {
     const int s = (n_taps - 1) / 2;
-    return (n_taps & 1) && s >= 1 && 2 * s - 1 <= 512 && (M == 1024 || M == 2048 || M == 4096);
+    return (n_taps & 1) && s >= 1 && 2 * s - 1 <= 512 && (M == 1024 || M == 2048 || M == 4096 || M == 8192 || M == 16384);
 }
 
 void launch_dc_pv_tables(hipStream_t st, int n_bands, int nk, int gstride, size_t M, const c32 *H, const c32 *hht, float *g,
@@ -3137,6 +3236,9 @@ void launch_dc_energy_pv(hipStream_t st, const DcPvTables &Tb, size_t npix, int 
         case 513: launch_dc_energy_pv_n<2, 4>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
         case 1025: launch_dc_energy_pv_n<4, 4>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
         case 2049: launch_dc_energy_pv_n<8, 2>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
+        // padded lengths without an F core (nt > 3598): the edges do not depend on M, the Parseval sums only read more bins
+        case 4097: launch_dc_energy_pv_n<16, 1>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
+        case 8193: launch_dc_energy_pv_n<32, 1>(st, T, npix, nt, n_bands, shift, nk, in, spec, energy); return;
         default: break;
         }
     fprintf(stderr, "thzgpu: launch_dc_energy_pv: no kernel for %d bins, row stride %d (dc_energy_pv_supported, dc_pv_gstride)\n",
