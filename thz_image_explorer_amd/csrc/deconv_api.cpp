@@ -276,7 +276,9 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
     if (PL.M != M && phase != 2 && phase != 4) {
         if (PL.d_tw) (void)hipFree(PL.d_tw);
         PL = thz_ctx::DcPlan{};
-        if (M > 16384 || !build_plan(M, PL.H, true))  // with the F core's tables where M has them (band energies)
+        // (M = 16384: the generic recombination's three LDS buffers are 192 KiB — its launch was refused with
+        // "invalid argument" — so traces of more than 7694 samples are refused here, by name)
+        if (M > 8192 || !build_plan(M, PL.H, true))  // with the F core's tables where M has them (band energies)
             return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: trace too long for the FIR transform");
         PlanHost &H = PL.H;
         std::vector<c32> pack(H.tw);

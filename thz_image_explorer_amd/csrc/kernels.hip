@@ -1299,28 +1299,30 @@ __global__ __launch_bounds__(256) void k_dc_energy_full(DcPvDev T, size_t npix, 
     }
 }
 
-constexpr int kDcPvWaves = 8;
+template <int W>
 struct DcPvLds {
     using PL = FPlan1024;
     static constexpr int TAB_ENTRIES = 2 * PL::N;                       // cx units: a band's 512 {Hp, Hm}
-    static constexpr int TAB_UNITS = TAB_ENTRIES / 2;                   // 16-byte units = threads of a block
-    static constexpr int TAB_OFF = PL::T1_ENTRIES + PL::T2_ENTRIES + kDcPvWaves * PL::WAVE_ENTRIES;
+    static constexpr int TAB_UNITS = TAB_ENTRIES / 2;                   // 16-byte units
+    static constexpr int UNITS = TAB_UNITS / (W * 64);                  // ... per thread
+    static constexpr int TAB_OFF = PL::T1_ENTRIES + PL::T2_ENTRIES + W * PL::WAVE_ENTRIES;
     static constexpr size_t bytes() { return (size_t)(TAB_OFF + 2 * TAB_ENTRIES) * sizeof(cx); }
-    static_assert(TAB_OFF % 2 == 0 && TAB_UNITS == kDcPvWaves * 64, "16-byte units, one per thread");
+    static_assert(TAB_OFF % 2 == 0 && UNITS * W * 64 == TAB_UNITS, "16-byte units, the same number for every thread");
 };
 
 // SHIFT: the edges' length as a compile-time number (249 for the reference's 499 taps: which of a lane's eight output
 // samples are head, tail or neither is then known per j, only j = 3 and j = 7 keep a lane test), or 0: run-time `shift`
-template <int SHIFT>
-__global__ __launch_bounds__(kDcPvWaves * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edges(DcPvDev T, size_t npix, int nt,
-                                                                                           int n_bands, int shift_rt,
-                                                                                           const float *__restrict__ in,
-                                                                                           float *__restrict__ energy)
+// W: waves (= pixels) per block, 8 or 4
+template <int SHIFT, int W>
+__global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edges(DcPvDev T, size_t npix, int nt,
+                                                                                  int n_bands, int shift_rt,
+                                                                                  const float *__restrict__ in,
+                                                                                  float *__restrict__ energy)
 {
     using PL = FPlan1024;
-    using L = DcPvLds;
+    using L = DcPvLds<W>;
     THZ_DYN_LDS(lds);
-    constexpr int R1 = PL::R1, NC = PL::N, W = kDcPvWaves;
+    constexpr int R1 = PL::R1, NC = PL::N, U = L::UNITS;
     static_assert(PL::C1 == 1 && NC == 512 && R1 == 8, "edge transform: 512 complex points, one column per lane");
     const int shift = SHIFT > 0 ? SHIFT : shift_rt;
     const int lane = lane_id();
@@ -1332,10 +1334,14 @@ __global__ __launch_bounds__(kDcPvWaves * 64) THZ_WAVES_PER_SIMD(4) void k_dc_en
     cx *tab = t1 + L::TAB_OFF;
     for (int i = tid; i < PL::T1_ENTRIES; i += W * kWave) t1[i] = T.t1[i];
     for (int i = tid; i < PL::T2_ENTRIES; i += W * kWave) t2[i] = T.t2[i];
-    const float4 *hsrc = reinterpret_cast<const float4 *>(T.hpm) + tid;  // a band's row: 512 16-byte units, one per thread
+    const float4 *hsrc = reinterpret_cast<const float4 *>(T.hpm) + tid;  // a band's row: 512 16-byte units, U per thread
     float4 *hdst = reinterpret_cast<float4 *>(tab) + tid;
-    float4 stage = hsrc[0];
-    hdst[0] = stage;
+    float4 stage[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        stage[i] = hsrc[W * kWave * i];
+        hdst[W * kWave * i] = stage[i];
+    }
     FAddr<PL> ad;
     ad.init(lane);
     const int sba = nat(lane), sbb = nat(kWave + lane) - kWave;  // nat(64 j + lane) - 64 j for even / odd j
@@ -1350,7 +1356,10 @@ __global__ __launch_bounds__(kDcPvWaves * 64) THZ_WAVES_PER_SIMD(4) void k_dc_en
         for (int b = 0; b < n_bands; ++b, ++t) {
             __syncthreads();  // this band's row is in tab[t & 1]; nobody reads the other half any more
             const bool more = !(last_batch && b + 1 == n_bands);
-            if (more) stage = hsrc[(size_t)(b + 1 < n_bands ? b + 1 : 0) * NC];
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) stage[i] = hsrc[(size_t)(b + 1 < n_bands ? b + 1 : 0) * NC + W * kWave * i];
+            }
             const cx *tb = tab + (size_t)(t & 1u) * L::TAB_ENTRIES;
             if (live) {
                 float full = 0.0f;
@@ -1409,7 +1418,10 @@ __global__ __launch_bounds__(kDcPvWaves * 64) THZ_WAVES_PER_SIMD(4) void k_dc_en
                 if (lane == 0) energy[(size_t)b * npix + p] = full - acc;
                 wave_sync();
             }
-            if (more) hdst[(size_t)((t + 1u) & 1u) * L::TAB_UNITS] = stage;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) hdst[(size_t)((t + 1u) & 1u) * L::TAB_UNITS + W * kWave * i] = stage[i];
+            }
         }
     }
 }
@@ -3211,17 +3223,21 @@ static void launch_dc_energy_pv_n(hipStream_t st, const DcPvDev &T, size_t npix,
         THZ_LAUNCH((k_dc_energy_full<NG, PX>), (unsigned)g, 256, 0, st, T, npix, n_bands, nk, reinterpret_cast<const cx *>(spec),
                    energy);
     }
-    const size_t lds = DcPvLds::bytes();
-    size_t per_cu = kLdsBytesPerCU / lds;
-    if (per_cu > 2) per_cu = 2;  // sixteen waves per CU: the kernel is compiled for four per SIMD
-    size_t g = (npix + kDcPvWaves - 1) / kDcPvWaves;
-    if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+    // THZ_DC_EDGE_WAVES=4 (developer knob): blocks of four waves, four per CU, instead of eight-wave blocks, two per CU
+    static const bool four = [] { const char *e = getenv("THZ_DC_EDGE_WAVES"); return e && e[0] == '4'; }();
+    auto go = [&](auto kernel, int waves) {
+        const size_t lds = waves == 8 ? DcPvLds<8>::bytes() : DcPvLds<4>::bytes();
+        const size_t per_cu = 16 / waves;  // sixteen waves per CU: the kernel is compiled for four per SIMD
+        size_t g = (npix + waves - 1) / waves;
+        if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+        allow_dynamic_lds(kernel, lds);
+        THZ_LAUNCH(kernel, (unsigned)g, (unsigned)(waves * kWave), lds, st, T, npix, nt, n_bands, shift, in, energy);
+    };
     if (shift == 249) {
-        allow_dynamic_lds(k_dc_energy_edges<249>, lds);
-        THZ_LAUNCH(k_dc_energy_edges<249>, (unsigned)g, kDcPvWaves * kWave, lds, st, T, npix, nt, n_bands, shift, in, energy);
+        if (four) go(k_dc_energy_edges<249, 4>, 4);
+        else go(k_dc_energy_edges<249, 8>, 8);
     } else {
-        allow_dynamic_lds(k_dc_energy_edges<0>, lds);
-        THZ_LAUNCH(k_dc_energy_edges<0>, (unsigned)g, kDcPvWaves * kWave, lds, st, T, npix, nt, n_bands, shift, in, energy);
+        go(k_dc_energy_edges<0, 8>, 8);
     }
 }
 
