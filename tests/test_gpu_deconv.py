@@ -186,7 +186,9 @@ def test_deconvolution_abort_and_progress(engine):
 
 def test_untiled_fallback_matches_tiled(engine, monkeypatch):
     """PSFs too wide for an LDS tile take k_rl_step (every tap from L2); forced here with the developer knob:
-    narrow kernels (the reference's direct sums) must agree bit for bit, wide ones within rounding"""
+    narrow kernels in the reference's own order of every sum (THZ_RL_NARROW_EXACT: k_rl_step_tiled<false>, the
+    reference's direct sums) must agree bit for bit, wide ones within rounding"""
+    monkeypatch.setenv("THZ_RL_NARROW_EXACT", "1")
     z = np.load(os.path.join(GOLD, "psf_sample.npz"))
     psf = pkg.psf_from_npz(z)
     for case in (dict(nx=32, ny=32, nt=256, d=0.5, cfg=pkg.DeconvCfg(10, 4, 0.8, 3.0, 0.5), exact=True),
@@ -244,6 +246,39 @@ def test_separable_wide_kernels_match_the_2d_sums(engine, monkeypatch):
     assert not np.array_equal(res[0][1], res[1][1])          # two different kernels did run
     assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < 5e-6
     assert np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max() < 5e-6
+    d_in.free(); d_out.free(); d_g.free()
+
+
+def test_narrow_kernels_as_two_passes_match_the_reference_order_sums(engine, monkeypatch):
+    """kernels of <= 256 taps are the reference's direct sums (deconvolution.rs:432-458, a correlation, m outer / n
+    inner); by default they run as the same two 1-D passes as the wide ones (mode 0 of k_rl_step_sep: profiles the other
+    way round), THZ_RL_NARROW_EXACT=1 keeps the reference's order of every sum — the two agree within rounding,
+    through 40 iterations on every band, and both are within the end-to-end bar of the oracle"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf, opsf = pkg.psf_from_npz(z), ob.psf_from_npz(z)
+    nx, ny, nt, d = 40, 36, 256, 0.5
+    cfg = pkg.DeconvCfg(40, 5, 0.8, 3.0, 0.5)
+    time, cube = _bar_target_cube(nx, ny, nt)
+    sizes = [pkg.host_band_psf(psf, f, d, d, nx, ny).shape for f in pkg.host_filter_bank(time, cfg)[1]]
+    assert all(a * b <= 256 and a % 2 == 1 and b % 2 == 1 for a, b in sizes) and len(set(sizes)) > 1
+    engine.set_time_axis(time)
+    d_in = engine.to_device(cube); d_out = engine.empty((nx * ny, nt)); d_g = engine.empty((5, nx * ny))
+    res = []
+    for knob in (None, "1"):
+        if knob:
+            monkeypatch.setenv("THZ_RL_NARROW_EXACT", knob)
+        else:
+            monkeypatch.delenv("THZ_RL_NARROW_EXACT", raising=False)
+        assert engine.deconvolve(psf, cfg, nx, ny, d, d, d_in, d_out, None, d_g) == 0
+        res.append((d_out.download((nx, ny, nt), np.float32), d_g.download((5, nx, ny), np.float32)))
+    monkeypatch.delenv("THZ_RL_NARROW_EXACT", raising=False)
+    assert not np.array_equal(res[0][1], res[1][1])          # two different kernels did run
+    assert np.abs(res[0][0] - res[1][0]).max() / np.abs(res[1][0]).max() < 2e-6
+    assert np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max() < 2e-6
+    rc, oref, oimg, og, onit = ob.deconvolution(cube, time, d, d, opsf, 40, 5, 0.8, 3.0, 0.5)
+    for out, g in res:
+        assert np.abs(out - oref).max() / np.abs(oref).max() < 1e-5
+        assert np.abs(g - og).max() / np.abs(og).max() < 1e-5
     d_in.free(); d_out.free(); d_g.free()
 
 

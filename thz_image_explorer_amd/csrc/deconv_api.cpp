@@ -428,6 +428,12 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
     // the band PSFs are outer products of two profiles: their wide kernels run as two 1-D passes (k_rl_step_sep);
     // THZ_RL_NO_SEPARABLE (developer knob, for A/B timing) keeps the 2-D sums of k_rl_step_tiled<true>
     const bool separable = getenv("THZ_RL_NO_SEPARABLE") == nullptr;
+    // ... and so do the narrow ones (<= 256 taps, the reference's direct sums) unless THZ_RL_NARROW_EXACT is set: the same
+    // sums in another order (pr + pc multiply-adds per pixel instead of pr pc, tiles of 32 x 32 pixels), equal to the
+    // reference's to rounding and inside the 1e-5 of the end-to-end tests; with the knob the reference's own order of
+    // every sum, bit for bit (k_rl_step_tiled<false>)
+    const bool narrow_sep = separable && getenv("THZ_RL_NARROW_EXACT") == nullptr;
+    std::vector<char> sep_band((size_t)nbs, 0);
     for (int b = 0; b < nbs; ++b) {
         psfs[(size_t)b] = band_psf(*psf, centers[(size_t)b], dx, dy, (int)nx, (int)ny);
         const BandPsf &bp = psfs[(size_t)b];
@@ -443,11 +449,14 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
         if (B.n_iter > max_iter) max_iter = B.n_iter;
         B.blk0 = blk;
         blk += (unsigned)(((size_t)B.H * B.W + 255) / 256);
-        const int tile_kind = separable && B.mode != 0 ? kRlSeparable : kRlNarrow;
+        const bool sep_b = separable && (B.mode != 0 || (narrow_sep && (int)bp.fx.size() == bp.rows && (int)bp.fy.size() == bp.cols
+                                                           && (bp.rows & 1) && (bp.cols & 1)));
+        sep_band[(size_t)b] = sep_b;
+        const int tile_kind = sep_b ? kRlSeparable : kRlNarrow;
         const int tile_rows = rl_tile_rows(tile_kind), tile_cols = rl_tile_cols(tile_kind);
         B.tiles_w = (B.W + tile_cols - 1) / tile_cols;
         B.n_tiles = B.tiles_w * ((B.H + tile_rows - 1) / tile_rows);
-        tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc, separable && B.mode != 0));
+        tile_lds = std::max(tile_lds, rl_tile_lds_bytes(B.pr, B.pc, sep_b));
         const size_t img = (size_t)B.H * B.W;
         B.off_d = (unsigned)ws_floats; ws_floats += img;
         B.off_u = (unsigned)ws_floats; ws_floats += img;
@@ -489,10 +498,15 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
     std::vector<TileList> lists;
     {
         std::vector<int> wide_bands, narrow_bands;
-        for (int b = 0; b < nbs; ++b) (bands[(size_t)b].mode != 0 ? wide_bands : narrow_bands).push_back(b);
+        // narrow bands that run as two 1-D passes keep a chain of their own (their tile list is long and short-lived: at
+        // 512 x 512 pixels 18 bands x 304 tiles, most of which have left after 25 iterations)
+        std::vector<int> narrow_sep_bands;
+        for (int b = 0; b < nbs; ++b)
+            (bands[(size_t)b].mode != 0 ? wide_bands : sep_band[(size_t)b] ? narrow_sep_bands : narrow_bands).push_back(b);
         auto by_iter = [&](int a, int c) { return bands[(size_t)a].n_iter > bands[(size_t)c].n_iter; };
         std::stable_sort(wide_bands.begin(), wide_bands.end(), by_iter);
         std::stable_sort(narrow_bands.begin(), narrow_bands.end(), by_iter);
+        std::stable_sort(narrow_sep_bands.begin(), narrow_sep_bands.end(), by_iter);
         const bool split_wide = getenv("THZ_RL_SPLIT_WIDE") != nullptr;  // developer knob, for A/B timing
         const size_t cut[3] = {split_wide ? 1 : wide_bands.size(), 3, wide_bands.size()};
         size_t at = 0;
@@ -505,10 +519,18 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
             lists.push_back(L);
             at = end;
         }
-        if (!narrow_bands.empty()) {
+        if (!narrow_sep_bands.empty()) {
+            TileList L;
+            L.kind = kRlSeparable;
+            L.order = narrow_sep_bands;
+            lists.push_back(L);
+        }
+        if (!narrow_bands.empty() && lists.size() < (size_t)kRlChains) {
             TileList L;
             L.order = narrow_bands;
             lists.push_back(L);
+        } else if (!narrow_bands.empty()) {
+            return fail(ctx, THZ_ERR_UNSUPPORTED, "thz_deconvolve: more chains than streams (THZ_RL_SPLIT_WIDE with mixed narrow bands)");
         }
     }
     static_assert(kRlChains >= 4, "three wide chains and the narrow one");

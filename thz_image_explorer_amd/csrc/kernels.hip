@@ -1984,8 +1984,13 @@ __global__ __launch_bounds__(NT, 8) void k_rl_step_sep(const RlTileRef *__restri
     // the profiles (step 0 convolves with the PSF: reversed profiles in this upward walk; step 1 with its mirror
     // image), the update's other operand, which does not depend on the sums, and then the halo.
     float fy_v = 0.0f, fx_v = 0.0f, other[kRlPix] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (px < pc) fy_v = fy[step == 0 ? pc - 1 - px : px];
-    if (px < pr) fx_v = fx[step == 0 ? pr - 1 - px : px];
+    // mode 1 (the reference's "same" convolution) walks the kernel downwards: step 0 takes the profiles reversed in this
+    // upward walk, step 1 (the mirrored PSF) as they are.  Mode 0 (the reference's direct sums of kernels of <= 256 taps,
+    // a[i + m - pr/2][j + n - pc/2] k[m][n]: a correlation) is the other way round — for the odd sizes every band PSF
+    // has, correlating with k is convolving with its mirror image over the same halo.
+    const bool rev = (step == 0) == (B.mode != 0);
+    if (px < pc) fy_v = fy[rev ? pc - 1 - px : px];
+    if (px < pr) fx_v = fx[rev ? pr - 1 - px : px];
     if (col_task && j < B.W) {
         const unsigned o_off = step == 0 ? B.off_d : B.off_u;
 #pragma unroll
@@ -2037,8 +2042,8 @@ __global__ __launch_bounds__(NT, 8) void k_rl_step_sep(const RlTileRef *__restri
         if (px < nch * kRlChunk) fy_s[px] = fy_v;
         if (px < nchr * kRlChunk) fx_s[px] = fx_v;  // zeros behind the profile: whole chunks of taps
         for (int n = px + NT; n < nch * kRlChunk; n += NT)  // profiles of more than 1 024 taps
-            fy_s[n] = n < pc ? fy[step == 0 ? pc - 1 - n : n] : 0.0f;
-        for (int m = px + NT; m < nchr * kRlChunk; m += NT) fx_s[m] = m < pr ? fx[step == 0 ? pr - 1 - m : m] : 0.0f;
+            fy_s[n] = n < pc ? fy[rev ? pc - 1 - n : n] : 0.0f;
+        for (int m = px + NT; m < nchr * kRlChunk; m += NT) fx_s[m] = m < pr ? fx[rev ? pr - 1 - m : m] : 0.0f;
         // what a column window of pass B reaches behind the last halo row is multiplied by those zero taps: finite
         for (int n = px; n < kRlSepTileCols * (hsp - hs); n += NT) t_s[(n / (hsp - hs)) * hsp + hs + n % (hsp - hs)] = 0.0f;
     }
