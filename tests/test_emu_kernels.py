@@ -419,6 +419,34 @@ def test_rl_step_separable_kernel(emu, case):
     assert es <= 2 * e2 + 1e-7 * np.abs(u64).max()
 
 
+@pytest.mark.parametrize("case", [dict(h=14, w=19, pr=7, pc=9), dict(h=9, w=41, pr=13, pc=17), dict(h=35, w=12, pr=3, pc=5),
+                                  dict(h=33, w=34, pr=15, pc=17)])
+def test_rl_step_separable_kernel_narrow_mode(emu, case):
+    """k_rl_step_sep in mode 0: a kernel of <= 256 taps — in the reference a direct sum, correlation-indexed
+    (deconvolution.rs:432-458) — that is an outer product, as the same two 1-D passes with the profiles the other way
+    round; against the reference-order kernels (which are the reference's loops bit for bit) within rounding, with
+    off-centre profiles so that a wrong direction in either step or either axis would show"""
+    h, w, pr, pc = (case[k] for k in ("h", "w", "pr", "pc"))
+    assert pr * pc <= 256 and pr % 2 == 1 and pc % 2 == 1
+    rng = np.random.default_rng(pr * 1000 + pc)
+    H, W = h + 2 * (pr // 2), w + 2 * (pc // 2)
+    d = (0.5 + rng.random((H, W))).astype(np.float32)
+    u = (0.5 + rng.random((H, W))).astype(np.float32)
+    x, y = np.arange(pr) - pr // 2, np.arange(pc) - pc // 2
+    fx = np.exp(-(x - 0.7) ** 2 / (2 * (pr / 5) ** 2)).astype(np.float32)
+    fy = np.exp(-(y + 1.3) ** 2 / (2 * (pc / 6) ** 2)).astype(np.float32)
+    psf = np.outer(fx, fy).astype(np.float32)
+    res = {}
+    for tiled in (1, 2):   # 1: k_rl_step_tiled<false> (reference order), 2: k_rl_step_sep
+        t, un = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+        assert emu.emu_rl_iteration_sep(h, w, pr, pc, 0, _p(psf), _p(fx), _p(fy), _p(d), _p(u), tiled, _p(t), _p(un)) == 0
+        res[tiled] = (t, un)
+    rt, ru = _rl_reference(d, u, psf, 0)
+    assert np.array_equal(res[1][0], rt) and np.array_equal(res[1][1], ru)
+    assert np.abs(res[2][0] - rt).max() / np.abs(rt).max() < 2e-6
+    assert np.abs(res[2][1] - ru).max() / np.abs(ru).max() < 4e-6
+
+
 def _conv_same_f64(a, k):
     """'same' linear convolution in float64: rows / columns [(b-1)/2, (b-1)/2 + a) of the full one"""
     from scipy.signal import convolve2d
