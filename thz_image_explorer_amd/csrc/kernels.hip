@@ -3050,7 +3050,9 @@ void launch_dc_fft(hipStream_t st, const PlanDev &P, size_t npix, int nt, const 
 // The recombination on the F core: per pixel the gain-weighted sum of the filter spectra is built in
 // registers (bin by bin in the spectrum's register layout), multiplied into the spectrum, and ONE
 // inverse transform gives the "same" slice of the output trace and its intensity.
-template <class PL>
+// PX pixels per wave share every band's row of H (round 3: at one pixel per wave the rows were 52 GB of L2 reads per
+// call at 512 x 512 pixels — 2.7 ms, which is what L2 delivers); the sums are packed FMAs over {re, im} pairs.
+template <class PL, int PX>
 __global__ __launch_bounds__(512) void k_dc_combine_f(FTables T, size_t npix, int nt, int n_bands, int shift,
                                                       const cx *__restrict__ spec, const cx *__restrict__ H,
                                                       const float *__restrict__ gain, float *__restrict__ out,
@@ -3077,42 +3079,55 @@ __global__ __launch_bounds__(512) void k_dc_combine_f(FTables T, size_t npix, in
     const int sb2 = (2 * lane) ^ (s2 & 2);
     const bool swap2 = (s2 & 1) != 0;
     const int sb1a = nat(lane), sb1b = nat(kWave + lane) - kWave;
-    for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
-        float hc[R1][2 * C1], hs[R1][2 * C1];
+    for (size_t p0 = ((size_t)blockIdx.x * wpb + wib) * PX; p0 < npix; p0 += (size_t)gridDim.x * wpb * PX) {
+        cx hc[PX][R1][C1];
+        float hc_nyq[PX], hs[R1][2 * C1];
 #pragma unroll
-        for (int j = 0; j < R1; ++j)
+        for (int q = 0; q < PX; ++q) {
+            hc_nyq[q] = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 2 * C1; ++i) hc[j][i] = 0.0f;
-        float hc_nyq = 0.0f;
+            for (int j = 0; j < R1; ++j)
+#pragma unroll
+                for (int c = 0; c < C1; ++c) hc[q][j][c] = cx{0.0f, 0.0f};
+        }
         f_load_spec<PL>(H, lane, hs);
         float h_nyq = H[N].x;
 #pragma unroll 1
         for (int b = 0; b < n_bands; ++b) {
-            const float g = gain[(size_t)b * npix + p];
+            float g[PX];
 #pragma unroll
-            for (int j = 0; j < R1; ++j)
+            for (int q = 0; q < PX; ++q) g[q] = gain[(size_t)b * npix + (p0 + q < npix ? p0 + q : p0)];
 #pragma unroll
-                for (int i = 0; i < 2 * C1; ++i) hc[j][i] += g * hs[j][i];
-            hc_nyq += g * h_nyq;
+            for (int q = 0; q < PX; ++q) {
+#pragma unroll
+                for (int j = 0; j < R1; ++j)
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) hc[q][j][c] += cx{g[q], g[q]} * cx{hs[j][2 * c], hs[j][2 * c + 1]};
+                hc_nyq[q] += g[q] * h_nyq;
+            }
             if (b + 1 < n_bands) {
                 f_load_spec<PL>(H + (size_t)(b + 1) * nf, lane, hs);
                 h_nyq = H[(size_t)(b + 1) * nf + N].x;
             }
         }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+        const size_t p = p0 + q;
+        if (p >= npix) break;  // wave-uniform
         f_load_spec<PL>(spec + p * nf, lane, hs);  // the pixel's spectrum
         const float x_nyq = spec[p * nf + N].x;
         ad.refresh();
 #pragma unroll
         for (int j = 0; j < R1; ++j) {
             if constexpr (C1 == 2) {
-                const cx e0 = cx_mul(cx{hs[j][0], hs[j][1]}, cx{hc[j][0], hc[j][1]});
-                const cx e1 = cx_mul(cx{hs[j][2], hs[j][3]}, cx{hc[j][2], hc[j][3]});
+                const cx e0 = cx_mul(cx{hs[j][0], hs[j][1]}, hc[q][j][0]);
+                const cx e1 = cx_mul(cx{hs[j][2], hs[j][3]}, hc[q][j][C1 - 1]);
                 st2(buf + sb2 + 2 * kWave * j, swap2 ? e1 : e0, swap2 ? e0 : e1);
             } else {
-                buf[((j & 1) ? sb1b : sb1a) + kWave * j] = cx_mul(cx{hs[j][0], hs[j][1]}, cx{hc[j][0], hc[j][1]});
+                buf[((j & 1) ? sb1b : sb1a) + kWave * j] = cx_mul(cx{hs[j][0], hs[j][1]}, hc[q][j][0]);
             }
         }
-        if (lane == 0) buf[N] = cx{x_nyq * hc_nyq, 0.0f};
+        if (lane == 0) buf[N] = cx{x_nyq * hc_nyq[q], 0.0f};
         wave_sync();
         cx r[C1][R1];
         f_inverse_input<PL, false>(buf, w2n_s, wg_s, nullptr, lane, r);
@@ -3145,6 +3160,7 @@ __global__ __launch_bounds__(512) void k_dc_combine_f(FTables T, size_t npix, in
             if (lane == 0) img[p] = acc;
         }
         wave_sync();
+        }
     }
 }
 
@@ -3277,13 +3293,24 @@ static void launch_dc_combine_f(hipStream_t st, const PlanDev &P, size_t npix, i
     size_t per_cu = kLdsBytesPerCU / lds;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
-    size_t g = (npix + wpb - 1) / wpb;
+    // pixels per wave: THZ_DC_COMBINE_PX (developer knob: 1, 2, 4); default by the plan's register budget
+    static const int px_env = [] { const char *e = getenv("THZ_DC_COMBINE_PX"); return e ? atoi(e) : 0; }();
+    constexpr int kDefaultPx = PL::N <= 1024 ? 2 : 1;
+    const int px = (px_env == 1 || px_env == 2 || px_env == 4) ? px_env : kDefaultPx;
+    size_t g = (npix + (size_t)wpb * px - 1) / ((size_t)wpb * px);
     if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
     FTables T{reinterpret_cast<const cx *>(P.f_t1), reinterpret_cast<const cx *>(P.f_t2),
               reinterpret_cast<const cx *>(P.f_w2n)};
-    allow_dynamic_lds(k_dc_combine_f<PL>, lds);
-    THZ_LAUNCH((k_dc_combine_f<PL>), (unsigned)g, wpb * kWave, lds, st, T, npix, nt, n_bands, shift,
-               reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), gain, out, img);
+    auto go = [&](auto kernel) {
+        allow_dynamic_lds(kernel, lds);
+        THZ_LAUNCH(kernel, (unsigned)g, wpb * kWave, lds, st, T, npix, nt, n_bands, shift,
+                   reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), gain, out, img);
+    };
+    if constexpr (PL::N <= 1024) {
+        if (px == 4) return go(k_dc_combine_f<PL, 4>);
+        if (px == 2) return go(k_dc_combine_f<PL, 2>);
+    }
+    go(k_dc_combine_f<PL, 1>);
 }
 
 void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
