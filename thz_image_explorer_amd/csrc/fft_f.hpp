@@ -383,8 +383,28 @@ __device__ __forceinline__ void f_core_pass1(cx (&r)[P::C1][P::R1], cx *buf, con
     wave_sync();
 }
 
-template <class P, bool PK = false>
-__device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr<P> &ad, int lane)
+// Pass 1 with the lane's twiddles W_N^(lane k1), k1 = 1 .. R1 - 1, already in registers (C1 = 1: they do not depend on
+// the transform; a kernel that runs many transforms per table load keeps them) — products through cx_mul_pk
+template <class P>
+__device__ __forceinline__ void f_core_pass1_regs(cx (&r)[1][P::R1], cx *buf, const cx (&tw)[P::R1], const FAddr<P> &ad)
+{
+    static_assert(P::C1 == 1, "one column per lane");
+    constexpr int R1 = P::R1, M1 = P::M1;
+    dftR<R1>(r[0]);
+    THZ_SCHED_FENCE();
+    buf[ad.w1[0]] = r[0][0];
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) {
+        buf[ad.w1[k1 & 3] + k1 * M1] = cx_mul_pk(r[0][k1], tw[k1]);  // = e1(k1, lane)
+        if ((k1 & 3) == 3) THZ_SCHED_FENCE();
+    }
+    wave_sync();
+}
+
+// KEEP (C3 = 1): the transform's outputs Z[lane + 64 k3] stay in `keep` instead of going to LDS in natural order — for
+// a consumer that only reduces over them
+template <class P, bool PK = false, bool KEEP = false>
+__device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr<P> &ad, int lane, cx (*keep)[P::R3] = nullptr)
 {
     constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, C2 = P::C2, C3 = P::C3;
     constexpr int M1 = P::M1;
@@ -432,6 +452,13 @@ __device__ __forceinline__ void f_core_pass23(cx *buf, const cx *t2, const FAddr
     // (k >> 5) & 3 = ((lane >> 5) + (off >> 5)) & 3, and (off >> 5) & 3 is 0 or 2
     const int nb0 = launder_v(lane ^ ((lane >> 5) & 3));
     const int nb1 = launder_v(lane ^ (((lane >> 5) + 2) & 3));
+    if constexpr (KEEP) {
+        static_assert(C3 == 1 && R1 * R2 == kWave, "outputs lane + 64 k3");
+        dftR<R3>(d[0]);
+#pragma unroll
+        for (int k3 = 0; k3 < R3; ++k3) (*keep)[k3] = d[0][k3];
+        return;  // every lane's reads of this pass are behind the wave_sync above: the buffer is free
+    }
 #pragma unroll
     for (int c3 = 0; c3 < C3; ++c3) {
         dftR<R3>(d[c3]);

@@ -1346,6 +1346,10 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
     ad.init(lane);
     const int sba = nat(lane), sbb = nat(kWave + lane) - kWave;  // nat(64 j + lane) - 64 j for even / odd j
     const size_t n_batches = (npix + W - 1) / W;
+    cx tw1[R1];  // W_512^(lane k1)
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) tw1[k1] = T.t1[k1 * PL::M1 + lane];
+    tw1[0] = cx{1.0f, 0.0f};
     cx za[R1], zb[R1];  // Z[k], conj Z[512 - k] at k = 64 j + lane
     unsigned t = 0;
     for (size_t q = blockIdx.x; q < n_batches; q += gridDim.x) {
@@ -1394,12 +1398,15 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
                     const cx w = cx_mul_pk(za[j], h.a) + cx_mul_pk(zb[j], h.b);
                     r[0][j] = cx{w.y, w.x};  // swapped in, swapped out: the inverse transform through the forward core
                 }
-                f_core_pass1<PL, false, true>(r, buf, t1, ad, lane);
-                f_core_pass23<PL, true>(buf, t2, ad, lane);
+                // the lane's pass-1 twiddles stay in registers across the bands, and the outputs never go to LDS: of the
+                // 39 KiB a band moved through LDS (the kernel's bound beside its VALU work) 11.5 less
+                cx outv[R1];
+                f_core_pass1_regs<PL>(r, buf, tw1, ad);
+                f_core_pass23<PL, true, true>(buf, t2, ad, lane, &outv);
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < R1; ++j) {
-                    const cx v = buf[((j & 1) ? sbb : sba) + kWave * j];  // {Im w[n], Re w[n]}, n = 64 j + lane
+                    const cx v = outv[j];  // {Im w[n], Re w[n]}, n = 64 j + lane
                     const int n = kWave * j + lane;
                     // with SHIFT known the j-th sample's range [64 j, 64 j + 63] settles most of these at compile time
                     const bool all_h = SHIFT > 0 && kWave * j + kWave - 1 < SHIFT, no_h = SHIFT > 0 && kWave * j >= SHIFT;
@@ -1416,7 +1423,6 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
                 }
                 acc = wave_reduce_add(acc);
                 if (lane == 0) energy[(size_t)b * npix + p] = full - acc;
-                wave_sync();
             }
             if (more) {
 #pragma unroll
