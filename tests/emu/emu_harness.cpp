@@ -248,6 +248,22 @@ extern "C" int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, 
     std::vector<c32> spec(npix * nk);
     launch_dc_fft(nullptr, D, npix, nt, in, spec.data());
     launch_dc_energy(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, energy);
+    if (use_f == 0 && dc_weight_spectra_supported(n_bands)) {
+        // the recombination of padded lengths without an F core as deconv_api.cpp runs it: the multiplier sum as a kernel of
+        // its own, then the generic transform alone; checked against the one-kernel form
+        std::vector<c32> y(npix * nk);
+        std::vector<float> out1(npix * (size_t)nt), img1(npix);
+        launch_dc_combine(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, gain, out1.data(), img1.data());
+        launch_dc_weight_spectra(nullptr, npix, npix, (int)nk, n_bands, spec.data(), (const c32 *)H, gain, y.data());
+        launch_dc_combine(nullptr, D, npix, nt, 0, shift, y.data(), nullptr, nullptr, out, img);
+        double worst = 0.0, top = 0.0;
+        for (size_t i = 0; i < out1.size(); ++i) {
+            worst = std::max(worst, (double)std::fabs(out1[i] - out[i]));
+            top = std::max(top, (double)std::fabs(out1[i]));
+        }
+        if (worst > 2e-6 * top) return -5;
+        return 0;
+    }
     launch_dc_combine(nullptr, D, npix, nt, n_bands, shift, spec.data(), (const c32 *)H, gain, out, img);
     return 0;
 }

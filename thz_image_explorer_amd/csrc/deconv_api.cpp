@@ -179,6 +179,30 @@ void dc_band_energies(thz_ctx *ctx, const PlanDev &P, size_t npix, int nt, int n
     launch_dc_energy(ctx->stream, P, npix, nt, nbs, shift, d_spec, d_H, d_energy);
 }
 
+// the recombination of npix traces: one launch where the padded length has an F core; elsewhere (M = 8192) the
+// multiplier sum as a kernel of its own into a scratch of at most 256 MiB, chunk by chunk, and the generic transform
+// behind it (THZ_DC_COMBINE_OLD, developer knob: everything in the generic kernel, as in rounds 1-3)
+int dc_recombine(thz_ctx *ctx, DevFree &mem, const PlanDev &P, size_t npix, int nt, int nbs, int shift, size_t nk,
+                 const c32 *d_spec, const c32 *d_H, const float *d_gain, float *d_out, float *d_img)
+{
+    if (dc_combine_has_f_core(P, nt, shift) || !dc_weight_spectra_supported(nbs) || getenv("THZ_DC_COMBINE_OLD")) {
+        launch_dc_combine(ctx->stream, P, npix, nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
+        return THZ_OK;
+    }
+    size_t chunk = ((size_t)256 << 20) / (nk * sizeof(c32));
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > npix) chunk = npix;
+    c32 *d_y = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_y, chunk * nk * sizeof(c32)));
+    for (size_t p0 = 0; p0 < npix; p0 += chunk) {
+        const size_t n = std::min(chunk, npix - p0);
+        launch_dc_weight_spectra(ctx->stream, n, npix, (int)nk, nbs, d_spec + p0 * nk, d_H, d_gain + p0, d_y);
+        launch_dc_combine(ctx->stream, P, n, nt, 0, shift, d_y, nullptr, nullptr, d_out + p0 * (size_t)nt,
+                          d_img ? d_img + p0 : nullptr);
+    }
+    return THZ_OK;
+}
+
 int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg, size_t nx, size_t ny,
                     float dx, float dy, const float *d_in, float *d_out, float *d_img,
                     float *d_gains_out, volatile const int *abort_flag, float *progress, const DcSplit *sp)
@@ -410,7 +434,7 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
         const thz_ctx::DcSlab &S = ctx->dc_slab;
         if (!S.d_spec || S.npix != npix_t || S.nk != nk || S.M != M)
             return fail(ctx, THZ_ERR_NOT_READY, "thz_dc_slab_combine: no spectra of this slab (thz_dc_slab_energies comes first)");
-        launch_dc_combine(ctx->stream, P, npix_t, (int)nt, nbs, shift, S.d_spec, d_H, sp->d_gain, d_out, d_img);
+        if (int rc = dc_recombine(ctx, mem, P, npix_t, (int)nt, nbs, shift, nk, S.d_spec, d_H, sp->d_gain, d_out, d_img)) return rc;
         if (int rc = check_launch(ctx)) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         tick("slab: recombination");
@@ -813,7 +837,8 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
     }
     tick("iterations");
     launch_dc_gain(ctx->stream, d_bands, nbs, npix, d_energy, d_ws, d_gain);
-    if (phase == 0) launch_dc_combine(ctx->stream, P, npix, (int)nt, nbs, shift, d_spec, d_H, d_gain, d_out, d_img);
+    if (phase == 0)
+        if (int rc = dc_recombine(ctx, mem, P, npix, (int)nt, nbs, shift, nk, d_spec, d_H, d_gain, d_out, d_img)) return rc;
     if (int rc = check_launch(ctx)) return rc;
     if (d_gains_out)
         HIP_TRY(ctx, hipMemcpyAsync(d_gains_out, d_gain, (size_t)nbs * npix * sizeof(float),

@@ -1432,6 +1432,49 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
     }
 }
 
+// Padded lengths without an F core (M = 8192: traces of 3599 .. 7694 samples): the recombination's multiplier sum as a
+// kernel of its own.  In k_dc_combine every pixel reads all n_bands rows of H from L2 (25 x 32 KiB at M = 8192) at one or
+// two waves per CU — 59 of the 79 ms of the call at 256 x 256 x 4000.  Here a block keeps a 256-bin slice of every
+// band's row in LDS and walks the pixels: y[p][k] = X[p][k] sum_b g_b[p] H_b[k]; k_dc_combine then only transforms
+// (n_bands = 0).
+constexpr int kDcWeightBins = 256;
+__global__ __launch_bounds__(256) void k_dc_weight_spectra(size_t npix, size_t gain_stride, int nk, int n_bands, unsigned gx,
+                                                           const cx *__restrict__ spec, const cx *__restrict__ H,
+                                                           const float *__restrict__ gain, cx *__restrict__ y)
+{
+    THZ_DYN_LDS(lds);
+    cx *h_s = reinterpret_cast<cx *>(lds);  // [n_bands][256]
+    // block -> (slice of bins, group of pixels): gx slices, gridDim.x / gx groups
+    const unsigned slice = blockIdx.x % gx, group = blockIdx.x / gx, groups = gridDim.x / gx;
+    const int k0 = (int)slice * kDcWeightBins;
+    for (int i = (int)threadIdx.x; i < n_bands * kDcWeightBins; i += (int)blockDim.x) {
+        const int b = i / kDcWeightBins, k = k0 + i % kDcWeightBins;
+        h_s[i] = k < nk ? H[(size_t)b * nk + k] : cx{0.0f, 0.0f};
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const int wib = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const int kl = k0 + 4 * lane;
+    for (size_t p = (size_t)group * wpb + wib; p < npix; p += (size_t)groups * wpb) {
+        cx x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = kl + c < nk ? spec[p * (size_t)nk + kl + c] : cx{0.0f, 0.0f};
+        cx hc[4] = {cx{0.0f, 0.0f}, cx{0.0f, 0.0f}, cx{0.0f, 0.0f}, cx{0.0f, 0.0f}};
+        const cx *hl = h_s + 4 * launder_v(lane);
+        for (int b = 0; b < n_bands; ++b) {
+            const float g = gain[(size_t)b * gain_stride + p];
+            const cx2 h01 = ld2(hl + b * kDcWeightBins), h23 = ld2(hl + b * kDcWeightBins + 2);
+            hc[0] += cx{g, g} * h01.a;
+            hc[1] += cx{g, g} * h01.b;
+            hc[2] += cx{g, g} * h23.a;
+            hc[3] += cx{g, g} * h23.b;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (kl + c < nk) y[p * (size_t)nk + kl + c] = cx_mul(x[c], hc[c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dc_combine(PlanDev P, size_t npix, int nt, int n_bands,
                                                     int shift, const c32 *__restrict__ spec,
                                                     const c32 *__restrict__ H,
@@ -1444,11 +1487,15 @@ __global__ __launch_bounds__(256) void k_dc_combine(PlanDev P, size_t npix, int 
     const int wib = (int)(threadIdx.x >> 6);
     const int wpb = (int)(blockDim.x >> 6);
     const int N = 1 << P.log2n;
-    c32 *X = reinterpret_cast<c32 *>(lds + (size_t)wib * (size_t)(3 * P.buf_entries) * sizeof(c32));
-    c32 *A = X + P.buf_entries;
+    // two buffers per wave; n_bands == 0: `spec` already holds X . sum_b g_b H_b (k_dc_weight_spectra), H and gain unused
+    c32 *A = reinterpret_cast<c32 *>(lds + (size_t)wib * (size_t)(2 * P.buf_entries) * sizeof(c32));
     c32 *B = A + P.buf_entries;
     for (size_t p = (size_t)blockIdx.x * wpb + wib; p < npix; p += (size_t)gridDim.x * wpb) {
         for (int k = lane; k <= N; k += kWave) {
+            if (n_bands == 0) {  // wave-uniform
+                A[k] = spec[p * (size_t)(N + 1) + k];
+                continue;
+            }
             c32 hc = c32{0.0f, 0.0f};
             for (int b = 0; b < n_bands; ++b) {
                 const float g = gain[(size_t)b * npix + p];
@@ -3332,9 +3379,33 @@ void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, in
     }
     unsigned grid, block;
     size_t lds;
-    dc_geometry(P, npix, 3, &grid, &block, &lds);
+    dc_geometry(P, npix, 2, &grid, &block, &lds);
     allow_dynamic_lds(k_dc_combine, lds);
     THZ_LAUNCH(k_dc_combine, grid, block, lds, st, P, npix, nt, n_bands, shift, spec, H, gain, out, img);
+}
+
+bool dc_combine_has_f_core(const PlanDev &P, int nt, int shift)
+{
+    return P.f_t1 && P.f_t2 && P.f_w2n && nt + shift <= P.nt && (P.nt == 4096 || P.nt == 2048 || P.nt == 1024);
+}
+
+bool dc_weight_spectra_supported(int n_bands) { return n_bands >= 1 && (size_t)n_bands * kDcWeightBins * sizeof(cx) <= 128 * 1024; }
+
+void launch_dc_weight_spectra(hipStream_t st, size_t npix, size_t gain_stride, int nk, int n_bands, const c32 *spec,
+                              const c32 *H, const float *gain, c32 *y)
+{
+    const size_t lds = (size_t)n_bands * kDcWeightBins * sizeof(cx);
+    const unsigned gx = (unsigned)((nk + kDcWeightBins - 1) / kDcWeightBins);
+    size_t per_cu = kLdsBytesPerCU / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    size_t gy = ((size_t)kNumCU * per_cu + gx - 1) / gx;
+    const size_t need = (npix + 3) / 4;
+    if (gy > need) gy = need;
+    if (gy < 1) gy = 1;
+    allow_dynamic_lds(k_dc_weight_spectra, lds);
+    THZ_LAUNCH(k_dc_weight_spectra, gx * (unsigned)gy, 256, lds, st, npix, gain_stride, nk, n_bands, gx,
+               reinterpret_cast<const cx *>(spec), reinterpret_cast<const cx *>(H), gain, reinterpret_cast<cx *>(y));
 }
 
 void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,

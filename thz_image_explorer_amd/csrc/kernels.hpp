@@ -99,6 +99,12 @@ void launch_dc_energy_pv(hipStream_t st, const DcPvTables &T, size_t npix, int n
                          const float *in, const c32 *spec, float *energy);
 void launch_dc_combine(hipStream_t st, const PlanDev &P, size_t npix, int nt, int n_bands, int shift,
                        const c32 *spec, const c32 *H, const float *gain, float *out, float *img);
+// padded lengths without an F core: y[p][k] = spec[p][k] sum_b gain[b gain_stride + p] H[b][k] as a kernel of its own
+// (H slices in LDS), after which launch_dc_combine with n_bands = 0 only transforms y
+bool dc_combine_has_f_core(const PlanDev &P, int nt, int shift);
+bool dc_weight_spectra_supported(int n_bands);
+void launch_dc_weight_spectra(hipStream_t st, size_t npix, size_t gain_stride, int nk, int n_bands, const c32 *spec,
+                              const c32 *H, const float *gain, c32 *y);
 void launch_rl_init(hipStream_t st, const RlBand *d_bands, int n_bands, unsigned total_blocks,
                     size_t npix, const float *energy, float *ws);
 // iteration = (it_base ? *it_base : 0) + iteration: a captured batch is replayed with a new base
