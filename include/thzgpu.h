@@ -382,7 +382,8 @@ int thz_host_band_psf(const thz_psf *psf, float center_freq, float dx, float dy,
  * reference's cancellable loops; *progress (may be NULL) is updated in [0,1].
  * Returns THZ_SKIPPED with out = in when one of the reference's guards applies
  * (empty PSF, image < 16x16, PSF wider than the image), THZ_ERR_ABORTED (out =
- * in) when aborted.  Blocking.  The call's device scratch (one padded spectrum
+ * in) when aborted, THZ_ERR_UNSUPPORTED for traces of more than 7694 samples
+ * (the FIR transform's padded length is at most 8192).  Blocking.  The call's device scratch (one padded spectrum
  * per pixel, the bands' images: ~0.6 KB x nt/1000 per pixel and band) and the
  * iteration graphs stay with the context for the next call of the same geometry and is released by a call of
  * another geometry or by thz_destroy.
