@@ -282,6 +282,35 @@ def test_narrow_kernels_as_two_passes_match_the_reference_order_sums(engine, mon
     d_in.free(); d_out.free(); d_g.free()
 
 
+def test_chain_scheduling_knobs_change_no_bit(engine, monkeypatch):
+    """how the Richardson-Lucy chains are laid over the streams — the chains behind the first started late
+    (THZ_RL_DELAY), every chain as a replayed graph over its whole tile list (THZ_RL_EXACT=0), plain launches
+    (THZ_NO_GRAPH) — is scheduling only: the bands never exchange anything, so every variant returns the same bits"""
+    z = np.load(os.path.join(GOLD, "psf_sample.npz"))
+    psf = pkg.psf_from_npz(z)
+    nx, ny, nt, d = 48, 40, 128, 1.0
+    cfg = pkg.DeconvCfg(100, 6, 0.25, 3.0, 0.5)    # more than two batches of 32 iterations, wide and narrow bands
+    time, cube = _bar_target_cube(nx, ny, nt)
+    sizes = [pkg.host_band_psf(psf, f, d, d, nx, ny).size for f in pkg.host_filter_bank(time, cfg)[1]]
+    assert min(sizes) <= 256 < max(sizes)
+    engine.set_time_axis(time)
+    d_in = engine.to_device(cube); d_out = engine.empty((nx * ny, nt)); d_g = engine.empty((6, nx * ny))
+    knobs = ({}, {"THZ_RL_DELAY": "2"}, {"THZ_RL_EXACT": "0"}, {"THZ_NO_GRAPH": "1"}, {"THZ_RL_DELAY": "1", "THZ_RL_NARROW_EXACT": "1"})
+    res = []
+    for kn in knobs:
+        for k, v in kn.items():
+            monkeypatch.setenv(k, v)
+        assert engine.deconvolve(psf, cfg, nx, ny, d, d, d_in, d_out, None, d_g) == 0
+        res.append((d_out.download((nx, ny, nt), np.float32), d_g.download((6, nx, ny), np.float32)))
+        for k in kn:
+            monkeypatch.delenv(k, raising=False)
+    for out, g in res[1:4]:
+        assert np.array_equal(out, res[0][0]) and np.array_equal(g, res[0][1])
+    # the reference-order narrow sums are another kernel: equal within rounding, not bit for bit
+    assert np.abs(res[4][0] - res[0][0]).max() / np.abs(res[0][0]).max() < 2e-6
+    d_in.free(); d_out.free(); d_g.free()
+
+
 def test_repeated_calls_reuse_and_release_device_blocks():
     """the call's device blocks, iteration graphs, FIR bank, transform tables and filter spectra stay in the context for
     the next call (ctx.hpp: dc_pool, dc_graph, dc_bank, dc_plan, dc_spectra): a second call of the same geometry, a
