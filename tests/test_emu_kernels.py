@@ -486,7 +486,7 @@ def test_deconvolution_transform_kernels(emu, M, nt):
 
 @pytest.mark.parametrize("M,nt,kind", [(1024, 300, "pulse"), (2048, 1001, "pulse"), (2048, 1001, "noise"),
                                        (2048, 1001, "edges"), (4096, 2000, "pulse"), (1024, 100, "noise"),
-                                       (8192, 4000, "pulse"), (16384, 8000, "noise")])
+                                       (8192, 4000, "pulse"), (16384, 8000, "noise"), (2048, 1001, "middle")])
 def test_deconvolution_band_energies_parseval_form(emu, M, nt, kind):
     """k_dc_energy_pv: band energies over the 'same' slice as Parseval's sum over |X|^2 c_k M |H_b|^2 minus the
     energies of the first / last 249 samples of the full convolution (one 512-point complex transform per band),
@@ -499,6 +499,11 @@ def test_deconvolution_band_energies_parseval_form(emu, M, nt, kind):
         x = synth.make_traces(np.arange(npix) + 3, max(nt, 320))[:, :nt].astype(np.float32)
     elif kind == "noise":
         x = rng.standard_normal((npix, nt)).astype(np.float32)
+    elif kind == "middle":   # nothing in the first / last 249 samples: no edges to subtract (the kernel skips their transforms)
+        x = rng.standard_normal((npix, nt)).astype(np.float32)
+        x[:, :260] = 0.0
+        x[:, -255:] = 0.0
+        x[0, 250] = 0.0; x[1, :] = 0.0   # ... and a trace that is zero altogether
     else:
         x = np.zeros((npix, nt), np.float32)
         x[:, :5] = rng.standard_normal((npix, 5))
@@ -514,6 +519,8 @@ def test_deconvolution_band_energies_parseval_form(emu, M, nt, kind):
     assert rc == 0
     err = np.abs(en - e_ref).max() / e_ref.max()
     assert err < 5e-6, err
+    if kind == "middle":
+        assert np.all(en[:, 1] == 0.0)
     # against the kernel it replaces (same forward transform, same f32 filter spectra)
     Hs = np.fft.rfft(h.astype(np.float64), M, axis=-1) / M
     H = np.stack([Hs.real, Hs.imag], -1).astype(np.float32)

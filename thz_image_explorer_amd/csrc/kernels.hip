@@ -1351,6 +1351,7 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
     for (int k1 = 1; k1 < R1; ++k1) tw1[k1] = T.t1[k1 * PL::M1 + lane];
     tw1[0] = cx{1.0f, 0.0f};
     cx za[R1], zb[R1];  // Z[k], conj Z[512 - k] at k = 64 j + lane
+    bool edges_nz = true;
     unsigned t = 0;
     for (size_t q = blockIdx.x; q < n_batches; q += gridDim.x) {
         const size_t p = q * W + (size_t)wib;
@@ -1367,28 +1368,36 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
             const cx *tb = tab + (size_t)(t & 1u) * L::TAB_ENTRIES;
             if (live) {
                 float full = 0.0f;
-                if (lane == 0) full = energy[(size_t)b * npix + p];  // what k_dc_energy_full stored
+                if (lane == 0 && (b == 0 || edges_nz)) full = energy[(size_t)b * npix + p];  // what k_dc_energy_full stored
                 if (b == 0) {
                     // ---- Z = FFT_512(xh + i xt): xh[n] = x[n], xt[n] = x[nt - s + n], n < s
                     const float *x = in + p * (size_t)nt;
                     ad.refresh();
                     cx r[1][R1];
+                    float nzf = 0.0f;
 #pragma unroll
                     for (int j = 0; j < R1; ++j) {
                         const int n = kWave * j + lane, m = nt - shift + n;
                         const float xa = (n < shift && n < nt) ? x[n] : 0.0f;
                         const float xb = (n < shift && m >= 0) ? x[m] : 0.0f;
                         r[0][j] = cx{xa, xb};
+                        nzf += (xa != 0.0f || xb != 0.0f) ? 1.0f : 0.0f;
                     }
-                    f_core_pass1<PL>(r, buf, t1, ad, lane);
-                    f_core_pass23<PL>(buf, t2, ad, lane);
+                    // a trace whose first and last `shift` samples are all zero (a scan behind a time band pass narrower
+                    // than the trace) has no edges to subtract: every band's transform would return exact zeros
+                    edges_nz = wave_reduce_add(nzf) > 0.0f;  // wave-uniform
+                    if (edges_nz) {
+                        f_core_pass1<PL>(r, buf, t1, ad, lane);
+                        f_core_pass23<PL>(buf, t2, ad, lane);
 #pragma unroll
-                    for (int j = 0; j < R1; ++j) {
-                        za[j] = buf[((j & 1) ? sbb : sba) + kWave * j];
-                        zb[j] = cx_conj(buf[nat(NC - kWave * j - lane)]);
+                        for (int j = 0; j < R1; ++j) {
+                            za[j] = buf[((j & 1) ? sbb : sba) + kWave * j];
+                            zb[j] = cx_conj(buf[nat(NC - kWave * j - lane)]);
+                        }
+                        wave_sync();
                     }
-                    wave_sync();
                 }
+                if (edges_nz) {
                 ad.refresh();
                 cx r[1][R1];
                 const cx *hb = tb + 2 * launder_v(lane);
@@ -1423,6 +1432,7 @@ __global__ __launch_bounds__(W * 64) THZ_WAVES_PER_SIMD(4) void k_dc_energy_edge
                 }
                 acc = wave_reduce_add(acc);
                 if (lane == 0) energy[(size_t)b * npix + p] = full - acc;
+                }
             }
             if (more) {
 #pragma unroll
