@@ -25,6 +25,8 @@ int emu_rl_iteration_sep(int h, int w, int pr, int pc, int mode, const float *ps
                          const float *d, const float *u, int tiled, float *t_out, float *u_out);
 int emu_dc_chain(int M, int nt, size_t npix, int n_bands, int shift, const float *in, const float *H,
                  const float *gain, int use_f, float *energy, float *out, float *img);
+int emu_dc_energy_pv(int M, int nt, size_t npix, int n_bands, int n_taps, const float *in, const float *filters,
+                     float *energy);
 int emu_td_window(size_t npix, int nt, const float *in, const float *win, float *out);
 int emu_pixel_sum(size_t nrows, size_t L, const float *arr, float *out);
 int emu_gather_sum(const float *arr, size_t len, const uint32_t *list, uint32_t count, float div, float *out);
@@ -142,6 +144,19 @@ int main(int argc, char **argv)
                 std::vector<float> out2(npix * nt2);
                 emu_dc_chain(M2, nt2, npix, nb, 249, x2.data(), H2.data(), g.data(), 1, en.data(), out2.data(), img.data());
             }
+        }
+        {   // the band energies in Parseval form: the edges kernel's blocks walk the bands together and stage every band's
+            // row in LDS one band ahead (block barriers, two halves of a table); more pixels than one round of waves, a
+            // last round that is not full, a trace without edges (its transforms are skipped while the block goes on)
+            const int taps = 499, nb3 = 3, M3 = 2048, nt3 = 1001;
+            const size_t npix3 = 21;
+            auto x3 = noise(npix3 * nt3, 28), h3 = noise((size_t)nb3 * taps, 29, -0.05f, 0.05f);
+            for (int i = 0; i < nt3; ++i)
+                if (i < 260 || i >= nt3 - 260) x3[(size_t)5 * nt3 + i] = 0.0f;
+            std::vector<float> en3((size_t)nb3 * npix3);
+            emu_set_grid_cap(2);
+            emu_dc_energy_pv(M3, nt3, npix3, nb3, taps, x3.data(), h3.data(), en3.data());
+            emu_set_grid_cap(0);
         }
         std::printf("dc done\n");
     }

@@ -3304,6 +3304,7 @@ static void launch_dc_energy_pv_n(hipStream_t st, const DcPvDev &T, size_t npix,
         const size_t waves = (npix + PX - 1) / PX;
         size_t g = (waves + 3) / 4;
         if (g > (size_t)kNumCU * 8) g = (size_t)kNumCU * 8;
+        if (g_grid_cap_override > 0 && g > (size_t)g_grid_cap_override) g = (size_t)g_grid_cap_override;
         THZ_LAUNCH((k_dc_energy_full<NG, PX>), (unsigned)g, 256, 0, st, T, npix, n_bands, nk, reinterpret_cast<const cx *>(spec),
                    energy);
     }
@@ -3314,6 +3315,7 @@ static void launch_dc_energy_pv_n(hipStream_t st, const DcPvDev &T, size_t npix,
         const size_t per_cu = 16 / waves;  // sixteen waves per CU: the kernel is compiled for four per SIMD
         size_t g = (npix + waves - 1) / waves;
         if (g > (size_t)kNumCU * per_cu) g = (size_t)kNumCU * per_cu;
+        if (g_grid_cap_override > 0 && g > (size_t)g_grid_cap_override) g = (size_t)g_grid_cap_override;  // tests: several batches per block
         allow_dynamic_lds(kernel, lds);
         THZ_LAUNCH(kernel, (unsigned)g, (unsigned)(waves * kWave), lds, st, T, npix, nt, n_bands, shift, in, energy);
     };
