@@ -531,7 +531,16 @@ int deconvolve_impl(thz_ctx *ctx, const thz_psf *psf, const thz_deconv_cfg *cfg,
         std::stable_sort(wide_bands.begin(), wide_bands.end(), by_iter);
         std::stable_sort(narrow_bands.begin(), narrow_bands.end(), by_iter);
         std::stable_sort(narrow_sep_bands.begin(), narrow_sep_bands.end(), by_iter);
-        const bool split_wide = getenv("THZ_RL_SPLIT_WIDE") != nullptr;  // developer knob, for A/B timing
+        // The wide bands in three chains by iteration count ({b0}, {b1, b2}, the rest) when their tiles are many: every
+        // chain's launches then reserve the LDS of ITS widest kernel only (the 47 x 57 band's 42 KB put three blocks on a CU
+        // whatever band a block belongs to) and pick their block size by their own tile count.  Measured with the separable
+        // kernels, call in ms, one chain / three: 128 x 128 pixels 7.2 / 8.4, 256 x 256 11.7 / 11.6, 384 x 384 18.9 / 17.6,
+        // 512 x 512 27.5 / 25.8 (round 2's 2-D kernels at 128 x 128: 16.6 / 19.3) — so from 1024 wide tiles on.
+        // THZ_RL_SPLIT_WIDE=0 / 1 (developer knob) forces one / three.
+        size_t wide_tiles = 0;
+        for (int b : wide_bands) wide_tiles += (size_t)bands[(size_t)b].n_tiles;
+        const char *split_env = getenv("THZ_RL_SPLIT_WIDE");
+        const bool split_wide = split_env ? split_env[0] != '0' : wide_tiles >= 1024;
         const size_t cut[3] = {split_wide ? 1 : wide_bands.size(), 3, wide_bands.size()};
         size_t at = 0;
         for (size_t end : cut) {
